@@ -1,0 +1,85 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+for p in (ROOT, GOLDEN):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    def load(name):
+        z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+        return {k: z[k] for k in z.files}
+    return load
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(dtype) if dtype is not None else t
+
+
+def assert_close(got, want, rtol=1e-4, atol=1e-5, what=''):
+    got = got.detach().cpu().double() if isinstance(got, torch.Tensor) else torch.as_tensor(np.asarray(got)).double()
+    want = want.detach().cpu().double() if isinstance(want, torch.Tensor) else torch.as_tensor(np.asarray(want)).double()
+    assert got.shape == want.shape, f'{what}: shape {tuple(got.shape)} vs {tuple(want.shape)}'
+    fin = torch.isfinite(want)
+    assert torch.equal(fin, torch.isfinite(got)), f'{what}: non-finite pattern differs'
+    if fin.any():
+        err = (got[fin] - want[fin]).abs()
+        tol = atol + rtol * want[fin].abs()
+        bad = err > tol
+        assert not bad.any(), f'{what}: max err {err.max():.3e} (tol {tol[err.argmax()]:.3e}), {int(bad.sum())}/{bad.numel()} off'
+
+
+def check_summary(fx, prefix, tensor, rtol=1e-4, atol=1e-5, l2rel=None):
+    """Compare `tensor` with a weights.summarize() record stored under `prefix` in fixture dict fx.
+    l2rel: compare by relative L2 error of the whole record instead of elementwise (used for gradients of deep
+    compositions, which amplify 1e-7 input rounding to ~1e-3: see DESIGN.md "conditioning")."""
+    t = tensor.detach().cpu().to(torch.float32).contiguous().flatten()
+    if l2rel is not None:
+        if prefix + '.full' in fx:
+            want, got = T(fx[prefix + '.full']).double(), t.double()
+        else:
+            want = T(fx[prefix + '.sample']).double()
+            got = t[::int(fx[prefix + '.step'])][:want.numel()].double()
+        assert got.shape == want.shape, prefix
+        err = float((got - want).norm()) / max(float(want.norm()), 1e-12)
+        assert err <= l2rel or float((got - want).abs().max()) <= atol, f'{prefix}: rel-L2 err {err:.3e} > {l2rel:.1e}'
+        return
+    if prefix + '.full' in fx:
+        want = T(fx[prefix + '.full'])
+        assert_close(t, want, rtol, atol + rtol * float(want.double().pow(2).mean().sqrt()), prefix)
+    else:
+        step = int(fx[prefix + '.step'])
+        want = T(fx[prefix + '.sample'])
+        # gradients: elementwise tolerance is taken relative to the tensor's RMS as well as to each element
+        assert_close(t[::step][:want.numel()], want, rtol, atol + rtol * float(want.double().pow(2).mean().sqrt()), prefix)
+        l2 = float(fx[prefix + '.l2'])
+        assert abs(float(t.double().norm()) - l2) <= rtol * l2 + atol, prefix + ' l2'
+
+
+def check_param_grads(fx, base, named_grads, rtol=1e-4, atol=1e-5, key='gpar', l2rel=None):
+    """named_grads: dict name -> grad tensor or None; fixture keys '<base><key>.<name>.(full|sample|none)'."""
+    seen = 0
+    for name, g in named_grads.items():
+        p = f'{base}{key}.{name}'
+        if p + '.none' in fx:
+            assert g is None or float(g.abs().max()) == 0.0, f'{p}: reference has no grad'
+            continue
+        if p + '.full' not in fx and p + '.sample' not in fx:
+            continue
+        assert g is not None, f'{p}: missing grad'
+        check_summary(fx, p, g, rtol, atol, l2rel)
+        seen += 1
+    assert seen > 0, f'no gradient entries matched under {base}{key}'
