@@ -1,0 +1,145 @@
+/* tamtr_hip.h - C ABI of libtamtr_hip.so: hand-written CDNA4 (gfx950 / MI355X) kernels for the TAM-TR
+ * text-image attention hot path (BTA-PAN max-sigmoid text gate + MEH deformable-attention decoder).
+ *
+ * The reference (Xjh-UCAS/TAM-TR) is 100 % Python and has no FFI of its own; each entry point
+ * below therefore cites the reference *Python* interface whose arithmetic it replaces (paths relative to the
+ * reference root).  INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM), row-major/contiguous in the layout stated per function;
+ *   - `dtype`: element type of the activation tensors marked (T): TAMTR_F32 or TAMTR_BF16.  Index/offset/weight
+ *     side inputs and all accumulation are always fp32;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Functions only enqueue work: no
+ *     allocation, no synchronisation, no globals - they are safe to call from several host threads on different
+ *     streams and can be captured into a hipGraph;
+ *   - return value: 0 = enqueued; TAMTR_EINVAL (bad argument), TAMTR_EUNSUP (shape/dtype outside what the kernels
+ *     are built for), TAMTR_ELAUNCH (HIP reported a launch error).  Nothing is ever thrown across the ABI.
+ */
+#ifndef TAMTR_HIP_H
+#define TAMTR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAMTR_F32 0
+#define TAMTR_BF16 1
+
+#define TAMTR_OK 0
+#define TAMTR_EINVAL (-1)
+#define TAMTR_EUNSUP (-2)
+#define TAMTR_ELAUNCH (-3)
+
+/* ABI version, bumped on any signature change. */
+int tamtr_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * a-1  Max-sigmoid text gate.   Replaces the body of MaxSigmoidAttnBlock.forward,
+ *      ultralytics/nn/extra_modules/block.py:217-226 (dup ultralytics/nn/modules/block.py:672-681):
+ *          aw  = sigmoid( max_n( <x[b,m,:,p], gk[b,n,m,:]> ) / sqrt(hc) + bias[m] ) * scale
+ *          out = v * aw           (broadcast over the hc channels of head m)
+ *      x   (T) [B, nh*hc, HW]   NCHW feature map (embed == x: `ec` is None in every TAM-TR instance)
+ *      gk  f32 [B, T, nh*hc]    guide after the `gl` Linear (block.py:212-213)
+ *      bias f32 [nh]            scale: python float (1.0 in TAM-TR)
+ *      v   (T) [B, nh*hc, HW]   proj_conv(x) (Conv3x3+BN, block.py:223)
+ *      out (T) [B, nh*hc, HW]
+ *      aw  f32 [B, nh, HW]      saved gate (post-sigmoid, pre-scale)      } consumed by _bwd
+ *      arg i32 [B, nh, HW]      argmax text index per pixel and head      }
+ */
+int tamtr_maxsigmoid_gate_fwd(const void* x, const float* gk, const float* bias, const void* v, void* out, float* aw,
+                              int32_t* arg, int B, int nh, int hc, int HW, int T, float scale, int dtype, void* stream);
+
+/*      Backward of the above.  dout (T) [B,C,HW] ->
+ *      dx (T) [B,C,HW]    gradient through the embed operand (add to the conv's input gradient on the host side)
+ *      dv (T) [B,C,HW]    gradient of proj_conv's output
+ *      dlogit f32 [B,nh,HW]  d loss / d (max_n <x,gk>)  (host reduces it into dgk / dbias with one small batched GEMM)
+ */
+int tamtr_maxsigmoid_gate_bwd(const void* dout, const void* x, const float* gk, const void* v, const float* aw,
+                              const int32_t* arg, void* dx, void* dv, float* dlogit, int B, int nh, int hc, int HW, int T,
+                              float scale, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * a-6  Multi-scale deformable attention core.  Replaces multi_scale_deformable_attn_pytorch,
+ *      ultralytics/nn/modules/utils.py:42-89 (3x F.grid_sample(bilinear, zeros, align_corners=False) + weighted sum).
+ *      value (T) [B, L, M, D]           L = sum_l H_l*W_l, levels concatenated fine -> coarse
+ *      shapes i32 [nl, 2]  (HOST pointer) (H_l, W_l)
+ *      loc   f32 [B, Q, M, nl, P, 2]    sampling locations (x, y) in [0,1] image coordinates
+ *      aw    f32 [B, Q, M, nl, P]       attention weights (already softmaxed over nl*P)
+ *      out   (T) [B, Q, M*D]
+ *      D must be a multiple of 4 (f32) / 8 (bf16) and <= 256; nl <= 8.
+ */
+int tamtr_msdeform_attn_fwd(const void* value, const int32_t* shapes_host, const float* loc, const float* aw, void* out,
+                            int B, int L, int M, int D, int Q, int nl, int P, int dtype, void* stream);
+
+/*      Backward: gout (T) [B,Q,M*D] -> gvalue f32 [B,L,M,D] (ACCUMULATED with float atomics: caller zeroes it),
+ *      gloc f32 [B,Q,M,nl,P,2], gaw f32 [B,Q,M,nl,P].
+ */
+int tamtr_msdeform_attn_bwd(const void* gout, const void* value, const int32_t* shapes_host, const float* loc,
+                            const float* aw, float* gvalue, float* gloc, float* gaw, int B, int L, int M, int D, int Q,
+                            int nl, int P, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * a-8  Text-contrastive logits.  Replaces ContrastiveHeadMLP.forward, ultralytics/nn/modules/block.py:534-541:
+ *          logits[b,q,k] = < x[b,q,:]/max(|x|,1e-12), w[b,k,:]/max(|w|,1e-12) > * exp(logit_scale) + bias
+ *      x (T) [B,Q,C]; w f32 [B,K,C]; logit_scale, bias: f32 device scalars; logits f32 [B,Q,K];
+ *      xinv f32 [B,Q], winv f32 [B,K]: saved reciprocal norms (for _bwd).   C % 64 == 0, C <= 2048, K <= 128.
+ */
+int tamtr_contrastive_logits_fwd(const void* x, const float* w, const float* logit_scale, const float* bias, float* logits,
+                                 float* xinv, float* winv, int B, int Q, int K, int C, int dtype, void* stream);
+
+/*      Backward: g f32 [B,Q,K] -> dx (T) [B,Q,C], dwhat f32 [B,K,C] (ACCUMULATED: caller zeroes it; it is the gradient
+ *      w.r.t. the *normalised* text rows, the host projects it through the normalisation - a [B,K,C] elementwise op).
+ */
+int tamtr_contrastive_logits_bwd(const float* g, const void* x, const float* w, const float* logit_scale, const float* xinv,
+                                 const float* winv, void* dx, float* dwhat, int B, int Q, int K, int C, int dtype,
+                                 void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * a-5  MEH cross-attention value projection (the dominant dense contraction, M = B*L = 537 600 at 640^2 bs 16).
+ *      Replaces `value = self.value_proj(value)`, ultralytics/nn/modules/transformer.py:273 (nn.Linear(512,512)),
+ *      and any other y = x @ W^T + b of the head with N, K multiples of 128/64:
+ *          Y[M,N] = X[M,K] @ W[N,K]^T + bias[N]        bf16 in, fp32 MFMA accumulate, bf16 out
+ *      X bf16 [M,K] row-major, W bf16 [N,K] row-major (nn.Linear layout), bias f32 [N] or NULL, Y bf16 [M,N].
+ *      Requires K % 64 == 0, N % 128 == 0; any M >= 1.
+ */
+int tamtr_linear_bf16(const void* X, const void* W, const float* bias, void* Y, int M, int N, int K, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * a-7  Small-Q masked multi-head self-attention core.  Replaces the attention inside nn.MultiheadAttention as called
+ *      at ultralytics/nn/modules/transformer.py:546 (after the packed in-projection, before out_proj):
+ *          O[b,:,h,:] = softmax( Qh Kh^T / sqrt(dh) + mask ) Vh
+ *      q,k,v (T) [B, Q, nh, dh] (row stride nh*dh, i.e. views into the packed projection); mask u8 [Q,Q] or NULL
+ *      (1 = blocked); o (T) [B,Q,nh,dh]; lse f32 [B,nh,Q] saved log-sum-exp.  dh in {32, 64}, Q <= 1024.
+ */
+int tamtr_selfattn_fwd(const void* q, const void* k, const void* v, const uint8_t* mask, void* o, float* lse, int B, int Q,
+                       int nh, int dh, int dtype, void* stream);
+int tamtr_selfattn_bwd(const void* go, const void* q, const void* k, const void* v, const void* o, const float* lse,
+                       const uint8_t* mask, void* gq, void* gk, void* gv, int B, int Q, int nh, int dh, int dtype,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * a-9  Selective scan (S6), replacing the external CUDA extension selective_scan_cuda_core.fwd/bwd that the reference
+ *      calls at ultralytics/nn/extra_modules/VManba/csms6s.py:257,267 (contract: vmamba.py:962-990), fp32:
+ *          dt = softplus(delta + dbias);  h_t = exp(dt_t A) h_{t-1} + dt_t B_t u_t;  y_t = <C_t, h_t> + D u_t
+ *      u, delta f32 [B, KD, L]; A f32 [KD, N]; Bm, Cm f32 [B, K, N, L]; D, dbias f32 [KD]; y f32 [B, KD, L].
+ *      N == 16.  hstate f32 [B, KD, nchunk, N]: chunk-boundary states saved for _bwd, nchunk = ceil(L / chunk) with
+ *      `chunk` returned by tamtr_selective_scan_chunk().
+ */
+int tamtr_selective_scan_chunk(void);
+int tamtr_selective_scan_fwd(const float* u, const float* delta, const float* A, const float* Bm, const float* Cm,
+                             const float* D, const float* dbias, float* y, float* hstate, int B, int K, int Dk, int N, int L,
+                             void* stream);
+/*      Backward: gy f32 [B,KD,L] -> gu, gdelta f32 [B,KD,L]; gB, gC f32 [B,K,N,L] (ACCUMULATED over the Dk rows of a
+ *      group with float atomics: caller zeroes); gA f32 [KD,N], gD, gdbias f32 [KD] (ACCUMULATED over B: caller zeroes).
+ */
+int tamtr_selective_scan_bwd(const float* gy, const float* u, const float* delta, const float* A, const float* Bm,
+                             const float* Cm, const float* D, const float* dbias, const float* hstate, float* gu,
+                             float* gdelta, float* gA, float* gB, float* gC, float* gD, float* gdbias, int B, int K, int Dk,
+                             int N, int L, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAMTR_HIP_H */

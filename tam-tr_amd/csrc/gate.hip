@@ -1,0 +1,204 @@
+// gate.hip - fused max-sigmoid text gate (BTA-PAN), forward + backward, gfx950.
+//
+// Replaces MaxSigmoidAttnBlock.forward's einsum/max/div/add/sigmoid/mul chain
+// (reference: ultralytics/nn/extra_modules/block.py:217-226), which materialises aw[B,nh,H,W,T] and makes >= 8 passes
+// over HBM.  Here: ONE pass.  HBM-bound by construction (AI ~ 5 flop/B), so the design rules are the byte ones:
+//   * NCHW is read as it lies: a workgroup owns (b, head m, a run of PXB pixels); lanes run along the pixel axis so
+//     every channel row is a coalesced 16-B-per-lane (f32) / 8-B-per-lane (bf16) stream;
+//   * the text tile gk[b, :, m, :]  ([T, hc] f32, <= 20 KB) is staged ONCE per workgroup in LDS and read back as
+//     wave-uniform broadcasts (no bank conflicts);
+//   * the T dot products of a pixel live in registers (TC accumulators x 4 pixels per lane), max/argmax over the
+//     text axis never leaves the lane, so no cross-lane traffic at all;
+//   * x is read once (T <= TC; once per TC-chunk otherwise), v once, out written once.
+#include "common.h"
+
+namespace {
+
+constexpr int GATE_THREADS = 256;
+constexpr int TC = 16;  // text rows accumulated per pass
+
+template <typename ET, int PX>
+__global__ __launch_bounds__(GATE_THREADS) void gate_fwd_kernel(const ET* __restrict__ x, const float* __restrict__ gk,
+                                                                 const float* __restrict__ bias, const ET* __restrict__ v,
+                                                                 ET* __restrict__ out, float* __restrict__ aw_out,
+                                                                 int32_t* __restrict__ arg_out, int nh, int hc, int HW, int T,
+                                                                 float scale) {
+  extern __shared__ float s_gk[];  // [T][hc]
+  const int m = blockIdx.y, b = blockIdx.z;
+  const int C = nh * hc;
+  for (int i = threadIdx.x; i < T * hc; i += GATE_THREADS) {
+    int n = i / hc, c = i - n * hc;
+    s_gk[i] = gk[((size_t)b * T + n) * C + m * hc + c];
+  }
+  __syncthreads();
+  const int p0 = (blockIdx.x * GATE_THREADS + threadIdx.x) * PX;
+  if (p0 >= HW) return;
+  const size_t base = ((size_t)b * C + (size_t)m * hc) * HW + p0;
+  const ET* xp = x + base;
+
+  float best[PX];
+  int besti[PX];
+#pragma unroll
+  for (int j = 0; j < PX; ++j) { best[j] = -INFINITY; besti[j] = 0; }
+
+  for (int n0 = 0; n0 < T; n0 += TC) {
+    float acc[TC][PX];
+#pragma unroll
+    for (int n = 0; n < TC; ++n)
+#pragma unroll
+      for (int j = 0; j < PX; ++j) acc[n][j] = 0.f;
+    for (int c = 0; c < hc; ++c) {
+      float xv[PX];
+      if constexpr (PX == 4) Elt<ET>::ld4(xp + (size_t)c * HW, xv);
+      else xv[0] = Elt<ET>::ld(xp + (size_t)c * HW);
+#pragma unroll
+      for (int n = 0; n < TC; ++n) {
+        // rows beyond T read row T-1 again (in bounds) and are ignored by the max below
+        float g = s_gk[min(n0 + n, T - 1) * hc + c];
+#pragma unroll
+        for (int j = 0; j < PX; ++j) acc[n][j] = fmaf(xv[j], g, acc[n][j]);
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < TC; ++n) {
+      if (n0 + n < T) {
+#pragma unroll
+        for (int j = 0; j < PX; ++j)
+          if (acc[n][j] > best[j]) { best[j] = acc[n][j]; besti[j] = n0 + n; }
+      }
+    }
+  }
+
+  const float rs = sqrtf((float)hc), bm = bias[m];
+  float a[PX];
+#pragma unroll
+  for (int j = 0; j < PX; ++j) a[j] = 1.f / (1.f + __expf(-(best[j] / rs + bm)));
+  const size_t pa = ((size_t)b * nh + m) * HW + p0;
+  if constexpr (PX == 4) {
+    *reinterpret_cast<float4*>(aw_out + pa) = make_float4(a[0], a[1], a[2], a[3]);
+    *reinterpret_cast<int4*>(arg_out + pa) = make_int4(besti[0], besti[1], besti[2], besti[3]);
+  } else {
+    aw_out[pa] = a[0];
+    arg_out[pa] = besti[0];
+  }
+  const ET* vp = v + base;
+  ET* op = out + base;
+  for (int c = 0; c < hc; ++c) {
+    float vv[PX];
+    if constexpr (PX == 4) {
+      Elt<ET>::ld4(vp + (size_t)c * HW, vv);
+#pragma unroll
+      for (int j = 0; j < PX; ++j) vv[j] *= a[j] * scale;
+      Elt<ET>::st4(op + (size_t)c * HW, vv);
+    } else {
+      Elt<ET>::st(op + (size_t)c * HW, Elt<ET>::ld(vp + (size_t)c * HW) * a[0] * scale);
+    }
+  }
+}
+
+template <typename ET, int PX>
+__global__ __launch_bounds__(GATE_THREADS) void gate_bwd_kernel(const ET* __restrict__ dout, const float* __restrict__ gk,
+                                                                 const ET* __restrict__ v, const float* __restrict__ aw,
+                                                                 const int32_t* __restrict__ arg, ET* __restrict__ dx,
+                                                                 ET* __restrict__ dv, float* __restrict__ dlogit, int nh, int hc,
+                                                                 int HW, int T, float scale) {
+  extern __shared__ float s_gk[];  // [T][hc+1] (padded: per-lane row gather in the last loop)
+  const int m = blockIdx.y, b = blockIdx.z;
+  const int C = nh * hc, ld = hc + 1;
+  for (int i = threadIdx.x; i < T * hc; i += GATE_THREADS) {
+    int n = i / hc, c = i - n * hc;
+    s_gk[n * ld + c] = gk[((size_t)b * T + n) * C + m * hc + c];
+  }
+  __syncthreads();
+  const int p0 = (blockIdx.x * GATE_THREADS + threadIdx.x) * PX;
+  if (p0 >= HW) return;
+  const size_t base = ((size_t)b * C + (size_t)m * hc) * HW + p0;
+  const size_t pa = ((size_t)b * nh + m) * HW + p0;
+  float a[PX], daw[PX];
+  int n_[PX];
+  if constexpr (PX == 4) {
+    float4 t = *reinterpret_cast<const float4*>(aw + pa);
+    int4 q = *reinterpret_cast<const int4*>(arg + pa);
+    a[0] = t.x; a[1] = t.y; a[2] = t.z; a[3] = t.w;
+    n_[0] = q.x; n_[1] = q.y; n_[2] = q.z; n_[3] = q.w;
+  } else {
+    a[0] = aw[pa];
+    n_[0] = arg[pa];
+  }
+#pragma unroll
+  for (int j = 0; j < PX; ++j) daw[j] = 0.f;
+  for (int c = 0; c < hc; ++c) {
+    float g[PX], vv[PX];
+    if constexpr (PX == 4) {
+      Elt<ET>::ld4(dout + base + (size_t)c * HW, g);
+      Elt<ET>::ld4(v + base + (size_t)c * HW, vv);
+    } else {
+      g[0] = Elt<ET>::ld(dout + base + (size_t)c * HW);
+      vv[0] = Elt<ET>::ld(v + base + (size_t)c * HW);
+    }
+#pragma unroll
+    for (int j = 0; j < PX; ++j) { daw[j] = fmaf(g[j], vv[j], daw[j]); g[j] *= a[j] * scale; }
+    if constexpr (PX == 4) Elt<ET>::st4(dv + base + (size_t)c * HW, g);
+    else Elt<ET>::st(dv + base + (size_t)c * HW, g[0]);
+  }
+  const float rs = sqrtf((float)hc);
+  float dl[PX];
+#pragma unroll
+  for (int j = 0; j < PX; ++j) dl[j] = daw[j] * scale * a[j] * (1.f - a[j]) / rs;
+  if constexpr (PX == 4) *reinterpret_cast<float4*>(dlogit + pa) = make_float4(dl[0], dl[1], dl[2], dl[3]);
+  else dlogit[pa] = dl[0];
+  for (int c = 0; c < hc; ++c) {
+    float o[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) o[j] = dl[j] * s_gk[n_[j] * ld + c];
+    if constexpr (PX == 4) Elt<ET>::st4(dx + base + (size_t)c * HW, o);
+    else Elt<ET>::st(dx + base + (size_t)c * HW, o[0]);
+  }
+}
+
+inline bool gate_args_ok(int B, int nh, int hc, int HW, int T) {
+  return B > 0 && nh > 0 && hc > 0 && HW > 0 && T > 0 && nh <= 65535 && B <= 65535;
+}
+
+}  // namespace
+
+extern "C" int tamtr_maxsigmoid_gate_fwd(const void* x, const float* gk, const float* bias, const void* v, void* out,
+                                         float* aw, int32_t* arg, int B, int nh, int hc, int HW, int T, float scale, int dtype,
+                                         void* stream) {
+  if (!x || !gk || !bias || !v || !out || !aw || !arg || !gate_args_ok(B, nh, hc, HW, T)) return TAMTR_EINVAL;
+  if ((size_t)T * hc * sizeof(float) > 60 * 1024) return TAMTR_EUNSUP;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)T * hc * sizeof(float);
+  const bool vec = (HW % 4) == 0;
+  const int px = vec ? 4 : 1;
+  dim3 grid((HW + GATE_THREADS * px - 1) / (GATE_THREADS * px), nh, B);
+#define GO(ET, PX) \
+  hipLaunchKernelGGL((gate_fwd_kernel<ET, PX>), grid, dim3(GATE_THREADS), lds, s, (const ET*)x, gk, bias, (const ET*)v, \
+                     (ET*)out, aw, arg, nh, hc, HW, T, scale)
+  if (dtype == TAMTR_F32) { if (vec) GO(float, 4); else GO(float, 1); }
+  else if (dtype == TAMTR_BF16) { if (vec) GO(bf16_t, 4); else GO(bf16_t, 1); }
+  else return TAMTR_EINVAL;
+#undef GO
+  return tamtr_launch_status();
+}
+
+extern "C" int tamtr_maxsigmoid_gate_bwd(const void* dout, const void* x, const float* gk, const void* v, const float* aw,
+                                         const int32_t* arg, void* dx, void* dv, float* dlogit, int B, int nh, int hc, int HW,
+                                         int T, float scale, int dtype, void* stream) {
+  (void)x;
+  if (!dout || !gk || !v || !aw || !arg || !dx || !dv || !dlogit || !gate_args_ok(B, nh, hc, HW, T)) return TAMTR_EINVAL;
+  if ((size_t)T * (hc + 1) * sizeof(float) > 60 * 1024) return TAMTR_EUNSUP;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)T * (hc + 1) * sizeof(float);
+  const bool vec = (HW % 4) == 0;
+  const int px = vec ? 4 : 1;
+  dim3 grid((HW + GATE_THREADS * px - 1) / (GATE_THREADS * px), nh, B);
+#define GO(ET, PX) \
+  hipLaunchKernelGGL((gate_bwd_kernel<ET, PX>), grid, dim3(GATE_THREADS), lds, s, (const ET*)dout, gk, (const ET*)v, aw, arg, \
+                     (ET*)dx, (ET*)dv, dlogit, nh, hc, HW, T, scale)
+  if (dtype == TAMTR_F32) { if (vec) GO(float, 4); else GO(float, 1); }
+  else if (dtype == TAMTR_BF16) { if (vec) GO(bf16_t, 4); else GO(bf16_t, 1); }
+  else return TAMTR_EINVAL;
+#undef GO
+  return tamtr_launch_status();
+}
