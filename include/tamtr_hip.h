@@ -110,14 +110,17 @@ int tamtr_linear_bf16(const void* X, const void* W, const float* bias, void* Y, 
  * a-7  Small-Q masked multi-head self-attention core.  Replaces the attention inside nn.MultiheadAttention as called
  *      at ultralytics/nn/modules/transformer.py:546 (after the packed in-projection, before out_proj):
  *          O[b,:,h,:] = softmax( Qh Kh^T / sqrt(dh) + mask ) Vh
- *      q,k,v (T) [B, Q, nh, dh] (row stride nh*dh, i.e. views into the packed projection); mask u8 [Q,Q] or NULL
- *      (1 = blocked); o (T) [B,Q,nh,dh]; lse f32 [B,nh,Q] saved log-sum-exp.  dh in {32, 64}, Q <= 1024.
+ *      q,k,v (T): row (b, i) of head h starts at ptr + (b*Q + i)*ld + h*dh  (ldq/ldk/ldv in elements, multiples of 4:
+ *      views into the packed in-projection output need no copy); mask_bits u32 [Q, ceil(Q/32)] or NULL, bit j%32 of word
+ *      j/32 of row i set = query i may NOT attend to key j; o (T) [B,Q,nh*dh] contiguous; lse f32 [B,nh,Q] saved
+ *      log-sum-exp.  dh in {32, 64}, Q <= 4096.
  */
-int tamtr_selfattn_fwd(const void* q, const void* k, const void* v, const uint8_t* mask, void* o, float* lse, int B, int Q,
-                       int nh, int dh, int dtype, void* stream);
+int tamtr_selfattn_fwd(const void* q, const void* k, const void* v, const uint32_t* mask_bits, void* o, float* lse, int B,
+                       int Q, int nh, int dh, int ldq, int ldk, int ldv, int dtype, void* stream);
+/*      Backward: go (T) [B,Q,nh*dh] -> gq, gk, gv (T) [B,Q,nh*dh] contiguous; delta_ws f32 [B,nh,Q] caller workspace. */
 int tamtr_selfattn_bwd(const void* go, const void* q, const void* k, const void* v, const void* o, const float* lse,
-                       const uint8_t* mask, void* gq, void* gk, void* gv, int B, int Q, int nh, int dh, int dtype,
-                       void* stream);
+                       const uint32_t* mask_bits, void* gq, void* gk, void* gv, float* delta_ws, int B, int Q, int nh, int dh,
+                       int ldq, int ldk, int ldv, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * a-9  Selective scan (S6), replacing the external CUDA extension selective_scan_cuda_core.fwd/bwd that the reference

@@ -31,8 +31,8 @@ _SIGS = {
     'tamtr_contrastive_logits_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'tamtr_contrastive_logits_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'tamtr_linear_bf16': [_P, _P, _P, _P, _I, _I, _I, _P],
-    'tamtr_selfattn_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    'tamtr_selfattn_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'tamtr_selfattn_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'tamtr_selfattn_bwd': [_P] * 11 + [_I, _I, _I, _I, _I, _I, _I, _I, _P],
     'tamtr_selective_scan_chunk': [],
     'tamtr_selective_scan_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'tamtr_selective_scan_bwd': [_P] * 16 + [_I, _I, _I, _I, _I, _P],

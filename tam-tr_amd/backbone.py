@@ -1,0 +1,127 @@
+"""GELAN backbone / neck blocks that surround the hot path ("rest PyTorch-ROCm", BASELINE configs[1]).
+
+These are stock PyTorch modules (MIOpen convolutions) - they are NOT part of the hand-written HIP path; they exist so
+that the TAMTR graph can be assembled and its checkpoints (state_dict keys) stay interchangeable with the reference:
+  Conv            ultralytics/nn/modules/conv.py:23-40
+  RepConvN ... RepNCSPELAN4, SPPELAN, CPAM   ultralytics/nn/extra_modules/block.py:26-163,255-308
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+BN_EPS, BN_MOMENTUM = 1e-3, 0.03  # the reference rewrites every BatchNorm2d after construction (torch_utils.py:303-313)
+
+
+def batchnorm(c):
+    return nn.BatchNorm2d(c, eps=BN_EPS, momentum=BN_MOMENTUM)
+
+
+class Conv(nn.Module):
+    """conv (no bias, 'same' padding) -> BatchNorm -> SiLU | identity.  Args as the reference: (c1, c2, k, s, p, g, d, act)."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, d=1, act=True):
+        super().__init__()
+        if p is None:
+            p = (d * (k - 1) + 1) // 2 if d > 1 else k // 2
+        self.conv = nn.Conv2d(c1, c2, k, s, p, dilation=d, groups=g, bias=False)
+        self.bn = batchnorm(c2)
+        self.act = nn.SiLU() if act is True else act if isinstance(act, nn.Module) else nn.Identity()
+
+    def forward(self, x):
+        return self.act(self.bn(self.conv(x)))
+
+
+class RepConvN(nn.Module):
+    """Training-time RepVGG pair: SiLU(3x3 conv+BN  +  1x1 conv+BN)."""
+
+    def __init__(self, c1, c2, k=3, s=1, p=1, g=1, d=1, act=True, bn=False, deploy=False):
+        super().__init__()
+        assert k == 3 and p == 1
+        self.conv1 = Conv(c1, c2, 3, s, p=1, g=g, act=False)
+        self.conv2 = Conv(c1, c2, 1, s, p=0, g=g, act=False)
+        self.act = nn.SiLU() if act is True else act if isinstance(act, nn.Module) else nn.Identity()
+
+    def forward(self, x):
+        return self.act(self.conv1(x) + self.conv2(x))
+
+
+class RepNBottleneck(nn.Module):
+    def __init__(self, c1, c2, shortcut=True, g=1, k=(3, 3), e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = RepConvN(c1, c_, k[0], 1)
+        self.cv2 = Conv(c_, c2, k[1], 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def forward(self, x):
+        y = self.cv2(self.cv1(x))
+        return x + y if self.add else y
+
+
+class RepNCSP(nn.Module):
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1, self.cv2 = Conv(c1, c_, 1, 1), Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*(RepNBottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)))
+
+    def forward(self, x):
+        return self.cv3(torch.cat((self.m(self.cv1(x)), self.cv2(x)), 1))
+
+
+class RepNCSPELAN4(nn.Module):
+    """GELAN block: 1x1 split, two (RepNCSP -> 3x3) stages, concat of all four branches, 1x1 fuse."""
+
+    def __init__(self, c1, c2, c3, c4, c5=1):
+        super().__init__()
+        self.c = c3 // 2
+        self.cv1 = Conv(c1, c3, 1, 1)
+        self.cv2 = nn.Sequential(RepNCSP(c3 // 2, c4, c5), Conv(c4, c4, 3, 1))
+        self.cv3 = nn.Sequential(RepNCSP(c4, c4, c5), Conv(c4, c4, 3, 1))
+        self.cv4 = Conv(c3 + 2 * c4, c2, 1, 1)
+
+    def branches(self, x):
+        y = list(self.cv1(x).chunk(2, 1))
+        y.append(self.cv2(y[-1]))
+        y.append(self.cv3(y[-1]))
+        return y
+
+    def forward(self, x):
+        return self.cv4(torch.cat(self.branches(x), 1))
+
+
+class SPPELAN(nn.Module):
+    def __init__(self, c1, c2, c3):
+        super().__init__()
+        self.c = c3
+        self.cv1 = Conv(c1, c3, 1, 1)
+        self.cv5 = Conv(4 * c3, c2, 1, 1)
+
+    def forward(self, x):
+        y = [self.cv1(x)]
+        for _ in range(3):
+            y.append(F.max_pool2d(y[-1], 5, 1, 2))
+        return self.cv5(torch.cat(y, 1))
+
+
+class CPAM(nn.Module):
+    """Parameter-free channel + spatial max gates (extra_modules/block.py:271-308)."""
+
+    def __init__(self, c1, c2=None):
+        super().__init__()
+
+    def forward(self, x):
+        c = torch.sigmoid(F.interpolate(F.max_pool2d(x, 3, 2, 1), scale_factor=2, mode='bilinear', align_corners=False)) * x
+        B, C, H, W = c.shape
+        g = c.view(B, 8, C // 8, H, W)
+        return (torch.sigmoid(g.amax(2, keepdim=True)) * g).view(B, C, H, W)
+
+
+class Concat(nn.Module):
+    def __init__(self, dimension=1):
+        super().__init__()
+        self.d = dimension
+
+    def forward(self, x):
+        return torch.cat(x, self.d)

@@ -1,0 +1,124 @@
+"""Multi-modal Encoder-decoder Head (MEH).  Reference: ManbaWorldDecoder, ultralytics/nn/modules/head.py:1005-1290.
+
+Data layout in HBM: the three input maps go VSSBlock (NHWC) -> 1x1 conv+BN -> flattened and concatenated once into
+`feats` [B, L, hd] (L = 33 600 tokens at 640^2), which stays resident for the whole decoder: enc_output, the three
+value projections and the gather kernels all read that one buffer.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .backbone import batchnorm
+from .loss import get_cdn_group
+from .modules import ContrastiveHeadMLP, DeformableTransformerDecoderLayer, MLP, TextDeformableTransformerDecoder
+from .vss import VSSBlock
+
+
+class ManbaWorldDecoder(nn.Module):
+    export = False
+
+    def __init__(self, nc=80, ch=(512, 1024, 2048), hd=512, nq=300, ndp=4, nh=8, ndl=6, d_ffn=1024, eval_idx=-1, dropout=0.,
+                 act=nn.ReLU(), nd=100, label_noise_ratio=0.5, box_noise_scale=1.0, learnt_init_query=False,
+                 dims=(128, 256, 512), drop_path=(0.1, 0.1, 0.1), embed=512, with_bn=False):
+        super().__init__()
+        if with_bn:
+            raise NotImplementedError('BNContrastiveHeadMLP is not used by TAMTR.yaml and is not built')
+        self.hidden_dim, self.nhead, self.nl, self.nc = hd, nh, len(ch), nc
+        self.num_queries, self.num_decoder_layers = nq, ndl
+        self.input_proj = nn.ModuleList(nn.Sequential(nn.Conv2d(c, hd, 1, bias=False), batchnorm(hd)) for c in ch)
+        self.VSSBlocks = nn.ModuleList(VSSBlock(hidden_dim=d, drop_path=p) for d, p in zip(dims, drop_path))
+        self.num_Blocks = len(dims)
+        layer = DeformableTransformerDecoderLayer(hd, nh, d_ffn, dropout, act, self.nl, ndp)
+        self.decoder = TextDeformableTransformerDecoder(hd, layer, ndl, eval_idx)
+        self.denoising_class_embed = nn.Embedding(nc + 1, hd)
+        self.num_denoising, self.label_noise_ratio, self.box_noise_scale = nd, label_noise_ratio, box_noise_scale
+        self.learnt_init_query = learnt_init_query
+        if learnt_init_query:
+            self.tgt_embed = nn.Embedding(nq, hd)
+        self.query_pos_head = MLP(4, 2 * hd, hd, num_layers=2)
+        self.enc_output = nn.Sequential(nn.Linear(hd, hd), nn.LayerNorm(hd))
+        self.enc_score_head = nn.Linear(hd, nc)
+        self.enc_bbox_head = MLP(hd, hd, 4, num_layers=3)
+        self.dec_score_head = nn.ModuleList(ContrastiveHeadMLP() for _ in range(ndl))
+        self.dec_bbox_head = nn.ModuleList(MLP(hd, hd, 4, num_layers=3) for _ in range(ndl))
+        self._anchor_cache = {}
+        self._reset_parameters()
+
+    def forward(self, x, text, batch=None):
+        x = [blk(f.permute(0, 2, 3, 1)).permute(0, 3, 1, 2) for blk, f in zip(self.VSSBlocks, x)]
+        feats, shapes = self._get_encoder_input(x)
+        dn_embed, dn_bbox, attn_mask, dn_meta = get_cdn_group(batch, self.nc, self.num_queries,
+                                                              self.denoising_class_embed.weight, self.num_denoising,
+                                                              self.label_noise_ratio, self.box_noise_scale, self.training)
+        embed, refer_bbox, enc_bboxes, enc_scores = self._get_decoder_input(feats, shapes, dn_embed, dn_bbox)
+        dec_bboxes, dec_scores = self.decoder(embed, refer_bbox, feats, shapes, text, self.dec_bbox_head, self.dec_score_head,
+                                              self.query_pos_head, attn_mask=attn_mask)
+        x = dec_bboxes, dec_scores, enc_bboxes, enc_scores, dn_meta
+        if self.training:
+            return x
+        y = torch.cat((dec_bboxes.squeeze(0), dec_scores.squeeze(0).sigmoid()), -1)
+        return y if self.export else (y, x)
+
+    def _generate_anchors(self, shapes, grid_size=0.05, dtype=torch.float32, device='cpu', eps=1e-2):
+        """Grid-centre anchors in logit space.  The reference normalises (x, y) by [h, w] (head.py:1188-1189) - kept."""
+        key = (tuple(map(tuple, shapes)), str(device))
+        if key not in self._anchor_cache:
+            out = []
+            for i, (h, w) in enumerate(shapes):
+                gy, gx = torch.meshgrid(torch.arange(h, dtype=torch.float32, device=device),
+                                        torch.arange(w, dtype=torch.float32, device=device), indexing='ij')
+                xy = (torch.stack([gx, gy], -1) + 0.5) / torch.tensor([h, w], dtype=torch.float32, device=device)
+                out.append(torch.cat([xy, torch.full_like(xy, grid_size * 2.0 ** i)], -1).view(1, h * w, 4))
+            a = torch.cat(out, 1)
+            valid = ((a > eps) & (a < 1 - eps)).all(-1, keepdim=True)
+            a = torch.log(a / (1 - a)).masked_fill(~valid, float('inf'))
+            self._anchor_cache = {key: (a, valid)}
+        a, valid = self._anchor_cache[key]
+        return a.to(dtype), valid
+
+    def _get_encoder_input(self, x):
+        feats, shapes = [], []
+        for proj, f in zip(self.input_proj, x):
+            y = proj(f)
+            feats.append(y.flatten(2).permute(0, 2, 1))
+            shapes.append([y.shape[2], y.shape[3]])
+        return torch.cat(feats, 1), shapes
+
+    def _get_decoder_input(self, feats, shapes, dn_embed=None, dn_bbox=None, text=None):
+        bs = feats.shape[0]
+        anchors, valid = self._generate_anchors(shapes, dtype=torch.float32, device=feats.device)
+        memory = self.enc_output(valid.to(feats.dtype) * feats)
+        scores = self.enc_score_head(memory)
+        top = torch.topk(scores.max(-1).values, self.num_queries, dim=1).indices
+        bi = torch.arange(bs, device=feats.device).unsqueeze(-1)
+        top_feat = memory[bi, top]
+        refer = self.enc_bbox_head(top_feat).float() + anchors[0][top]
+        enc_bboxes = refer.sigmoid()
+        if dn_bbox is not None:
+            refer = torch.cat([dn_bbox, refer], 1)
+        enc_scores = scores[bi, top]
+        embed = self.tgt_embed.weight.unsqueeze(0).repeat(bs, 1, 1) if self.learnt_init_query else top_feat
+        if self.training:
+            refer = refer.detach()
+            if not self.learnt_init_query:
+                embed = embed.detach()
+        if dn_embed is not None:
+            embed = torch.cat([dn_embed.to(embed.dtype), embed], 1)
+        return embed, refer, enc_bboxes, enc_scores
+
+    def _reset_parameters(self):
+        bias_cls = float(-math.log((1 - 0.01) / 0.01)) / 80 * self.nc
+        nn.init.constant_(self.enc_score_head.bias, bias_cls)
+        for m in [self.enc_bbox_head, *self.dec_bbox_head]:
+            nn.init.zeros_(m.layers[-1].weight)
+            nn.init.zeros_(m.layers[-1].bias)
+        nn.init.xavier_uniform_(self.enc_output[0].weight)
+        bound = 1 / math.sqrt(self.hidden_dim)
+        nn.init.uniform_(self.enc_output[0].bias, -bound, bound)
+        if self.learnt_init_query:
+            nn.init.xavier_uniform_(self.tgt_embed.weight)
+        nn.init.xavier_uniform_(self.query_pos_head.layers[0].weight)
+        nn.init.xavier_uniform_(self.query_pos_head.layers[1].weight)
+        for layer in self.input_proj:
+            nn.init.xavier_uniform_(layer[0].weight)

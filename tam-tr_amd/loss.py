@@ -1,0 +1,222 @@
+"""Host-side training objective of the hot path (stays PyTorch by design): RIOU, Hungarian assignment,
+contrastive-denoising query groups and the 12-term RT-DETR loss.
+
+  bbox_iou(RIOU)        ultralytics/utils/metrics.py:71-130
+  HungarianMatcher      ultralytics/models/utils/ops.py:12-119     (cost on device, ONE async D2H per layer, scipy LSA)
+  get_cdn_group         ultralytics/models/utils/ops.py:152-291
+  RTDETRDetectionLoss   ultralytics/models/utils/loss.py:14-442 (VFL + L1 + RIOU, aux + dn branches)
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def xywh2xyxy(b):
+    half = b[..., 2:] / 2
+    return torch.cat([b[..., :2] - half, b[..., :2] + half], -1)
+
+
+def xyxy2xywh(b):
+    return torch.cat([(b[..., :2] + b[..., 2:]) / 2, b[..., 2:] - b[..., :2]], -1)
+
+
+def bbox_iou(box1, box2, xywh=True, RIOU=False, eps=1e-7, **unused):
+    """IoU or RIOU = IoU - (rho^2 / (max(w1,h1) + max(w2,h2) + rho + eps)^2 + v*alpha) of broadcastable box tensors."""
+    if xywh:
+        x1, y1, w1, h1 = box1.chunk(4, -1)
+        x2, y2, w2, h2 = box2.chunk(4, -1)
+        ax1, ax2, ay1, ay2 = x1 - w1 / 2, x1 + w1 / 2, y1 - h1 / 2, y1 + h1 / 2
+        bx1, bx2, by1, by2 = x2 - w2 / 2, x2 + w2 / 2, y2 - h2 / 2, y2 + h2 / 2
+    else:
+        ax1, ay1, ax2, ay2 = box1.chunk(4, -1)
+        bx1, by1, bx2, by2 = box2.chunk(4, -1)
+        w1, h1 = ax2 - ax1, ay2 - ay1 + eps
+        w2, h2 = bx2 - bx1, by2 - by1 + eps
+    inter = (torch.minimum(ax2, bx2) - torch.maximum(ax1, bx1)).clamp(min=0) * \
+            (torch.minimum(ay2, by2) - torch.maximum(ay1, by1)).clamp(min=0)
+    iou = inter / (w1 * h1 + w2 * h2 - inter + eps)
+    if not RIOU:
+        return iou
+    rho2 = ((bx1 + bx2 - ax1 - ax2) ** 2 + (by1 + by2 - ay1 - ay2) ** 2) / 4
+    c2 = (torch.max(w1, h1) + torch.max(w2, h2) + torch.sqrt(rho2) + eps).pow(2)
+    v = (4 / math.pi ** 2) * (torch.atan(w2 / h2) - torch.atan(w1 / h1)).pow(2)
+    with torch.no_grad():
+        alpha = v / (v - iou + (1 + eps))
+    return iou - (rho2 / c2 + v * alpha)
+
+
+class HungarianMatcher(nn.Module):
+    def __init__(self, cost_gain=None, use_fl=True, with_mask=False, num_sample_points=12544, alpha=0.25, gamma=2.0):
+        super().__init__()
+        self.cost_gain = cost_gain or {'class': 1, 'bbox': 5, 'giou': 2, 'mask': 1, 'dice': 1}
+        self.use_fl, self.alpha, self.gamma = use_fl, alpha, gamma
+        if with_mask:
+            raise NotImplementedError('mask costs are not part of TAM-TR')
+
+    @torch.no_grad()
+    def forward(self, pred_bboxes, pred_scores, gt_bboxes, gt_cls, gt_groups, masks=None, gt_mask=None):
+        from scipy.optimize import linear_sum_assignment
+        bs, nq, nc = pred_scores.shape
+        if sum(gt_groups) == 0:
+            return [(torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long)) for _ in range(bs)]
+        ps = pred_scores.detach().float().reshape(-1, nc)
+        ps = (ps.sigmoid() if self.use_fl else ps.softmax(-1))[:, gt_cls]
+        pb = pred_bboxes.detach().float().reshape(-1, 4)
+        if self.use_fl:
+            neg = (1 - self.alpha) * ps ** self.gamma * (-(1 - ps + 1e-8).log())
+            pos = self.alpha * (1 - ps) ** self.gamma * (-(ps + 1e-8).log())
+            c_cls = pos - neg
+        else:
+            c_cls = -ps
+        c_l1 = (pb.unsqueeze(1) - gt_bboxes.unsqueeze(0)).abs().sum(-1)
+        c_iou = 1.0 - bbox_iou(pb.unsqueeze(1), gt_bboxes.unsqueeze(0), xywh=True, RIOU=True).squeeze(-1)
+        C = self.cost_gain['class'] * c_cls + self.cost_gain['bbox'] * c_l1 + self.cost_gain['giou'] * c_iou
+        C = torch.where(torch.isfinite(C), C, torch.zeros_like(C)).view(bs, nq, -1)
+        C = C.cpu()  # the one device->host sync of this layer's loss
+        out, off = [], 0
+        for i, c in enumerate(C.split(list(gt_groups), -1)):
+            r, k = linear_sum_assignment(c[i].numpy())
+            out.append((torch.as_tensor(r, dtype=torch.long), torch.as_tensor(k, dtype=torch.long) + off))
+            off += gt_groups[i]
+        return out
+
+
+def get_cdn_group(batch, num_classes, num_queries, class_embed, num_dn=100, cls_noise_ratio=0.5, box_noise_scale=1.0,
+                  training=False):
+    """Contrastive-denoising queries.  RNG draws are made on the CPU generator in the reference's order (rand,
+    randint_like, randint_like, rand_like) so that a given torch.manual_seed reproduces the reference's groups."""
+    if (not training) or num_dn <= 0 or batch is None:
+        return None, None, None, None
+    groups = batch['gt_groups']
+    total, mx = sum(groups), max(groups)
+    if mx == 0:
+        return None, None, None, None
+    dev = class_embed.device
+    ng = max(num_dn // mx, 1)
+    bs = len(groups)
+    cls = batch['cls'].cpu().repeat(2 * ng)
+    box = batch['bboxes'].cpu().float().repeat(2 * ng, 1)
+    bidx = batch['batch_idx'].cpu().repeat(2 * ng).view(-1)
+    neg = torch.arange(total * ng, dtype=torch.long) + ng * total
+    if cls_noise_ratio > 0:
+        idx = torch.nonzero(torch.rand(cls.shape) < cls_noise_ratio * 0.5).squeeze(-1)
+        cls[idx] = torch.randint_like(idx, 0, num_classes, dtype=cls.dtype)
+    if box_noise_scale > 0:
+        known = xywh2xyxy(box)
+        diff = (box[..., 2:] * 0.5).repeat(1, 2) * box_noise_scale
+        sign = torch.randint_like(box, 0, 2) * 2.0 - 1.0
+        part = torch.rand_like(box)
+        part[neg] += 1.0
+        known = (known + part * sign * diff).clip(0.0, 1.0)
+        box = torch.logit(xyxy2xywh(known), eps=1e-6)
+    n_dn = int(mx * 2 * ng)
+    within = torch.cat([torch.arange(n, dtype=torch.long) for n in groups])
+    pos_idx = torch.stack([within + mx * i for i in range(ng)], 0)
+    slot = torch.cat([within + mx * i for i in range(2 * ng)])
+    cls, box, bidx, slot = cls.to(dev), box.to(dev), bidx.to(dev), slot.to(dev)
+    emb = class_embed[cls]
+    pad_c = torch.zeros(bs, n_dn, emb.shape[-1], device=dev, dtype=emb.dtype)
+    pad_b = torch.zeros(bs, n_dn, 4, device=dev)
+    pad_c[bidx, slot] = emb
+    pad_b[bidx, slot] = box
+    size = n_dn + num_queries
+    mask = torch.zeros(size, size, dtype=torch.bool)
+    mask[n_dn:, :n_dn] = True
+    for i in range(ng):
+        lo, hi = mx * 2 * i, mx * 2 * (i + 1)
+        mask[lo:hi, hi:n_dn] = True
+        mask[lo:hi, :lo] = True
+    meta = {'dn_pos_idx': [p.reshape(-1) for p in pos_idx.split(list(groups), 1)], 'dn_num_group': ng,
+            'dn_num_split': [n_dn, num_queries]}
+    return pad_c, pad_b, mask.to(dev), meta
+
+
+def varifocal_loss(pred, gt_score, label, alpha=0.75, gamma=2.0):
+    w = alpha * pred.sigmoid().pow(gamma) * (1 - label) + gt_score * label
+    return (F.binary_cross_entropy_with_logits(pred.float(), gt_score.float(), reduction='none') * w).mean(1).sum()
+
+
+def focal_loss(pred, label, gamma=1.5, alpha=0.25):
+    loss = F.binary_cross_entropy_with_logits(pred, label, reduction='none')
+    p = pred.sigmoid()
+    pt = label * p + (1 - label) * (1 - p)
+    return (loss * (1.0 - pt) ** gamma * (label * alpha + (1 - label) * (1 - alpha))).mean(1).sum()
+
+
+class DETRLoss(nn.Module):
+    def __init__(self, nc=80, loss_gain=None, aux_loss=True, use_fl=True, use_vfl=False, **unused):
+        super().__init__()
+        self.nc = nc
+        self.loss_gain = loss_gain or {'class': 1, 'bbox': 5, 'giou': 2, 'no_object': 0.1, 'mask': 1, 'dice': 1}
+        self.matcher = HungarianMatcher(cost_gain={'class': 2, 'bbox': 5, 'giou': 2})
+        self.aux_loss, self.use_fl, self.use_vfl = aux_loss, use_fl, use_vfl
+
+    def _layer(self, pb, ps, gt_bboxes, gt_cls, gt_groups, match):
+        """(class, bbox, giou) of one decoder layer."""
+        dev = pb.device
+        if match is None:
+            match = self.matcher(pb, ps, gt_bboxes, gt_cls, gt_groups)
+        bi = torch.cat([torch.full_like(s, i) for i, (s, _) in enumerate(match)]).to(dev)
+        si = torch.cat([s for s, _ in match]).to(dev)
+        gi = torch.cat([g for _, g in match]).to(dev)
+        bs, nq = pb.shape[:2]
+        p_sel, g_sel = pb[bi, si].float(), gt_bboxes[gi]
+        n = int(g_sel.shape[0])
+        targets = torch.full((bs, nq), self.nc, device=dev, dtype=gt_cls.dtype)
+        targets[bi, si] = gt_cls[gi]
+        gt_scores = torch.zeros(bs, nq, device=dev)
+        if n:
+            gt_scores[bi, si] = bbox_iou(p_sel.detach(), g_sel, xywh=True).squeeze(-1)
+        one_hot = F.one_hot(targets, self.nc + 1)[..., :-1]
+        ps = ps.float()
+        if n and self.use_vfl:
+            l_cls = varifocal_loss(ps, gt_scores.view(bs, nq, 1) * one_hot, one_hot)
+        else:
+            l_cls = focal_loss(ps, one_hot.float())
+        l_cls = l_cls / (max(n, 1) / nq) * self.loss_gain['class']
+        if n == 0:
+            z = torch.zeros((), device=dev)
+            return l_cls, z, z.clone()
+        l_box = self.loss_gain['bbox'] * F.l1_loss(p_sel, g_sel, reduction='sum') / n
+        l_iou = self.loss_gain['giou'] * (1.0 - bbox_iou(p_sel, g_sel, xywh=True, RIOU=True)).sum() / n
+        return l_cls, l_box, l_iou
+
+    def forward(self, pred_bboxes, pred_scores, batch, postfix='', match_indices=None):
+        gt_cls, gt_bboxes, gt_groups = batch['cls'], batch['bboxes'], batch['gt_groups']
+        out = {}
+        c, b, g = self._layer(pred_bboxes[-1], pred_scores[-1], gt_bboxes, gt_cls, gt_groups, match_indices)
+        out[f'loss_class{postfix}'], out[f'loss_bbox{postfix}'], out[f'loss_giou{postfix}'] = c, b, g
+        if self.aux_loss:
+            aux = [torch.zeros((), device=pred_bboxes.device) for _ in range(3)]
+            for i in range(len(pred_bboxes) - 1):
+                t = self._layer(pred_bboxes[i], pred_scores[i], gt_bboxes, gt_cls, gt_groups, match_indices)
+                aux = [a + v for a, v in zip(aux, t)]
+            out[f'loss_class_aux{postfix}'], out[f'loss_bbox_aux{postfix}'], out[f'loss_giou_aux{postfix}'] = aux
+        return out
+
+
+class RTDETRDetectionLoss(DETRLoss):
+    def forward(self, preds, batch, dn_bboxes=None, dn_scores=None, dn_meta=None):
+        pred_bboxes, pred_scores = preds
+        total = super().forward(pred_bboxes, pred_scores, batch)
+        if dn_meta is not None:
+            match = self.get_dn_match_indices(dn_meta['dn_pos_idx'], dn_meta['dn_num_group'], batch['gt_groups'])
+            total.update(super().forward(dn_bboxes, dn_scores, batch, postfix='_dn', match_indices=match))
+        else:
+            total.update({f'{k}_dn': torch.zeros((), device=pred_bboxes.device) for k in list(total)})
+        return total
+
+    @staticmethod
+    def get_dn_match_indices(dn_pos_idx, dn_num_group, gt_groups):
+        out, off = [], 0
+        for i, n in enumerate(gt_groups):
+            if n > 0:
+                gt_idx = (torch.arange(n, dtype=torch.long) + off).repeat(dn_num_group)
+                assert len(dn_pos_idx[i]) == len(gt_idx)
+                out.append((dn_pos_idx[i], gt_idx))
+            else:
+                out.append((torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long)))
+            off += n
+        return out

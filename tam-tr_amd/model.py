@@ -1,0 +1,125 @@
+"""TAMTR graph + the BaseModel plugin boundary.  Reference: ultralytics/nn/tasks.py:28-43 (BaseModel.forward),
+:518-672 (RTDETRDetectionWorldModel.predict / loss), :841-972 (parse_model) and cfg/models/TAMTR/TAMTR.yaml.
+
+`model` is an nn.Sequential whose children carry `.i .f .type .np` exactly as parse_model attaches them, so state_dict
+keys are `model.{i}.…` and reference checkpoints' state_dicts load with strict=True.
+"""
+import torch
+import torch.nn as nn
+
+from .backbone import CPAM, Concat, Conv, RepNCSPELAN4, SPPELAN
+from .head import ManbaWorldDecoder
+from .loss import RTDETRDetectionLoss
+from .modules import TIAGELAN
+
+# [from, module, args] - same rows as cfg/models/TAMTR/TAMTR.yaml:9-67 (there is one scale only)
+TAMTR_SPEC = [
+    [-1, 'Conv', [64, 3, 2]], [-1, 'Conv', [128, 3, 2]], [-1, 'RepNCSPELAN4', [256, 128, 64, 1]],
+    [-1, 'Conv', [256, 3, 2]], [-1, 'RepNCSPELAN4', [512, 256, 128, 1]], [-1, 'Conv', [512, 3, 2]],
+    [-1, 'RepNCSPELAN4', [512, 512, 256, 1]], [-1, 'Conv', [512, 3, 2]], [-1, 'RepNCSPELAN4', [512, 512, 256, 1]],
+    [-1, 'SPPELAN', [512, 256]],
+    [-1, 'Conv', [512, 1, 1]], [-1, 'Upsample', [2.0]], [6, 'Conv', [512, 1, 1]], [4, 'Conv', [512, 1, 1]],
+    [-1, 'Upsample', [0.5]], [[-1, -3, -4], 'Concat', [1]], [-1, 'TIAGELAN', [512, 512, 256, 1, 8]], [-1, 'CPAM', []],
+    [-1, 'Conv', [256, 1, 1]], [-1, 'Upsample', [2.0]], [4, 'Conv', [256, 1, 1]], [2, 'Conv', [256, 1, 1]],
+    [-1, 'Upsample', [0.5]], [[-1, -3, -4], 'Concat', [1]], [-1, 'TIAGELAN', [256, 256, 128, 1, 4]], [-1, 'CPAM', []],
+    [-1, 'Conv', [128, 1, 1]], [-1, 'Upsample', [2.0]], [2, 'Conv', [128, 1, 1]], [0, 'Conv', [128, 1, 1]],
+    [-1, 'Upsample', [0.5]], [[-1, -3, -4], 'Concat', [1]], [-1, 'TIAGELAN', [128, 128, 64, 1, 2]], [-1, 'CPAM', []],
+    [-1, 'Conv', [128, 3, 2]], [[-1, 24], 'Concat', [1]], [-1, 'TIAGELAN', [256, 256, 128, 1, 4]], [-1, 'CPAM', []],
+    [-1, 'Conv', [256, 3, 2]], [[-1, 16], 'Concat', [1]], [-1, 'TIAGELAN', [512, 512, 256, 1, 8]],
+    [[32, 36, 40], 'ManbaWorldDecoder', ['nc', 512, 100, 4, 8, 3]],
+]
+
+
+def build_graph(spec, ch=3, nc=10):
+    """Instantiate the rows; returns (nn.Sequential, save list).  Channel bookkeeping as parse_model (tasks.py:886-955)."""
+    chans, layers, save = [], [], []
+    for i, (f, name, args) in enumerate(spec):
+        cin = ch if i == 0 else (chans[f] if isinstance(f, int) else None)
+        if name == 'Conv':
+            m, c2 = Conv(cin, *args), args[0]
+        elif name == 'RepNCSPELAN4':
+            m, c2 = RepNCSPELAN4(cin, *args), args[0]
+        elif name == 'TIAGELAN':
+            m, c2 = TIAGELAN(cin, *args), args[0]
+        elif name == 'SPPELAN':
+            m, c2 = SPPELAN(cin, *args), args[0]
+        elif name == 'Upsample':
+            m, c2 = nn.Upsample(None, args[0], 'nearest'), cin
+        elif name == 'Concat':
+            m, c2 = Concat(*args), sum(chans[j] for j in f)
+        elif name == 'CPAM':
+            m, c2 = CPAM(cin), cin
+        elif name == 'ManbaWorldDecoder':
+            a = [nc if v == 'nc' else v for v in args]
+            m, c2 = ManbaWorldDecoder(a[0], [chans[j] for j in f], *a[1:]), None
+        else:
+            raise ValueError(name)
+        m.i, m.f, m.type = i, f, name
+        m.np = sum(p.numel() for p in m.parameters())
+        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
+        layers.append(m)
+        chans.append(c2)
+    return nn.Sequential(*layers), sorted(set(save))
+
+
+class RTDETRDetectionWorldModel(nn.Module):
+    """forward(dict) -> (loss, loss_items)   [training batch: img, txt_feats, cls, bboxes, batch_idx]
+       forward(tensor) -> predictions        [uses self.txt_feats set in advance]"""
+
+    def __init__(self, cfg=None, ch=3, nc=10, verbose=False):
+        super().__init__()
+        self.yaml = {'nc': nc, 'ch': ch, 'spec': 'TAMTR'}
+        self.nc = nc
+        self.names = {i: f'{i}' for i in range(nc)}
+        self.txt_feats = torch.randn(1, nc, 512)
+        self.model, self.save = build_graph(cfg or TAMTR_SPEC, ch, nc)
+        self.stride = torch.Tensor([32])
+        self.autocast_dtype = None  # torch.bfloat16 => bf16 activations through the trunk and the head GEMMs
+
+    def forward(self, x, *args, **kwargs):
+        if isinstance(x, dict):
+            return self.loss(x, *args, **kwargs)
+        return self.predict(x, *args, **kwargs)
+
+    def init_criterion(self):
+        return RTDETRDetectionLoss(nc=self.nc, use_vfl=True)
+
+    def set_text_features(self, txt_feats):
+        """Offline vocabulary (stands in for set_classes(), tasks.py:552-571, whose CLIP encoder is out of scope)."""
+        self.txt_feats = txt_feats.reshape(-1, txt_feats.shape[-2], txt_feats.shape[-1])
+        self.model[-1].nc = self.txt_feats.shape[1]
+
+    def predict(self, x, profile=False, visualize=False, batch=None, augment=False, txt_feats=None):
+        txt = (self.txt_feats if txt_feats is None else txt_feats).to(device=x.device, dtype=torch.float32)
+        if len(txt) != len(x):
+            txt = txt.repeat(len(x), 1, 1)
+        head = self.model[-1]
+        with torch.autocast('cuda', dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None):
+            y = []
+            for m in self.model[:-1]:
+                if m.f != -1:
+                    x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+                x = m(x, txt) if isinstance(m, TIAGELAN) else m(x)
+                y.append(x if m.i in self.save else None)
+            return head([y[j] for j in head.f], txt.clone(), batch)
+
+    def loss(self, batch, preds=None):
+        if not hasattr(self, 'criterion'):
+            self.criterion = self.init_criterion()
+        img = batch['img']
+        bidx = batch['batch_idx'].to(img.device, dtype=torch.long).view(-1)
+        counts = torch.bincount(bidx, minlength=len(img)).tolist()  # one host sync for the ragged group sizes
+        targets = {'cls': batch['cls'].to(img.device, dtype=torch.long).view(-1), 'bboxes': batch['bboxes'].to(img.device),
+                   'batch_idx': bidx, 'gt_groups': counts}
+        preds = self.predict(img, batch=targets, txt_feats=batch['txt_feats']) if preds is None else preds
+        dec_bboxes, dec_scores, enc_bboxes, enc_scores, dn_meta = preds if self.training else preds[1]
+        dn_bboxes = dn_scores = None
+        if dn_meta is not None:
+            dn_bboxes, dec_bboxes = torch.split(dec_bboxes, dn_meta['dn_num_split'], dim=2)
+            dn_scores, dec_scores = torch.split(dec_scores, dn_meta['dn_num_split'], dim=2)
+        dec_bboxes = torch.cat([enc_bboxes.unsqueeze(0).to(dec_bboxes.dtype), dec_bboxes])
+        dec_scores = torch.cat([enc_scores.unsqueeze(0).to(dec_scores.dtype), dec_scores])
+        terms = self.criterion((dec_bboxes, dec_scores), targets, dn_bboxes=dn_bboxes, dn_scores=dn_scores, dn_meta=dn_meta)
+        self.last_loss_terms = terms
+        items = torch.stack([terms[k].detach() for k in ('loss_giou', 'loss_class', 'loss_bbox')])
+        return sum(terms.values()), items

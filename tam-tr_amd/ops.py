@@ -141,3 +141,136 @@ class _ContrastiveLogits(torch.autograd.Function):
 def contrastive_logits(x, w, logit_scale, bias):
     """x [B,Q,C] (f32|bf16), w [B,K,C] -> f32 logits [B,Q,K] (nn/modules/block.py:534-541)."""
     return _ContrastiveLogits.apply(x, w, logit_scale, bias)
+
+
+# ------------------------------------------------------------------------------------------------ a-5 value projection
+class _LinearBF16(torch.autograd.Function):
+    """Y = X W^T + b on the hand-written MFMA kernel (bf16 in/out, fp32 accumulate).  Backward = two plain library
+    GEMMs (dX = dY W, dW = dY^T X: rocBLAS/hipBLASLt through torch), which is what the tier rules reserve libraries for."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        require_gpu(x, weight, bias)
+        K = x.shape[-1]
+        N = weight.shape[0]
+        x2 = _c(x.reshape(-1, K))
+        if x2.dtype != torch.bfloat16:
+            raise _lib.TamtrHipError('linear_bf16 needs bf16 activations')
+        w16 = _c(weight.to(torch.bfloat16))
+        b32 = _c(bias.float()) if bias is not None else None
+        y = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.bfloat16)
+        call('tamtr_linear_bf16', ptr(x2), ptr(w16), ptr(b32), ptr(y), x2.shape[0], N, K, stream_ptr())
+        ctx.save_for_backward(x2, w16)
+        ctx.cfg = (x.shape, weight.dtype, None if bias is None else bias.dtype)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w16 = ctx.saved_tensors
+        xshape, w_dt, b_dt = ctx.cfg
+        g2 = _c(gy.reshape(-1, gy.shape[-1]).to(torch.bfloat16))
+        gx = (g2 @ w16).view(xshape) if ctx.needs_input_grad[0] else None
+        gw = (g2.t() @ x2).to(w_dt) if ctx.needs_input_grad[1] else None
+        gb = g2.float().sum(0).to(b_dt) if (b_dt is not None and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb
+
+
+def linear_bf16(x, weight, bias=None):
+    """x [..., K] bf16, weight [N, K], bias [N] -> [..., N] bf16 (transformer.py:273 value_proj)."""
+    return _LinearBF16.apply(x, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------------ a-7 self-attention
+_mask_cache = {}
+
+
+def pack_mask(mask):
+    """bool [Q,Q] (True = blocked) -> int32 bit words [Q, ceil(Q/32)]; cached per mask tensor (reused by all layers)."""
+    key = (mask.data_ptr(), mask._version, tuple(mask.shape), str(mask.device))
+    hit = _mask_cache.get(key)
+    if hit is not None:
+        return hit
+    Q = mask.shape[1]
+    W = (Q + 31) // 32
+    m = torch.zeros(mask.shape[0], W * 32, dtype=torch.int64, device=mask.device)
+    m[:, :Q] = mask.to(torch.int64)
+    words = (m.view(mask.shape[0], W, 32) << torch.arange(32, device=mask.device)).sum(-1)
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()
+    _mask_cache.clear()
+    _mask_cache[key] = words
+    return words
+
+
+class _SelfAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, nh, mask_bits):
+        require_gpu(q, k, v)
+        B, Q, C = q.shape
+        dh = C // nh
+        for t in (q, k, v):
+            if t.stride(-1) != 1 or t.stride(0) != Q * t.stride(1):
+                raise _lib.TamtrHipError('self_attention operands must be row-strided views [B,Q,C] of a packed projection')
+        if not (q.dtype == k.dtype == v.dtype):
+            raise _lib.TamtrHipError('self_attention operands must share a dtype')
+        o = torch.empty(B, Q, C, device=q.device, dtype=q.dtype)
+        lse = torch.empty(B, nh, Q, device=q.device, dtype=torch.float32)
+        call('tamtr_selfattn_fwd', ptr(q), ptr(k), ptr(v), ptr(mask_bits), ptr(o), ptr(lse), B, Q, nh, dh, q.stride(1), k.stride(1),
+             v.stride(1), dtype_code(q), stream_ptr())
+        ctx.save_for_backward(q, k, v, o, lse, mask_bits)
+        ctx.nh = nh
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v, o, lse, mask_bits = ctx.saved_tensors
+        nh = ctx.nh
+        B, Q, C = q.shape
+        go = _c(go.to(q.dtype))
+        gq, gk, gv = torch.empty_like(o), torch.empty_like(o), torch.empty_like(o)
+        ws = torch.empty(B, nh, Q, device=q.device, dtype=torch.float32)
+        call('tamtr_selfattn_bwd', ptr(go), ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(mask_bits), ptr(gq), ptr(gk), ptr(gv),
+             ptr(ws), B, Q, nh, C // nh, q.stride(1), k.stride(1), v.stride(1), dtype_code(q), stream_ptr())
+        return gq, gk, gv, None, None
+
+
+def self_attention(q, k, v, nh, attn_mask=None):
+    """softmax(q k^T / sqrt(dh) + mask) v per head; q,k,v [B,Q,C] (may be column slices of a packed projection);
+    attn_mask bool [Q,Q], True = blocked (transformer.py:546)."""
+    bits = pack_mask(attn_mask) if attn_mask is not None else None
+    return _SelfAttention.apply(q, k, v, int(nh), bits)
+
+
+# ------------------------------------------------------------------------------------------------ a-9 selective scan
+class _SelectiveScan(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, delta, A, Bm, Cm, D, dbias):
+        require_gpu(u, delta, A, Bm, Cm, D, dbias)
+        Bn, KD, L = u.shape
+        K, N = Bm.shape[1], Bm.shape[2]
+        u, delta, A, Bm, Cm, D, dbias = (_c(t.float()) for t in (u, delta, A, Bm, Cm, D, dbias))
+        chunk = _lib.lib().tamtr_selective_scan_chunk()
+        nchunk = (L + chunk - 1) // chunk
+        y = torch.empty_like(u)
+        hstate = torch.empty(Bn, KD, nchunk, N, device=u.device, dtype=torch.float32)
+        call('tamtr_selective_scan_fwd', ptr(u), ptr(delta), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(dbias), ptr(y), ptr(hstate), Bn, K,
+             KD // K, N, L, stream_ptr())
+        ctx.save_for_backward(u, delta, A, Bm, Cm, D, dbias, hstate)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        u, delta, A, Bm, Cm, D, dbias, hstate = ctx.saved_tensors
+        Bn, KD, L = u.shape
+        K, N = Bm.shape[1], Bm.shape[2]
+        gy = _c(gy.float())
+        gu, gdelta = torch.empty_like(u), torch.empty_like(u)
+        gA, gB, gC = torch.zeros_like(A), torch.zeros_like(Bm), torch.zeros_like(Cm)
+        gD, gbias = torch.zeros_like(D), torch.zeros_like(dbias)
+        call('tamtr_selective_scan_bwd', ptr(gy), ptr(u), ptr(delta), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(dbias), ptr(hstate), ptr(gu),
+             ptr(gdelta), ptr(gA), ptr(gB), ptr(gC), ptr(gD), ptr(gbias), Bn, K, KD // K, N, L, stream_ptr())
+        return gu, gdelta, gA, gB, gC, gD, gbias
+
+
+def selective_scan(u, delta, A, Bm, Cm, D, delta_bias):
+    """S6 scan with softplus(delta + bias): u, delta [B,K*Dk,L]; A [K*Dk,16]; Bm, Cm [B,K,16,L]; D, delta_bias [K*Dk]."""
+    return _SelectiveScan.apply(u, delta, A, Bm, Cm, D, delta_bias)

@@ -1,0 +1,114 @@
+"""VMamba VSSBlock / SS2D for the MEH head with the external CUDA selective-scan extension REPLACED by our own gfx950
+scan kernel (ops.selective_scan).  Reference: ultralytics/nn/extra_modules/VManba/vmamba.py:1169-1256 (VSSBlock),
+:330-484,898-1038 (SS2D forward_type "v2"), csms6s.py:4-46 (CrossScan/CrossMerge), csms6s.py:252-270 (scan call).
+
+state_dict keys are the reference's: norm, op.{x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, out_norm,
+in_proj, conv2d, out_proj}, norm2, mlp.{fc1, fc2}.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample (timm semantics: keep w.p. 1-p, rescale by 1/(1-p)); identity in eval or p=0."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        return x * mask / keep
+
+
+def cross_scan(x):
+    """[B,C,H,W] -> [B,4,C,HW]: row-major, column-major and both reversed (csms6s.py:4-14); autograd handles the merge."""
+    a = x.flatten(2)
+    b = x.transpose(2, 3).flatten(2)
+    return torch.stack([a, b, a.flip(-1), b.flip(-1)], 1)
+
+
+def cross_merge(ys, H, W):
+    """[B,4,D,HW] -> [B,D,HW] (csms6s.py:26-34)."""
+    B, K, D, L = ys.shape
+    y = ys[:, 0:2] + ys[:, 2:4].flip(-1)
+    return y[:, 0] + y[:, 1].view(B, D, W, H).transpose(2, 3).reshape(B, D, L)
+
+
+class SS2D(nn.Module):
+    def __init__(self, d_model=96, d_state=16, ssm_ratio=2.0, dt_rank='auto', d_conv=3, conv_bias=True, bias=False,
+                 dt_min=0.001, dt_max=0.1, dt_scale=1.0, dt_init_floor=1e-4, **kwargs):
+        super().__init__()
+        d_inner = int(ssm_ratio * d_model)
+        R = math.ceil(d_model / 16) if dt_rank == 'auto' else dt_rank
+        K = 4
+        self.d_inner, self.dt_rank, self.d_state = d_inner, R, d_state
+        self.out_norm = nn.LayerNorm(d_inner)
+        self.in_proj = nn.Linear(d_model, 2 * d_inner, bias=bias)
+        self.conv2d = nn.Conv2d(d_inner, d_inner, d_conv, padding=(d_conv - 1) // 2, groups=d_inner, bias=conv_bias)
+        self.x_proj_weight = nn.Parameter(torch.stack([nn.Linear(d_inner, R + 2 * d_state, bias=False).weight.detach()
+                                                       for _ in range(K)], 0))
+        self.out_proj = nn.Linear(d_inner, d_model, bias=bias)
+        # dt projection init (vmamba.py:152-176): weight U(-R^-0.5, R^-0.5), bias = softplus^-1(dt), dt log-uniform
+        std = R ** -0.5 * dt_scale
+        self.dt_projs_weight = nn.Parameter(torch.empty(K, d_inner, R).uniform_(-std, std))
+        dt = torch.exp(torch.rand(K, d_inner) * (math.log(dt_max) - math.log(dt_min)) + math.log(dt_min)).clamp(min=dt_init_floor)
+        self.dt_projs_bias = nn.Parameter(dt + torch.log(-torch.expm1(-dt)))
+        self.A_logs = nn.Parameter(torch.log(torch.arange(1, d_state + 1, dtype=torch.float32)).repeat(K * d_inner, 1))
+        self.Ds = nn.Parameter(torch.ones(K * d_inner))
+        self.A_logs._no_weight_decay = True
+        self.Ds._no_weight_decay = True
+
+    def forward(self, x):  # x: [B,H,W,C]
+        B, H, W, _ = x.shape
+        xz = self.in_proj(x)
+        xi, z = xz.chunk(2, -1)
+        z = F.silu(z)
+        xi = F.silu(self.conv2d(xi.permute(0, 3, 1, 2).contiguous()))
+        K, R, N, L = 4, self.dt_rank, self.d_state, H * W
+        xs = cross_scan(xi.float())  # the scan runs in fp32 (force_fp32, vmamba.py:980-981)
+        x_dbl = torch.einsum('bkdl,kcd->bkcl', xs, self.x_proj_weight.float())
+        dts, Bs, Cs = torch.split(x_dbl, [R, N, N], 2)
+        dts = torch.einsum('bkrl,kdr->bkdl', dts, self.dt_projs_weight.float())
+        As = -torch.exp(self.A_logs.float())
+        ys = ops.selective_scan(xs.reshape(B, -1, L), dts.reshape(B, -1, L), As, Bs.contiguous(), Cs.contiguous(),
+                                self.Ds.float(), self.dt_projs_bias.float().reshape(-1))
+        y = cross_merge(ys.view(B, K, -1, L), H, W)
+        y = self.out_norm(y.transpose(1, 2)).view(B, H, W, -1)
+        return self.out_proj((y * z).to(x.dtype))
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class VSSBlock(nn.Module):
+    """x + DropPath(SS2D(LN(x))); x + DropPath(Mlp(LN(x))), channels-last."""
+
+    def __init__(self, hidden_dim=0, drop_path=0.0, ssm_d_state=16, ssm_ratio=2.0, ssm_dt_rank='auto', ssm_conv=3,
+                 ssm_conv_bias=True, mlp_ratio=4.0, **kwargs):
+        super().__init__()
+        self.norm = nn.LayerNorm(hidden_dim)
+        self.op = SS2D(d_model=hidden_dim, d_state=ssm_d_state, ssm_ratio=ssm_ratio, dt_rank=ssm_dt_rank, d_conv=ssm_conv,
+                       conv_bias=ssm_conv_bias)
+        self.drop_path = DropPath(drop_path)
+        self.norm2 = nn.LayerNorm(hidden_dim)
+        self.mlp = Mlp(hidden_dim, int(hidden_dim * mlp_ratio))
+
+    def forward(self, x):
+        x = x + self.drop_path(self.op(self.norm(x)))
+        return x + self.drop_path(self.mlp(self.norm2(x)))

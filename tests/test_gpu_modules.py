@@ -1,0 +1,346 @@
+"""GPU parity of the product modules (tam-tr_amd/, HIP kernels through the C ABI) against the reference-generated
+golden vectors and the CPU oracle, fp32 mode, tolerance 1e-3 relative or tighter (north_star), plus bf16-mode sanity.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import T, assert_close, check_param_grads, check_summary
+from oracle import tamtr_oracle as O
+from weights import checksum, fill_state, rnd, urnd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import tamtr_amd  # noqa: F401
+    import tamtr_amd.head as head
+    import tamtr_amd.model as model
+    import tamtr_amd.modules as modules
+    import tamtr_amd.ops as ops
+    import tamtr_amd.vss as vss
+    return type('P', (), dict(modules=modules, head=head, model=model, ops=ops, vss=vss))
+
+
+def dev(t, dtype=None):
+    t = t.detach().cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def load(module, seed, wsum):
+    st = fill_state(module.state_dict(), seed)
+    assert abs(checksum(st) - float(wsum)) <= 1e-6 * max(1.0, abs(float(wsum))), 'state_dict keys/shapes differ from the reference'
+    module.load_state_dict(st, strict=True)
+    return module.cuda()
+
+
+def pgrads(m):
+    return {k: p.grad for k, p in m.named_parameters()}
+
+
+# ------------------------------------------------------------------------------------------------ kernels added later
+@pytest.mark.parametrize('Bn,K,Dk,L', [(2, 4, 3, 30), (1, 4, 8, 256), (2, 2, 5, 600), (1, 4, 64, 1028)])
+def test_selective_scan_vs_sequential_oracle(pkg, Bn, K, Dk, L):
+    """a-9 (parity unpinned): HIP chunked scan vs the oracle's plain sequential recurrence, values and all 7 gradients."""
+    u, dl = rnd((Bn, K * Dk, L), 1), rnd((Bn, K * Dk, L), 2)
+    A = -torch.exp(rnd((K * Dk, 16), 3, 0.5))
+    Bm, Cm = rnd((Bn, K, 16, L), 4), rnd((Bn, K, 16, L), 5)
+    D, bias = rnd((K * Dk,), 6), rnd((K * Dk,), 7) - 2.0
+    cot = rnd((Bn, K * Dk, L), 8)
+    ref_in = [t.clone().requires_grad_() for t in (u, dl, A, Bm, Cm, D, bias)]
+    ref = O.selective_scan(*ref_in)
+    (ref * cot).sum().backward()
+    got_in = [dev(t).requires_grad_() for t in (u, dl, A, Bm, Cm, D, bias)]
+    got = pkg.ops.selective_scan(*got_in)
+    (got * dev(cot)).sum().backward()
+    assert_close(got, ref, 1e-3, 1e-4, 'y')
+    for n, a, b in zip('u delta A B C D bias'.split(), got_in, ref_in):
+        scale = float(b.grad.abs().max())
+        assert_close(a.grad, b.grad, 2e-3, 2e-4 * max(scale, 1.0), 'grad ' + n)
+
+
+def _attn_ref(q, k, v, nh, mask):
+    B, Q, C = q.shape
+    dh = C // nh
+    qh, kh, vh = (t.view(B, Q, nh, dh).transpose(1, 2) for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2) / dh ** 0.5
+    if mask is not None:
+        s = s.masked_fill(mask[None, None], float('-inf'))
+    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Q, C)
+
+
+@pytest.mark.parametrize('B,Q,nh,dh,masked', [(2, 37, 8, 32, True), (1, 292, 8, 64, True), (2, 100, 4, 64, False), (1, 65, 2, 32, True)])
+def test_self_attention_kernel(pkg, B, Q, nh, dh, masked):
+    C = nh * dh
+    packed = rnd((B, Q, 3 * C), 1)
+    mask = None
+    if masked:
+        mask = torch.zeros(Q, Q, dtype=torch.bool)
+        nd = Q // 3
+        mask[nd:, :nd] = True
+        mask[:nd // 2, nd // 2:nd] = True
+        mask[nd // 2:nd, :nd // 2] = True
+    cot = rnd((B, Q, C), 2)
+    pr = packed.clone().requires_grad_()
+    ref = _attn_ref(pr[..., :C], pr[..., C:2 * C], pr[..., 2 * C:], nh, mask)
+    (ref * cot).sum().backward()
+    pd = dev(packed).requires_grad_()
+    out = pkg.ops.self_attention(pd[..., :C], pd[..., C:2 * C], pd[..., 2 * C:], nh, None if mask is None else dev(mask))
+    (out * dev(cot)).sum().backward()
+    assert_close(out, ref, 1e-4, 1e-5, 'attn out')
+    assert_close(pd.grad, pr.grad, 1e-3, 1e-5, 'attn grads (q|k|v)')
+    out16 = pkg.ops.self_attention(*(t.contiguous() for t in dev(packed).bfloat16().split(C, -1)), nh, None if mask is None else dev(mask))
+    assert_close(out16.float(), ref, 2e-2, 2e-2, 'attn bf16')
+
+
+@pytest.mark.parametrize('M,N,K', [(1000, 512, 512), (128 * 16, 128, 64), (77, 256, 192)])
+def test_linear_bf16_kernel(pkg, M, N, K):
+    """MFMA GEMM: exact products of bf16 inputs, fp32 accumulate -> agrees with an fp32 matmul of the same bf16 values
+    to accumulation-order noise; output rounded once to bf16 (2^-9 relative)."""
+    x, w, b = rnd((M, K), 1).bfloat16(), rnd((N, K), 2, K ** -0.5).bfloat16(), rnd((N,), 3)
+    ref = x.float() @ w.float().t() + b
+    xd, wd, bd = dev(x).requires_grad_(), dev(w).float().requires_grad_(), dev(b).requires_grad_()
+    y = pkg.ops.linear_bf16(xd, wd, bd)
+    assert y.dtype == torch.bfloat16 and y.shape == (M, N)
+    assert_close(y.float(), ref, 2 ** -8, 1e-3, 'linear_bf16')
+    y.float().sum().backward()
+    assert_close(bd.grad, torch.full((N,), float(M)), 1e-6, 1e-6, 'bias grad')
+    assert_close(xd.grad.float(), w.float().sum(0).expand(M, K), 2e-2, 2e-2, 'x grad')
+    # asymmetric-operand check of the fragment layout: X = I picks out W^T exactly
+    eye = torch.eye(K).bfloat16()
+    yi = pkg.ops.linear_bf16(dev(eye), dev(w).float(), None)
+    assert torch.equal(yi.cpu(), w.t().contiguous())
+
+
+def test_linear_bf16_full_size(pkg):
+    """BASELINE shape M = 16 * 33600, N = K = 512: checksum-of-rows property against an fp32 GEMV (size independent)."""
+    M, N, K = 16 * 33600, 512, 512
+    g = torch.Generator(device='cuda').manual_seed(0)
+    x = torch.randn(M, K, device='cuda', generator=g).bfloat16()
+    w = (torch.randn(N, K, device='cuda', generator=g) * K ** -0.5).bfloat16()
+    y = pkg.ops.linear_bf16(x, w.float(), None)
+    # sum over rows of Y == (sum over rows of X) @ W^T
+    want = (x.float().sum(0, keepdim=True) @ w.float().t()).squeeze(0)
+    got = y.float().sum(0)
+    assert_close(got, want, 0, 4e-3 * float(np.sqrt(M)), 'column checksum')  # bf16 output rounding ~ 2^-9 * |y| * sqrt(M)
+    idx = torch.randint(0, M, (64,), device='cuda', generator=g)
+    assert_close(y[idx].float(), x[idx].float() @ w.float().t(), 2 ** -8, 1e-3, 'sampled rows')
+
+
+# ------------------------------------------------------------------------------------------------ modules vs fixtures
+@pytest.mark.parametrize('tag', ['A', 'B', 'C'])
+def test_maxsigmoid_block(pkg, golden, tag):
+    fx = golden('gate')
+    B, c, nh, H, W, Tn, train = [int(v) for v in fx[f'{tag}.cfg']]
+    m = load(pkg.modules.MaxSigmoidAttnBlock(c, c, nh=nh, ec=c), 11, fx[f'{tag}.wsum']).train(bool(train))
+    x, g = dev(T(fx[f'{tag}.x'])).requires_grad_(), dev(T(fx[f'{tag}.guide'])).requires_grad_()
+    out = m(x, g)
+    assert_close(out, fx[f'{tag}.out'], 1e-3, 1e-4, 'gate module out')
+    if train:
+        (out * dev(T(fx[f'{tag}.cot']))).sum().backward()
+        check_summary(fx, f'{tag}.gin.x', x.grad, 1e-3, 1e-4)
+        check_summary(fx, f'{tag}.gin.guide', g.grad, 1e-3, 1e-4)
+        check_param_grads(fx, f'{tag}.', pgrads(m), 1e-3, 1e-4)
+        assert_close(m.proj_conv.bn.running_mean, fx[f'{tag}.bn_mean'], 1e-4, 1e-5)
+        assert_close(m.proj_conv.bn.running_var, fx[f'{tag}.bn_var'], 1e-4, 1e-5)
+
+
+def test_tiagelan_module(pkg, golden):
+    fx = golden('tiagelan')
+    m = load(pkg.modules.TIAGELAN(96, 64, 128, 64, 1, 2), 12, fx['wsum']).train()
+    x, g = dev(T(fx['x'])).requires_grad_(), dev(T(fx['guide'])).requires_grad_()
+    out = m(x, g)
+    assert_close(out, fx['out'], 1e-3, 1e-4)
+    (out * dev(T(fx['cot']))).sum().backward()
+    check_summary(fx, 'gin.x', x.grad, 1e-3, 1e-4)
+    assert g.grad is None
+    check_param_grads(fx, '', pgrads(m), 1e-3, 1e-4)
+    assert_close(m.attn.proj_conv.bn.running_mean, fx['attn_bn_mean'], 1e-4, 1e-5, 'discarded gate still updates BN')
+    m.eval()
+    with torch.no_grad():
+        assert_close(m(x, g), fx['out_eval'], 1e-3, 1e-4)
+
+
+def test_msdeform_attn_module(pkg, golden):
+    fx = golden('msdeform_attn')
+    m = load(pkg.modules.MSDeformAttn(256, 3, 8, 4), 21, fx['wsum'])
+    q, r, v = (dev(T(fx[k])).requires_grad_() for k in ('query', 'refer', 'value'))
+    out = m(q, r, v, fx['shapes'].tolist())
+    assert_close(out, fx['out'], 1e-3, 1e-4)
+    (out * dev(T(fx['cot']))).sum().backward()
+    for k, t in (('query', q), ('refer', r), ('value', v)):
+        check_summary(fx, f'gin.{k}', t.grad, 2e-3, 1e-4)
+    check_param_grads(fx, '', pgrads(m), 2e-3, 1e-4)
+    m0 = pkg.modules.MSDeformAttn(256, 3, 8, 4)
+    assert_close(m0.sampling_offsets.bias, fx['init_offsets_bias'], 1e-6, 1e-6, 'init KAT')
+    with pytest.raises(ValueError):
+        pkg.modules.MSDeformAttn(250, 3, 8, 4)
+
+
+def test_decoder_layer_module(pkg, golden):
+    fx = golden('decoder_layer')
+    m = load(pkg.modules.DeformableTransformerDecoderLayer(256, 8, 512, 0., nn.ReLU(), 3, 4), 41, fx['wsum'])
+    e, r, f, p = (dev(T(fx[k])).requires_grad_() for k in ('embed', 'refer', 'feats', 'pos'))
+    shapes = fx['shapes'].tolist()
+    out = m(e, r, f, shapes, None, dev(T(fx['mask'])), p)
+    assert_close(out, fx['out'], 1e-3, 1e-4)
+    (out * dev(T(fx['cot']))).sum().backward()
+    for k, t in (('embed', e), ('refer', r), ('feats', f), ('pos', p)):
+        check_summary(fx, f'gin.{k}', t.grad, 2e-3, 1e-4)
+    check_param_grads(fx, '', pgrads(m), 2e-3, 1e-4)
+    with torch.no_grad():
+        assert_close(m(e, r, f, shapes, None, None, p), fx['out_nomask'], 1e-3, 1e-4)
+
+
+def test_text_decoder_module(pkg, golden):
+    fx = golden('text_decoder')
+    M = pkg.modules
+    layer = M.DeformableTransformerDecoderLayer(256, 8, 512, 0., nn.ReLU(), 3, 4)
+    heads = nn.ModuleDict(dict(decoder=M.TextDeformableTransformerDecoder(256, layer, 3, -1),
+                               dec_bbox_head=nn.ModuleList([M.MLP(256, 256, 4, num_layers=3) for _ in range(3)]),
+                               dec_score_head=nn.ModuleList([M.ContrastiveHeadMLP() for _ in range(3)]),
+                               query_pos_head=M.MLP(4, 512, 256, num_layers=2)))
+    load(heads, 42, fx['wsum']).train()
+    e, r, f, t = (dev(T(fx[k])).requires_grad_() for k in ('embed', 'refer', 'feats', 'text'))
+    shapes = fx['shapes'].tolist()
+    bb, sc = heads['decoder'](e, r, f, shapes, t, heads['dec_bbox_head'], heads['dec_score_head'], heads['query_pos_head'],
+                              attn_mask=dev(T(fx['mask'])))
+    assert_close(bb, fx['bboxes'], 1e-3, 1e-4)
+    assert_close(sc, fx['scores'], 1e-3, 1e-3)
+    ((bb * dev(T(fx['cot_b']))).sum() + (sc * dev(T(fx['cot_s']))).sum()).backward()
+    for k, x in (('embed', e), ('refer', r), ('feats', f), ('text', t)):
+        check_summary(fx, f'gin.{k}', x.grad, atol=1e-5, l2rel=5e-3)
+    check_param_grads(fx, '', pgrads(heads), atol=1e-5, l2rel=5e-3)
+    heads.eval()
+    with torch.no_grad():
+        bb, sc = heads['decoder'](e, r, f, shapes, t, heads['dec_bbox_head'], heads['dec_score_head'], heads['query_pos_head'])
+    assert_close(bb, fx['bboxes_eval'], 1e-3, 1e-4)
+    assert_close(sc, fx['scores_eval'], 1e-3, 1e-3)
+
+
+def test_vss_block_vs_oracle(pkg):
+    """VSSBlock with the REAL HIP scan vs the oracle VSS block (sequential CPU scan) on the same weights."""
+    from oracle import specs
+    blk = pkg.vss.VSSBlock(hidden_dim=32, drop_path=0.0)
+    st = fill_state(blk.state_dict(), 51)
+    assert sorted(st) == sorted(n for n, _, _ in specs.vss_block(32))
+    blk.load_state_dict(st)
+    blk.cuda().train()
+    x = rnd((2, 6, 5, 32), 5)
+    cot = rnd((2, 6, 5, 32), 6)
+    so = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in st.items()}
+    xr = x.clone().requires_grad_()
+    ref = O.vss_block(xr, O.View(so))
+    (ref * cot).sum().backward()
+    xd = dev(x).requires_grad_()
+    out = blk(xd)
+    (out * dev(cot)).sum().backward()
+    assert_close(out, ref, 1e-3, 1e-4, 'vss out')
+    assert_close(xd.grad, xr.grad, 2e-3, 2e-4, 'vss dx')
+    for k, p in blk.named_parameters():
+        g = so[k].grad
+        assert_close(p.grad, g, 5e-3, 5e-4 * max(1.0, float(g.abs().max())), 'vss grad ' + k)
+
+
+def _targets(fx, cuda=True):
+    t = {'cls': T(fx['cls']).long(), 'bboxes': T(fx['bboxes']), 'batch_idx': T(fx['batch_idx']).long(),
+         'gt_groups': [int(v) for v in fx['n_per']]}
+    if cuda:
+        t = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in t.items()}
+    return t
+
+
+def test_meh_head_module(pkg, golden):
+    """ManbaWorldDecoder vs the reference fixture; as in the generator the VSSBlocks are swapped for identity by the TEST."""
+    fx = golden('head')
+    hd, nq, nh, ndl, ffn, nc = [int(v) for v in fx['cfg']]
+    ch = fx['ch'].tolist()
+    m = pkg.head.ManbaWorldDecoder(nc, ch, hd, nq, 4, nh, ndl, ffn, dims=ch, embed=hd)
+    m.VSSBlocks = nn.ModuleList([nn.Identity() for _ in ch])
+    load(m, 61, fx['wsum']).train()
+    xs = [dev(rnd((2, c, h, w), 70 + i)).requires_grad_() for i, (c, (h, w)) in enumerate(zip(ch, fx['sizes'].tolist()))]
+    text = dev(T(fx['text'])).requires_grad_()
+    torch.manual_seed(4321)
+    db, ds, eb, es, meta = m(xs, text, _targets(fx))
+    assert meta['dn_num_split'] == fx['split'].tolist()
+    for k, v in (('dec_bboxes', db), ('dec_scores', ds), ('enc_bboxes', eb), ('enc_scores', es)):
+        assert_close(v, fx[k], 1e-3, 2e-4, k)
+    sum((o * dev(T(fx[f'cot{i}']))).sum() for i, o in enumerate((db, ds, eb, es))).backward()
+    for i, x in enumerate(xs):
+        check_summary(fx, f'gin.x{i}', x.grad, atol=1e-5, l2rel=5e-3)
+    check_summary(fx, 'gin.text', text.grad, atol=1e-5, l2rel=5e-3)
+    check_param_grads(fx, '', pgrads(m), atol=1e-5, l2rel=5e-3)
+    m.eval()
+    with torch.no_grad():
+        y, _ = m(xs, text, None)
+    assert_close(y, fx['y_eval'], 1e-3, 2e-4, 'eval y')
+
+
+def test_full_model_vs_reference_fixture(pkg, golden):
+    """a-11: whole TAMTR graph at 64x64 against the reference's loss / gradients / eval output (VSS := identity in the test)."""
+    fx = golden('e2e')
+    model = pkg.model.RTDETRDetectionWorldModel(nc=10)
+    head = model.model[-1]
+    head.VSSBlocks = nn.ModuleList([nn.Identity() for _ in range(3)])
+    load(model, 71, fx['wsum']).train()
+    assert model.save == fx['save'].tolist()
+    batch = {'img': dev(T(fx['img'])), 'txt_feats': dev(T(fx['txt'])), 'cls': dev(T(fx['cls'])), 'bboxes': dev(T(fx['bboxes'])),
+             'batch_idx': dev(T(fx['batch_idx']))}
+    torch.manual_seed(999)
+    loss, items = model(batch)
+    assert_close(loss, fx['loss'], 1e-3, 1e-4, 'loss')
+    assert_close(items, fx['loss_items'], 1e-3, 1e-4, 'loss items')
+    loss.backward()
+    gr = pgrads(model)
+    assert sorted(k for k, g in gr.items() if g is None) == sorted(fx['grad_none'].tolist())
+    check_param_grads(fx, '', gr, atol=1e-5, key='g', l2rel=1e-2)
+    model.eval()
+    with torch.no_grad():
+        y, _ = model(batch['img'], txt_feats=batch['txt_feats'])
+    assert_close(y, fx['y_eval'], 1e-3, 2e-4, 'eval')
+
+
+def test_full_model_real_vss_vs_oracle(pkg):
+    """Whole graph WITH the VSSBlocks (HIP scan) vs the CPU oracle (sequential scan): loss, eval output, sampled grads."""
+    from oracle import specs
+    torch.manual_seed(0)
+    model = pkg.model.RTDETRDetectionWorldModel(nc=10)
+    for m in model.modules():
+        if hasattr(m, 'drop_prob'):
+            m.drop_prob = 0.0  # DropPath is stochastic; the oracle treats it as identity
+    st = fill_state(model.state_dict(), 71)
+    assert sorted(st) == sorted(n for n, _, _ in specs.tamtr_model(10, vss=True)), 'state_dict keys differ from the reference layout'
+    model.load_state_dict(st)
+    model.cuda().train()
+    B, S = 2, 64
+    img, txt = urnd((B, 3, S, S), 1), torch.nn.functional.normalize(rnd((B, 10, 512), 2), dim=-1)
+    g = torch.Generator().manual_seed(39)
+    cls = torch.randint(0, 10, (5,), generator=g)
+    bboxes = torch.cat([0.2 + 0.6 * torch.rand(5, 2, generator=g), 0.02 + 0.2 * torch.rand(5, 2, generator=g)], 1)
+    bidx = torch.tensor([0, 0, 0, 1, 1])
+    so = {k: v.clone().requires_grad_(v.dtype.is_floating_point and not k.endswith(('running_mean', 'running_var')))
+          for k, v in st.items()}
+    torch.manual_seed(5)
+    lref, iref, _ = O.tamtr_loss(so, {'img': img, 'txt_feats': txt, 'cls': cls, 'bboxes': bboxes, 'batch_idx': bidx}, True)
+    lref.backward()
+    torch.manual_seed(5)
+    loss, items = model({'img': dev(img), 'txt_feats': dev(txt), 'cls': dev(cls), 'bboxes': dev(bboxes), 'batch_idx': dev(bidx)})
+    loss.backward()
+    assert_close(loss, lref, 1e-3, 1e-4, 'loss (real VSS)')
+    assert_close(items, iref, 1e-3, 1e-4)
+    for k, p in model.named_parameters():
+        gr = so[k].grad
+        if gr is None:
+            assert p.grad is None, k
+        elif p.numel() <= 4096:
+            err = float((p.grad.cpu() - gr).norm()) / max(float(gr.norm()), 1e-9)
+            assert err < 2e-2 or float((p.grad.cpu() - gr).abs().max()) < 1e-5, f'{k}: rel-L2 {err:.2e}'
+    model.eval()
+    with torch.no_grad():
+        y, _ = model(dev(img), txt_feats=dev(txt))
+        yref = O.tamtr_predict({k: v.detach() for k, v in so.items()}, img, txt, None, False)
+    assert_close(y, yref, 1e-3, 2e-4, 'eval (real VSS)')
