@@ -83,3 +83,15 @@ def check_param_grads(fx, base, named_grads, rtol=1e-4, atol=1e-5, key='gpar', l
         check_summary(fx, p, g, rtol, atol, l2rel)
         seen += 1
     assert seen > 0, f'no gradient entries matched under {base}{key}'
+
+
+def assert_rows_match(got, want, tol, what=''):
+    """Permutation-invariant comparison of two [N, D] row sets (top-k order among near-tied scores is device dependent):
+    optimal one-to-one row matching, then every matched pair must agree to `tol` (max abs)."""
+    from scipy.optimize import linear_sum_assignment
+    got, want = got.detach().cpu().double(), torch.as_tensor(np.asarray(want)).double()
+    assert got.shape == want.shape, what
+    cost = torch.cdist(got, want, p=float('inf'))
+    r, c = linear_sum_assignment(cost.numpy())
+    worst = float(cost[r, c].max())
+    assert worst <= tol, f'{what}: worst matched row distance {worst:.3e} > {tol:.1e}'

@@ -472,8 +472,10 @@ def gen_head():
     save('head', d)
 
 
-def gen_e2e():
-    """a-11: full RTDETRDetectionWorldModel (nn/tasks.py:518-672) on a 64x64 image, VSSBlocks := identity."""
+def _gen_e2e(wseed):
+    """a-11: full RTDETRDetectionWorldModel (nn/tasks.py:518-672) on 256x256 images, VSSBlocks := identity.
+    (64x64 was tried first: BatchNorm over 2x2x2 samples in the deepest layers makes loss and gradients chaotic under
+    1e-6 input perturbations, so no cross-device comparison is meaningful there.)"""
     from ultralytics.nn.tasks import RTDETRDetectionWorldModel, yaml_model_load
     d = {'vss_identity': 1}
     torch.manual_seed(0)
@@ -484,15 +486,18 @@ def gen_e2e():
     head.VSSBlocks = nn.ModuleList([nn.Identity() for _ in range(3)])
     d['n_params'] = sum(p.numel() for p in m.parameters())
     d['save'] = np.asarray(m.save)
-    d['wsum'] = load_filled(m, seed=71)
-    B, S = 2, 64
+    d['wseed'] = wseed
+    d['wsum'] = load_filled(m, seed=wseed)
+    B, S = 2, 256
     img = urnd((B, 3, S, S), 1)
     txt = torch.nn.functional.normalize(rnd((B, 10, 512), 2), dim=-1)
     t = make_targets(B, [3, 2], 39)
     batch = {'img': img, 'txt_feats': txt, 'cls': t['cls'].view(-1, 1).float(), 'bboxes': t['bboxes'],
              'batch_idx': t['batch_idx'].float()}
-    d.update(img=img, txt=txt, cls=t['cls'], bboxes=t['bboxes'], batch_idx=t['batch_idx'],
+    d.update(S=S, txt=txt, cls=t['cls'], bboxes=t['bboxes'], batch_idx=t['batch_idx'],
              n_per=np.asarray(t['gt_groups']))
+    scores = []
+    hook = head.enc_score_head.register_forward_hook(lambda mod, i, o: scores.append(o.detach().max(-1).values))
     m.train()
     torch.manual_seed(999)
     loss, items = m(batch)
@@ -518,7 +523,24 @@ def gen_e2e():
     with torch.no_grad():
         y, _ = m.predict(img, txt_feats=txt)
     d['y_eval'] = y
+    hook.remove()
+    gaps = []
+    for sc in scores:  # SURVEY 8g "Top-k ties": the selection boundary (rank 100) must be clear of ties
+        srt = sc.sort(dim=1, descending=True).values
+        gaps.append(float((srt[:, 99] - srt[:, 100]).min()))
+    d['topk_gap'] = np.asarray(gaps)
+    if min(gaps) <= 1e-4:
+        print(f'  weight seed {wseed}: top-k boundary nearly tied {gaps}, trying the next seed')
+        return False
     save('e2e', d)
+    return True
+
+
+def gen_e2e():
+    for wseed in range(71, 91):
+        if _gen_e2e(wseed):
+            return
+    raise RuntimeError('no weight seed with a clear top-k boundary')
 
 
 if __name__ == '__main__':

@@ -38,7 +38,7 @@ def test_state_dict_layout_matches_reference(golden):
     assert model.save == [0, 2, 4, 6, 11, 12, 16, 19, 20, 24, 27, 28, 32, 36, 40]  # unique, sorted (SURVEY a-11 lists dups)
     # the checksum recorded when these weights were loaded into the REFERENCE model (VSS swapped out there)
     fx = golden('e2e')
-    st = {k: v for k, v in fill_state(model.state_dict(), 71).items() if '.VSSBlocks.' not in k}
+    st = {k: v for k, v in fill_state(model.state_dict(), int(fx['wseed'])).items() if '.VSSBlocks.' not in k}
     assert abs(checksum(st) - float(fx['wsum'])) < 1e-6 * abs(float(fx['wsum']))
     for i, m in enumerate(model.model):
         assert m.i == i and hasattr(m, 'f') and hasattr(m, 'type') and hasattr(m, 'np')

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from conftest import T, assert_close, check_param_grads, check_summary
 from oracle import specs
 from oracle import tamtr_oracle as O
-from weights import checksum, fill_state, rnd
+from weights import checksum, fill_state, rnd, urnd
 
 RT, AT = 2e-4, 2e-5
 
@@ -288,16 +288,17 @@ def test_meh_head(golden):
 
 
 def test_e2e(golden):
-    """Full TAMTR graph, 64x64, VSS := identity (fixture flag), 12-term loss + sampled gradients + eval output."""
+    """Full TAMTR graph, 256x256, VSS := identity (fixture flag), 12-term loss + sampled gradients + eval output."""
     fx = golden('e2e')
     assert int(fx['vss_identity']) == 1
     spec = specs.tamtr_model(10, vss=False)
-    st = make_state(spec, 71, fx['wsum'])
+    st = make_state(spec, int(fx['wseed']), fx['wsum'])
     n_par = sum(int(np.prod(s)) for n, s, d in spec if d.is_floating_point and not n.endswith(('running_mean', 'running_var')))
     vss_par = sum(int(np.prod(s)) for c in (128, 256, 512) for n, s, d in specs.vss_block(c))
     assert n_par + vss_par == 42124314  # SURVEY D3
     assert int(fx['n_params']) == n_par
-    batch = {'img': T(fx['img']), 'txt_feats': T(fx['txt']), 'cls': T(fx['cls']), 'bboxes': T(fx['bboxes']),
+    S = int(fx['S'])
+    batch = {'img': urnd((2, 3, S, S), 1), 'txt_feats': T(fx['txt']), 'cls': T(fx['cls']), 'bboxes': T(fx['bboxes']),
              'batch_idx': T(fx['batch_idx'])}
     torch.manual_seed(999)
     loss, items, terms = O.tamtr_loss(st, batch, True, vss='identity')
