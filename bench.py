@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py - images/sec of one TAM-TR training step (fwd + 12-term RIOU loss + bwd + AdamW) at 640x640, bs 16 per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--no-cpu-baseline]
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+Workload = BASELINE.json configs[1]/[2] ("TAM-TR-s" := the reference's only graph, TAMTR.yaml, 42.1 M params - SURVEY D3):
+synthetic images rand(B,3,640,640), unit-norm 10x512 text features, 8 GT boxes per image (=> 192 denoising + 100 queries).
+The step is the reference's training step (engine/trainer.py:328-357,471-479): forward through BaseModel.forward(dict),
+loss, backward, gradient clip 0.1, AdamW(lr 1e-4, wd 1e-4).  Every rank runs bs 16 (weak scaling); gradients are summed
+over ranks with bucketed RCCL all-reduces overlapped with the backward (tam-tr_amd/dist.py).
+
+One JSON line on rank 0.  `roofline`: the MEH value-projection GEMM (tamtr_linear_bf16, the dominant dense contraction of
+the head: 3 launches per step, M = 16*33600, N = K = 512), timed live with events on the launch stream inside the timed
+steps, priced against the dense bf16 MFMA peak.  `cpu_baseline`: the CPU oracle (oracle/, a port - the reference's own
+end-to-end path cannot run on CPU) timed on this box's host cores on a bounded sample (2 images, 1 step).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def synth_batch(B, S, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(B, 3, S, S, generator=g)
+    txt = torch.nn.functional.normalize(torch.randn(B, 10, 512, generator=g), dim=-1)
+    n = 8
+    cls = torch.randint(0, 10, (B * n, 1), generator=g).float()
+    xy = 0.2 + 0.6 * torch.rand(B * n, 2, generator=g)
+    wh = 0.02 + 0.2 * torch.rand(B * n, 2, generator=g)
+    bidx = torch.arange(B).repeat_interleave(n).float()
+    b = {'img': img, 'txt_feats': txt, 'cls': cls, 'bboxes': torch.cat([xy, wh], 1), 'batch_idx': bidx}
+    return {k: v.to(device) for k, v in b.items()}
+
+
+class KernelTimer:
+    """Wraps tamtr_amd.ops.linear_bf16 with a pair of events on the launch stream (torch's current stream)."""
+
+    def __init__(self):
+        self.events, self.flops, self.enabled = [], 0.0, False
+
+    def install(self):
+        import tamtr_amd.modules as M
+        import tamtr_amd.ops as ops
+        inner = ops.linear_bf16
+
+        def timed(x, w, b=None):
+            if not self.enabled:
+                return inner(x, w, b)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = inner(x, w, b)
+            e1.record()
+            self.events.append((e0, e1))
+            self.flops = 2.0 * x.numel() * w.shape[0]
+            return y
+        M.ops.linear_bf16 = timed
+
+    def summary(self):
+        if not self.events:
+            return None
+        ms = sorted(a.elapsed_time(b) for a, b in self.events)
+        avg = sum(ms) / len(ms)
+        return {'launches': len(ms), 'avg_ms': avg, 'min_ms': ms[0], 'tflops': self.flops / (avg * 1e-3) / 1e12}
+
+
+def cpu_baseline(n_img=2, S=640):
+    """The CPU oracle (port) on this box's host cores: one fwd+bwd of the same graph on n_img images."""
+    from oracle import selscan_c, specs, tamtr_oracle as O
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    from weights import fill_state
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    st = fill_state(specs.tamtr_model(10, vss=True), 7)
+    for k, v in st.items():
+        if v.dtype.is_floating_point and not k.endswith(('running_mean', 'running_var')):
+            v.requires_grad_()
+    b = synth_batch(n_img, S, 1, 'cpu')
+    tiny = synth_batch(n_img, 64, 1, 'cpu')
+    torch.manual_seed(0)
+    O.tamtr_loss(st, tiny, True, scan_fn=selscan_c.scan)[0].backward()  # thread-pool / allocator warm-up, untimed
+    t0 = time.time()
+    torch.manual_seed(0)
+    loss = O.tamtr_loss(st, b, True, scan_fn=selscan_c.scan)[0]
+    loss.backward()
+    dt = time.time() - t0
+    return {'value': n_img / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'{n_img} images 640x640, 1 fwd+bwd step of the fp32 CPU oracle (C scan twin, torch CPU ops), {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16, help='images per GPU')
+    ap.add_argument('--imgsz', type=int, default=640)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import tamtr_amd  # noqa: F401  (raises if the HIP library is missing)
+    from tamtr_amd import dist as tdist
+    from tamtr_amd.model import RTDETRDetectionWorldModel
+    rank, local, world = tdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    torch.backends.cudnn.benchmark = True  # MIOpen find mode for the (out-of-scope) trunk convolutions
+
+    torch.manual_seed(0)
+    model = RTDETRDetectionWorldModel(nc=10).to(dev).train()
+    model.autocast_dtype = torch.bfloat16 if args.dtype == 'bf16' else None
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999), fused=True)
+    reducer = None
+    if world > 1:
+        reducer = tdist.GradReducer(model.named_parameters(), skip=lambda n: '.attn.' in n)
+    batch = synth_batch(args.batch, args.imgsz, 1 + rank, dev)
+    timer = KernelTimer()
+    timer.install()
+
+    def step():
+        if reducer is not None:
+            reducer.prepare()
+        else:
+            opt.zero_grad(set_to_none=True)
+        loss, items = model(batch)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], max_norm=0.1)
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    if rank == 0:
+        ks = timer.summary()
+        peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == 'bf16' else MFMA_F32_PEAK_TFLOPS
+        out = {
+            'metric': 'images/sec fwd+bwd @640x640 bs=16/GPU', 'value': world * args.batch * args.steps / dt, 'unit': 'images/sec',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'TAM-TR (TAMTR.yaml graph, 42.1M params) train step fwd+loss+bwd+AdamW, {args.imgsz}x{args.imgsz}, '
+                                   f'bs {args.batch}/GPU, 10 text prompts, 8 GT/img, full BTA-PAN+MEH HIP path',
+                       'global_batch': world * args.batch, 'parallelism': f'dp{world}', 'final_loss': float(loss)},
+            'roofline': None if ks is None else {
+                'bound': 'mfma', 'kernel': 'linear_bf16_kernel (MEH value_proj, M=%d N=K=512)' % (args.batch * 33600),
+                'achieved': ks['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': ks['tflops'] / peak, 'traffic': None,
+                'avg_ms': ks['avg_ms'], 'launches': ks['launches']},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline()
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,113 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, RCCL (torch.distributed backend "nccl") over xGMI.
+
+Reference semantics (ultralytics/engine/trainer.py:200-204,241,252,346-347): images are sharded across ranks, every rank
+runs the same graph, gradients are averaged by DDP and the loss is pre-multiplied by world_size, i.e. the update uses the
+SUM over ranks of the per-rank gradients.  Here: an explicit bucketed gradient reducer instead of the DDP wrapper -
+  * parameters that never receive a gradient (the 30 `model.{16,24,32,36,40}.attn.*` tensors) are excluded up
+    front, which is what makes plain DDP fail on iteration 2 in the reference;
+  * gradients live in a few large flat buckets (views), one all-reduce per bucket, launched from a post-accumulate hook
+    as soon as the bucket's last gradient of this backward pass is written, so the collectives overlap the rest of the
+    backward; xGMI is point-to-point (7 links per GPU), so few large buckets (default 32 MiB) beat many small ones;
+  * no collective anywhere on the data path of the forward (per-rank BatchNorm statistics, like the reference).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  Returns (rank, local_rank, world)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_batch(global_batch, rank, world):
+    """Contiguous image shard [lo, hi) of rank (DistributedSampler-style equal split; global_batch % world == 0)."""
+    if global_batch % world:
+        raise ValueError(f'global batch {global_batch} not divisible by world size {world}')
+    per = global_batch // world
+    return rank * per, (rank + 1) * per
+
+
+class GradReducer:
+    """Bucketed, overlapped all-reduce (SUM or MEAN) of the gradients of `params` that are known to receive one."""
+
+    def __init__(self, named_params, bucket_bytes=32 << 20, op='sum', grad_dtype=None, skip=lambda name: False):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.op = op
+        self.buckets = []   # dicts: flat, params, pending, handle
+        self._hooks = []
+        params = [(n, p) for n, p in named_params if p.requires_grad and not skip(n)]
+        params.reverse()  # roughly the order gradients become ready in backward
+        cur, cur_bytes = [], 0
+        groups = []
+        for n, p in params:
+            nbytes = p.numel() * (torch.tensor([], dtype=grad_dtype or p.dtype).element_size())
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                groups.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append((n, p))
+            cur_bytes += nbytes
+        if cur:
+            groups.append(cur)
+        for g in groups:
+            dt = grad_dtype or g[0][1].dtype
+            flat = torch.zeros(sum(p.numel() for _, p in g), device=g[0][1].device, dtype=dt)
+            off = 0
+            bucket = {'flat': flat, 'params': g, 'pending': 0, 'handle': None, 'views': []}
+            for _, p in g:
+                v = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+                bucket['views'].append(v)
+                if dt == p.dtype:
+                    p.grad = v  # autograd accumulates straight into the bucket: no copy before the collective
+            self.buckets.append(bucket)
+            for (_, p), v in zip(g, bucket['views']):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bucket, p, v)))
+        self.n_params = sum(len(b['params']) for b in self.buckets)
+
+    def _make_hook(self, bucket, p, view):
+        def hook(param):
+            if param.grad is not view:  # dtype differs from the bucket (e.g. bf16 buckets) or grad was re-created
+                view.copy_(param.grad)
+                if view.dtype == param.dtype:
+                    param.grad = view
+            bucket['pending'] -= 1
+            if bucket['pending'] == 0 and self.world > 1:
+                bucket['handle'] = dist.all_reduce(bucket['flat'], op=dist.ReduceOp.SUM, async_op=True)
+        return hook
+
+    def prepare(self):
+        """Call before backward: arm the per-bucket counters and zero the flat buffers."""
+        for b in self.buckets:
+            b['pending'] = len(b['params'])
+            b['handle'] = None
+            b['flat'].zero_()
+
+    def finish(self):
+        """Call after backward: wait for the collectives (a bucket whose params did not all fire is reduced now)."""
+        for b in self.buckets:
+            if self.world > 1:
+                if b['handle'] is None:
+                    b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
+                b['handle'].wait()
+                if self.op == 'mean':
+                    b['flat'].div_(self.world)
+            for (_, p), v in zip(b['params'], b['views']):
+                if p.grad is not v and v.dtype != p.dtype:
+                    p.grad = v.to(p.dtype)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
