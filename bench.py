@@ -121,7 +121,6 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    torch.backends.cudnn.benchmark = True  # MIOpen find mode for the (out-of-scope) trunk convolutions
 
     torch.manual_seed(0)
     model = RTDETRDetectionWorldModel(nc=10).to(dev).train()
@@ -152,8 +151,16 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def note(msg):
+        if rank == 0:
+            print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+    note(f'model built on {world} GPU(s), dtype {args.dtype}; warm-up ({args.warmup} steps; the first one includes MIOpen kernel selection)')
+    for i in range(args.warmup):
+        t1 = time.perf_counter()
         step()
+        torch.cuda.synchronize()
+        note(f'warm-up step {i}: {time.perf_counter() - t1:.2f} s')
     fence()
     timer.enabled = True
     t0 = time.perf_counter()
@@ -166,6 +173,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
+    note(f'timed {args.steps} steps: {dt / args.steps * 1e3:.1f} ms/step')
     if rank == 0:
         ks = timer.summary()
         peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == 'bf16' else MFMA_F32_PEAK_TFLOPS

@@ -134,13 +134,15 @@ int tamtr_selective_scan_chunk(void);
 int tamtr_selective_scan_fwd(const float* u, const float* delta, const float* A, const float* Bm, const float* Cm,
                              const float* D, const float* dbias, float* y, float* hstate, int B, int K, int Dk, int N, int L,
                              void* stream);
-/*      Backward: gy f32 [B,KD,L] -> gu, gdelta f32 [B,KD,L]; gB, gC f32 [B,K,N,L] (ACCUMULATED over the Dk rows of a
- *      group with float atomics: caller zeroes); gA f32 [KD,N], gD, gdbias f32 [KD] (ACCUMULATED over B: caller zeroes).
+/*      Backward: gy f32 [B,KD,L] -> gu, gdelta f32 [B,KD,L]; gB, gC f32 [B,K,N,L] (plain stores); gA f32 [KD,N], gD,
+ *      gdbias f32 [KD] (ACCUMULATED over the batch: caller zeroes).  ws: caller workspace of
+ *      2 * tamtr_selective_scan_bwd_slabs(Dk) * B*K*N*L floats (per-workgroup partial dB/dC slabs, summed by a second kernel).
  */
+int tamtr_selective_scan_bwd_slabs(int Dk);
 int tamtr_selective_scan_bwd(const float* gy, const float* u, const float* delta, const float* A, const float* Bm,
                              const float* Cm, const float* D, const float* dbias, const float* hstate, float* gu,
-                             float* gdelta, float* gA, float* gB, float* gC, float* gD, float* gdbias, int B, int K, int Dk,
-                             int N, int L, void* stream);
+                             float* gdelta, float* gA, float* gB, float* gC, float* gD, float* gdbias, float* ws, int B, int K,
+                             int Dk, int N, int L, void* stream);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ import os
 from ctypes import c_float, c_int, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libtamtr_hip.so')
+LIB_PATH = os.environ.get('TAMTR_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libtamtr_hip.so')  # env override: kernel A/B experiments
 ABI_VERSION = 1
 
 F32, BF16 = 0, 1
@@ -35,7 +35,8 @@ _SIGS = {
     'tamtr_selfattn_bwd': [_P] * 11 + [_I, _I, _I, _I, _I, _I, _I, _I, _P],
     'tamtr_selective_scan_chunk': [],
     'tamtr_selective_scan_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    'tamtr_selective_scan_bwd': [_P] * 16 + [_I, _I, _I, _I, _I, _P],
+    'tamtr_selective_scan_bwd_slabs': [_I],
+    'tamtr_selective_scan_bwd': [_P] * 17 + [_I, _I, _I, _I, _I, _P],
 }
 EXPORTS = tuple(_SIGS)
 _lib = None

@@ -6,26 +6,40 @@
 //     dt = softplus(delta + dbias);  h_t = exp(dt_t A_n) h_{t-1} + dt_t B_{n,t} u_t;  y_t = sum_n C_{n,t} h_{n,t} + D u_t
 //
 // Mapping (wave64): ONE WAVE PER ROW (b, k*Dk+d); lanes run along TIME, 4 consecutive steps per lane, so a wave eats
-// a CHUNK of 256 steps per iteration with perfectly coalesced 16-B/lane loads of u, delta, B_n, C_n and stores of y.
-// Inside a chunk the linear recurrence is an associative scan on pairs (a, b): 3 sequential steps inside the lane,
-// then a 6-level Hillis-Steele scan across the 64 lanes with wave shuffles, then the carry h_{n} (wave-uniform) of the
-// previous chunk is folded in.  The 16 states are looped, the y dot product stays inside the lane (no cross-lane
-// reduction).  Chunk-boundary states are written out for the backward pass, which walks the chunks in reverse,
-// recomputes h inside the chunk and runs the mirrored (suffix) scan for dL/dh.
-// dB/dC are shared by the Dk rows of a (b, k) group: the ROWS waves of a workgroup (all in one group) first reduce
-// them in LDS, then issue full-row (256-B contiguous) float atomics - the full-rate atomic shape on gfx950.
+// a CHUNK of 256 steps per iteration with perfectly coalesced 16-B/lane loads of u, delta (and gy) and stores of y.
+// Inside a chunk the linear recurrence is an associative scan on affine maps h -> a*h + b: 3 sequential steps inside
+// the lane, then a 6-level scan across the 64 lanes done with DPP row shifts / row broadcasts (VALU-rate cross-lane
+// moves, no LDS round trip), then the carry h_n (wave-uniform) of the previous chunk is folded in.  The 16 states are
+// looped; the y dot product stays inside the lane.  Chunk-boundary states are written out for the backward pass, which
+// walks the chunks in reverse, recomputes h inside the chunk and runs the mirrored (suffix) scan for dL/dh.
+// B/C (and dB/dC) are shared by the Dk rows of a (b, k) group: a workgroup holds rows of ONE group and stages the chunk's
+// B/C tiles once in LDS.  In the backward every wave walks BWD_RPW rows per chunk and sums their dB/dC contributions in
+// REGISTERS; the waves then fold their register tiles into one LDS tile in turns, and the workgroup plain-stores it to
+// its slab of a workspace that a second kernel sums.  What was measured on the way (MI355X, level 0 = 16x1024 rows x
+// 25600 steps): float atomics straight into gB/gC ran at the contended-atomic rate (79 ms); an LDS tile fed by
+// ds_add_f32 from 8 waves was no better (81 ms, 64 of them in the LDS atomics); shuffles through ds_bpermute made both
+// passes instruction-bound (~2000 instructions per wave-chunk, 500 of them in log1pf/expf range handling).
 #include "common.h"
 
 namespace {
 
-constexpr int NS = 16;        // d_state
-constexpr int ITEMS = 4;      // time steps per lane
+constexpr int NS = 16;         // d_state
+constexpr int ITEMS = 4;       // time steps per lane
 constexpr int CHUNK = WAVE * ITEMS;
-constexpr int FWD_ROWS = 4;   // waves (rows) per workgroup, forward
-constexpr int BWD_ROWS = 8;   // waves (rows) per workgroup, backward (shares the dB/dC LDS reduction)
+constexpr int FWD_ROWS = 8;    // waves (= rows of one (b,k) group) per workgroup, forward
+constexpr int BWD_WAVES = 4;   // waves per workgroup, backward
+constexpr int BWD_RPW = 8;     // rows handled one after the other by each wave per chunk
+constexpr int BWD_ROWS = BWD_WAVES * BWD_RPW;  // rows of one (b,k) group per workgroup = one dB/dC slab
+constexpr float LOG2E = 1.4426950408889634f;
 
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+// softplus with torch's threshold (20); log(1+e^x) through the hardware exp2/log2 (abs err ~1e-7, the e^x branch keeps
+// the relative accuracy for very negative x where 1 + e^x rounds to 1)
+__device__ __forceinline__ float softplus_f(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * LOG2E);
+  const float sp = __builtin_amdgcn_logf(1.f + e) * 0.6931471805599453f;
+  return x > 20.f ? x : (x < -10.f ? e : sp);
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __builtin_amdgcn_exp2f(-x * LOG2E)); }
 
 template <bool VEC>
 __device__ __forceinline__ void load4(const float* __restrict__ p, int t, int L, float (&o)[ITEMS], float fill) {
@@ -52,77 +66,127 @@ __device__ __forceinline__ void store4(float* __restrict__ p, int t, int L, cons
   }
 }
 
-// inclusive prefix scan over lanes of the affine maps h -> A*h + B (composition: earlier map applied first)
-__device__ __forceinline__ void wave_scan_prefix(float& A, float& Bv, int lane) {
-#pragma unroll
-  for (int o = 1; o < WAVE; o <<= 1) {
-    const float pa = __shfl_up(A, o, WAVE), pb = __shfl_up(Bv, o, WAVE);
-    if (lane >= o) { Bv = fmaf(A, pb, Bv); A *= pa; }
-  }
+// DPP move: lanes without a valid source (row edge / masked row) keep `old`
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL,
+                                                               ROWMASK, 0xf, false));
 }
-// inclusive suffix scan: g -> A*g + B, later map applied first (mirror image)
-__device__ __forceinline__ void wave_scan_suffix(float& A, float& Bv, int lane) {
+#define SCAN_STEP(CTRL, RM)                                              \
+  {                                                                      \
+    const float pa = dpp<CTRL, RM>(1.f, A), pb = dpp<CTRL, RM>(0.f, Bv); \
+    Bv = fmaf(A, pb, Bv);                                                \
+    A *= pa;                                                             \
+  }
+// inclusive prefix scan over the 64 lanes of the affine maps h -> A*h + B (earlier map applied first):
+// row_shr 1,2,4,8 inside the 16-lane rows, then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3
+__device__ __forceinline__ void wave_scan_prefix(float& A, float& Bv) {
+  SCAN_STEP(0x111, 0xf) SCAN_STEP(0x112, 0xf) SCAN_STEP(0x114, 0xf) SCAN_STEP(0x118, 0xf)
+  SCAN_STEP(0x142, 0xa) SCAN_STEP(0x143, 0xc)
+}
+// value of the previous lane (lane 0 keeps `old`): wave_shr:1
+__device__ __forceinline__ float prev_lane(float old, float v) { return dpp<0x138, 0xf>(old, v); }
+// value of the next lane (lane 63 keeps `old`): wave_shl:1
+__device__ __forceinline__ float next_lane(float old, float v) { return dpp<0x130, 0xf>(old, v); }
+
+// inclusive suffix scan g -> A*g + B (later map applied first): row_shl 1,2,4,8 inside the rows; the two cross-row
+// levels fetch the composite held by the FIRST lane of row r+1 / r+2 with ds_bpermute (there is no "broadcast to the
+// previous row" DPP mode).  addr1/addr2: byte addresses of those lanes, or -1 when the row does not exist.
+__device__ __forceinline__ void wave_scan_suffix(float& A, float& Bv, int addr1, int addr2) {
+  SCAN_STEP(0x101, 0xf) SCAN_STEP(0x102, 0xf) SCAN_STEP(0x104, 0xf) SCAN_STEP(0x108, 0xf)
 #pragma unroll
-  for (int o = 1; o < WAVE; o <<= 1) {
-    const float pa = __shfl_down(A, o, WAVE), pb = __shfl_down(Bv, o, WAVE);
-    if (lane + o < WAVE) { Bv = fmaf(A, pb, Bv); A *= pa; }
+  for (int s = 0; s < 2; ++s) {
+    const int ad = s ? addr2 : addr1;
+    float pa = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(ad, __builtin_bit_cast(int, A)));
+    float pb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(ad, __builtin_bit_cast(int, Bv)));
+    if (ad < 0) { pa = 1.f; pb = 0.f; }
+    Bv = fmaf(A, pb, Bv);
+    A *= pa;
   }
 }
 
+// cooperative load of the chunk's B and C tiles ([NS][CHUNK] each) into LDS, zero beyond L
+template <int THREADS>
+__device__ __forceinline__ void stage_bc(const float* __restrict__ Bp, const float* __restrict__ Cp, int t0, int L,
+                                         float (*sB)[CHUNK], float (*sC)[CHUNK], bool vec) {
+  if (vec) {
+    for (int i = threadIdx.x; i < NS * CHUNK / 4; i += THREADS) {
+      const int n = i / (CHUNK / 4), tt = (i % (CHUNK / 4)) * 4;
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f), c = b;
+      if (t0 + tt < L) {
+        b = *reinterpret_cast<const float4*>(Bp + (size_t)n * L + t0 + tt);
+        c = *reinterpret_cast<const float4*>(Cp + (size_t)n * L + t0 + tt);
+      }
+      *reinterpret_cast<float4*>(&sB[n][tt]) = b;
+      *reinterpret_cast<float4*>(&sC[n][tt]) = c;
+    }
+  } else {
+    for (int i = threadIdx.x; i < NS * CHUNK; i += THREADS) {
+      const int n = i / CHUNK, tt = i % CHUNK;
+      const bool ok = t0 + tt < L;
+      sB[n][tt] = ok ? Bp[(size_t)n * L + t0 + tt] : 0.f;
+      sC[n][tt] = ok ? Cp[(size_t)n * L + t0 + tt] : 0.f;
+    }
+  }
+}
+
+// Forward: FWD_ROWS waves = FWD_ROWS rows of ONE (b, k) group per workgroup.
 template <bool VEC>
 __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float* __restrict__ u, const float* __restrict__ delta,
                                                                       const float* __restrict__ Am, const float* __restrict__ Bm,
                                                                       const float* __restrict__ Cm, const float* __restrict__ Dv,
                                                                       const float* __restrict__ dbias, float* __restrict__ y,
-                                                                      float* __restrict__ hstate, int n_rows, int K, int Dk, int L,
-                                                                      int nchunk) {
+                                                                      float* __restrict__ hstate, int K, int Dk, int L, int nchunk) {
+  __shared__ float sB[NS][CHUNK];
+  __shared__ float sC[NS][CHUNK];
+  __shared__ float s_A[FWD_ROWS][NS], s_h[FWD_ROWS][NS];  // wave-private, wave-uniform per-state values (A*log2e, carried h)
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-  const int row = blockIdx.x * FWD_ROWS + wave;  // row = b*K*Dk + k*Dk + d
-  if (row >= n_rows) return;
-  const int kd = row % (K * Dk);
-  const int b = row / (K * Dk);
-  const int k = kd / Dk;
-  const float* up = u + (size_t)row * L;
-  const float* dp = delta + (size_t)row * L;
-  const float* Bp = Bm + ((size_t)b * K + k) * NS * L;
-  const float* Cp = Cm + ((size_t)b * K + k) * NS * L;
-  float* yp = y + (size_t)row * L;
-  // per-state wave-uniform values (A_n, carried h_n) live in LDS so that the state loop can stay rolled: only this
-  // wave touches its slots and a wave's LDS operations execute in order, so no barrier is involved
-  __shared__ float s_A[FWD_ROWS][NS], s_h[FWD_ROWS][NS];
+  const int d = blockIdx.x * FWD_ROWS + wave;
+  const bool live = d < Dk;
+  const int bk = blockIdx.y, k = bk % K;
+  const int kd = k * Dk + (live ? d : 0);
+  const size_t row = (size_t)(bk / K) * K * Dk + kd;
+  const float* up = u + row * L;
+  const float* dp = delta + row * L;
+  const float* Bp = Bm + (size_t)bk * NS * L;
+  const float* Cp = Cm + (size_t)bk * NS * L;
+  float* yp = y + row * L;
   float* An = s_A[wave];
   float* h = s_h[wave];
-  if (lane < NS) { An[lane] = Am[(size_t)kd * NS + lane]; h[lane] = 0.f; }
+  if (lane < NS) { An[lane] = Am[(size_t)kd * NS + lane] * LOG2E; h[lane] = 0.f; }
   const float Dd = Dv[kd], bias = dbias[kd];
 
   for (int c = 0; c < nchunk; ++c) {
+    __syncthreads();  // previous chunk's tile fully consumed
+    stage_bc<FWD_ROWS * WAVE>(Bp, Cp, c * CHUNK, L, sB, sC, VEC);
+    __syncthreads();
+    if (!live) continue;
     const int t = c * CHUNK + lane * ITEMS;
-    float uu[ITEMS], dt[ITEMS], yy[ITEMS];
+    float uu[ITEMS], dt[ITEMS], dtu[ITEMS], yy[ITEMS];
     load4<VEC>(up, t, L, uu, 0.f);
     load4<VEC>(dp, t, L, dt, 0.f);
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-      // steps beyond L become the identity map (a = 1, b = 0)
-      dt[i] = (t + i < L) ? softplus_f(dt[i] + bias) : 0.f;
+      dt[i] = (t + i < L) ? softplus_f(dt[i] + bias) : 0.f;  // steps beyond L become the identity map (a = 1, b = 0)
+      dtu[i] = dt[i] * uu[i];
       yy[i] = Dd * uu[i];
     }
 #pragma unroll 4
     for (int n = 0; n < NS; ++n) {
-      float bb[ITEMS], cc[ITEMS], a[ITEMS];
-      load4<VEC>(Bp + (size_t)n * L, t, L, bb, 0.f);
-      load4<VEC>(Cp + (size_t)n * L, t, L, cc, 0.f);
+      const float4 b4 = *reinterpret_cast<const float4*>(&sB[n][lane * ITEMS]);
+      const float4 c4 = *reinterpret_cast<const float4*>(&sC[n][lane * ITEMS]);
+      float bb[ITEMS] = {b4.x, b4.y, b4.z, b4.w}, cc[ITEMS] = {c4.x, c4.y, c4.z, c4.w}, a[ITEMS];
       const float An_n = An[n];
-      float PA = 1.f, PB = 0.f;
+      float A = 1.f, Bv = 0.f;
 #pragma unroll
       for (int i = 0; i < ITEMS; ++i) {
-        a[i] = __expf(dt[i] * An_n);
-        bb[i] = dt[i] * uu[i] * bb[i];
-        PB = fmaf(a[i], PB, bb[i]);
-        PA *= a[i];
+        a[i] = __builtin_amdgcn_exp2f(dt[i] * An_n);
+        bb[i] *= dtu[i];
+        Bv = fmaf(a[i], Bv, bb[i]);
+        A *= a[i];
       }
-      wave_scan_prefix(PA, PB, lane);
-      float EA = __shfl_up(PA, 1, WAVE), EB = __shfl_up(PB, 1, WAVE);
-      if (lane == 0) { EA = 1.f; EB = 0.f; }
+      wave_scan_prefix(A, Bv);
+      const float EA = prev_lane(1.f, A), EB = prev_lane(0.f, Bv);
       float hh = fmaf(EA, h[n], EB);  // state entering this lane's first step
 #pragma unroll
       for (int i = 0; i < ITEMS; ++i) {
@@ -132,186 +196,252 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
       if (lane == WAVE - 1) h[n] = hh;  // state after the chunk
     }
     store4<VEC>(yp, t, L, yy);
-    if (lane < NS) hstate[((size_t)row * nchunk + c) * NS + lane] = h[lane];
+    if (lane < NS) hstate[(row * nchunk + c) * NS + lane] = h[lane];
   }
 }
 
+// Backward: BWD_WAVES waves x BWD_RPW rows each = BWD_ROWS rows of one (b, k) group per workgroup.
 template <bool VEC>
-__global__ __launch_bounds__(BWD_ROWS* WAVE) void selscan_bwd_kernel(
+__global__ __launch_bounds__(BWD_WAVES* WAVE) void selscan_bwd_kernel(
     const float* __restrict__ gy, const float* __restrict__ u, const float* __restrict__ delta, const float* __restrict__ Am,
     const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ Dv, const float* __restrict__ dbias,
     const float* __restrict__ hstate, float* __restrict__ gu, float* __restrict__ gdelta, float* __restrict__ gA,
-    float* __restrict__ gB, float* __restrict__ gC, float* __restrict__ gD, float* __restrict__ gdbias, int K, int Dk, int L,
-    int nchunk) {
+    float* __restrict__ wsB, float* __restrict__ wsC, float* __restrict__ gD, float* __restrict__ gdbias, int K, int Dk, int L,
+    int nchunk, size_t slab_elems) {
+  __shared__ float sB[NS][CHUNK];
+  __shared__ float sC[NS][CHUNK];
   __shared__ float s_dB[NS][CHUNK];
   __shared__ float s_dC[NS][CHUNK];
-  __shared__ float s_A[BWD_ROWS][NS], s_carry[BWD_ROWS][NS];  // wave-private, wave-uniform per-state values
-  __shared__ float s_dA[BWD_ROWS][NS][WAVE];                   // per-lane dA partial sums
+  __shared__ float s_A[BWD_WAVES][BWD_RPW][NS], s_carry[BWD_WAVES][BWD_RPW][NS], s_dA[BWD_WAVES][BWD_RPW][NS];
+  __shared__ float s_dD[BWD_WAVES][BWD_RPW], s_db[BWD_WAVES][BWD_RPW];
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-  // grid: x = row-block inside the (b,k) group, y = b*K + k  -> all waves of a workgroup share B/C
-  const int d = blockIdx.x * BWD_ROWS + wave;
-  const bool live = d < Dk;
-  const int bk = blockIdx.y;
-  const int k = bk % K;
-  const int kd = k * Dk + (live ? d : 0);
-  const size_t row = (size_t)(bk / K) * K * Dk + kd;
-  const float* up = u + row * L;
-  const float* dp = delta + row * L;
-  const float* gyp = gy + row * L;
+  const int bk = blockIdx.y, k = bk % K;
   const float* Bp = Bm + (size_t)bk * NS * L;
   const float* Cp = Cm + (size_t)bk * NS * L;
-  float* An = s_A[wave];
-  float* carry = s_carry[wave];
-  if (lane < NS) { An[lane] = Am[(size_t)kd * NS + lane]; carry[lane] = 0.f; }
-  for (int n = 0; n < NS; ++n) s_dA[wave][n][lane] = 0.f;
-  const float Dd = Dv[kd], bias = dbias[kd];
-  float dD = 0.f, dbs = 0.f;
+  float* slabB = wsB + (size_t)blockIdx.x * slab_elems + (size_t)bk * NS * L;
+  float* slabC = wsC + (size_t)blockIdx.x * slab_elems + (size_t)bk * NS * L;
+  const int d0 = blockIdx.x * BWD_ROWS + wave * BWD_RPW;
+  // ds_bpermute byte addresses of the first lane of the next / next-but-one 16-lane row (suffix scan, cross-row levels)
+  const int rowi = lane >> 4;
+  const int addr1 = rowi + 1 < 4 ? (rowi + 1) * 64 : -1;
+  const int addr2 = rowi + 2 < 4 ? (rowi + 2) * 64 : -1;
+  for (int r = 0; r < BWD_RPW; ++r) {
+    const int kd = k * Dk + min(d0 + r, Dk - 1);
+    if (lane < NS) { s_A[wave][r][lane] = Am[(size_t)kd * NS + lane]; s_carry[wave][r][lane] = 0.f; s_dA[wave][r][lane] = 0.f; }
+    if (lane == 0) { s_dD[wave][r] = 0.f; s_db[wave][r] = 0.f; }
+  }
 
   for (int c = nchunk - 1; c >= 0; --c) {
-    for (int i = threadIdx.x; i < NS * CHUNK; i += BWD_ROWS * WAVE) { (&s_dB[0][0])[i] = 0.f; (&s_dC[0][0])[i] = 0.f; }
+    __syncthreads();  // previous chunk's tiles fully consumed / flushed
+    stage_bc<BWD_WAVES * WAVE>(Bp, Cp, c * CHUNK, L, sB, sC, VEC);
     __syncthreads();
     const int t = c * CHUNK + lane * ITEMS;
-    if (live) {
-      float uu[ITEMS], dl[ITEMS], dt[ITEMS], g[ITEMS], ddt[ITEMS], du[ITEMS];
-      load4<VEC>(up, t, L, uu, 0.f);
-      load4<VEC>(dp, t, L, dl, 0.f);
-      load4<VEC>(gyp, t, L, g, 0.f);
+    float accB[NS][ITEMS], accC[NS][ITEMS];  // this wave's rows' dB/dC for the chunk, summed in registers
 #pragma unroll
-      for (int i = 0; i < ITEMS; ++i) {
-        dt[i] = (t + i < L) ? softplus_f(dl[i] + bias) : 0.f;
-        ddt[i] = 0.f;
-        du[i] = Dd * g[i];
-        dD = fmaf(g[i], uu[i], dD);
-      }
-#pragma unroll 2
-      for (int n = 0; n < NS; ++n) {
-        float bb[ITEMS], cc[ITEMS], a[ITEMS], hh[ITEMS], bu[ITEMS];
-        load4<VEC>(Bp + (size_t)n * L, t, L, bb, 0.f);
-        load4<VEC>(Cp + (size_t)n * L, t, L, cc, 0.f);
-        const float An_n = An[n];
-        float dA_n = 0.f;
-        // ---- recompute h inside the chunk (same arithmetic as the forward)
-        float PA = 1.f, PB = 0.f;
+    for (int n = 0; n < NS; ++n)
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-          a[i] = __expf(dt[i] * An_n);
-          bu[i] = dt[i] * uu[i] * bb[i];
-          PB = fmaf(a[i], PB, bu[i]);
-          PA *= a[i];
-        }
-        wave_scan_prefix(PA, PB, lane);
-        float EA = __shfl_up(PA, 1, WAVE), EB = __shfl_up(PB, 1, WAVE);
-        if (lane == 0) { EA = 1.f; EB = 0.f; }
-        const float h0 = (c == 0) ? 0.f : hstate[(row * nchunk + (c - 1)) * NS + n];
-        const float hin = fmaf(EA, h0, EB);  // h_{t-1} of this lane's first step
-        float hp = hin;
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) { hp = fmaf(a[i], hp, bu[i]); hh[i] = hp; }
-        // ---- dL/dh suffix scan:  gh_i = cc_i*g_i + a_{i+1} * gh_{i+1}
-        float a_next = __shfl_down(a[0], 1, WAVE);  // a of the next lane's first step
-        if (lane == WAVE - 1) a_next = 1.f;          // the chunk's last step takes `carry` (= a*gh of the next chunk)
-        float al[ITEMS];
-#pragma unroll
-        for (int i = 0; i < ITEMS - 1; ++i) al[i] = a[i + 1];
-        al[ITEMS - 1] = a_next;
-        float SA = 1.f, SB = 0.f;
-#pragma unroll
-        for (int i = ITEMS - 1; i >= 0; --i) { SB = fmaf(al[i], SB, cc[i] * g[i]); SA *= al[i]; }
-        wave_scan_suffix(SA, SB, lane);
-        float XA = __shfl_down(SA, 1, WAVE), XB = __shfl_down(SB, 1, WAVE);
-        if (lane == WAVE - 1) { XA = 1.f; XB = 0.f; }
-        float gh = fmaf(XA, carry[n], XB);  // gh of the step right after this lane's last one (already times its a)
-        float dBv[ITEMS], dCv[ITEMS];
-#pragma unroll
-        for (int i = ITEMS - 1; i >= 0; --i) {
-          gh = fmaf(al[i], gh, cc[i] * g[i]);  // dL/dh_t
-          const float hprev = (i == 0) ? hin : hh[i - 1];
-          const float da = gh * hprev * a[i];  // dL/d(dt*A) through a = exp(dt*A)
-          dA_n = fmaf(da, dt[i], dA_n);
-          ddt[i] = fmaf(da, An_n, ddt[i]);
-          ddt[i] = fmaf(gh * uu[i], bb[i], ddt[i]);
-          du[i] = fmaf(gh * dt[i], bb[i], du[i]);
-          dBv[i] = gh * dt[i] * uu[i];
-          dCv[i] = g[i] * hh[i];
-        }
-        if (lane == 0) carry[n] = a[0] * gh;  // a_t * gh_t of this chunk's first step, for the previous chunk
-        s_dA[wave][n][lane] += dA_n;
+      for (int i = 0; i < ITEMS; ++i) { accB[n][i] = 0.f; accC[n][i] = 0.f; }
+
+#pragma unroll 1
+    for (int r = 0; r < BWD_RPW; ++r) {  // a real loop: the state loop inside is fully unrolled (register tiles accB/accC)
+      const int d = d0 + r;
+      if (d < Dk) {  // wave-uniform
+        const int kd = k * Dk + d;
+        const size_t row = (size_t)(bk / K) * K * Dk + kd;
+        const float Dd = Dv[kd], bias = dbias[kd];
+        const float* An = s_A[wave][r];
+        float* carry = s_carry[wave][r];
+        float uu[ITEMS], dl[ITEMS], dt[ITEMS], g[ITEMS], ddt[ITEMS], du[ITEMS], dtu[ITEMS];
+        float dD = 0.f, dbs = 0.f;
+        load4<VEC>(u + row * L, t, L, uu, 0.f);
+        load4<VEC>(delta + row * L, t, L, dl, 0.f);
+        load4<VEC>(gy + row * L, t, L, g, 0.f);
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
-          atomicAdd(&s_dB[n][lane * ITEMS + i], dBv[i]);
-          atomicAdd(&s_dC[n][lane * ITEMS + i], dCv[i]);
+          dt[i] = (t + i < L) ? softplus_f(dl[i] + bias) : 0.f;
+          dtu[i] = dt[i] * uu[i];
+          ddt[i] = 0.f;
+          du[i] = Dd * g[i];
+          dD = fmaf(g[i], uu[i], dD);
+        }
+        const float* hs = hstate + (row * nchunk + (c > 0 ? c - 1 : 0)) * NS;
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+          const float4 b4 = *reinterpret_cast<const float4*>(&sB[n][lane * ITEMS]);
+          const float4 c4 = *reinterpret_cast<const float4*>(&sC[n][lane * ITEMS]);
+          const float bb[ITEMS] = {b4.x, b4.y, b4.z, b4.w}, cc[ITEMS] = {c4.x, c4.y, c4.z, c4.w};
+          float a[ITEMS], hh[ITEMS], bu[ITEMS], cg[ITEMS];
+          const float An_n = An[n];
+          const float A2 = An_n * LOG2E;
+          // ---- recompute h inside the chunk (same arithmetic as the forward)
+          float A = 1.f, Bv = 0.f;
+#pragma unroll
+          for (int i = 0; i < ITEMS; ++i) {
+            a[i] = __builtin_amdgcn_exp2f(dt[i] * A2);
+            bu[i] = dtu[i] * bb[i];
+            cg[i] = cc[i] * g[i];
+            Bv = fmaf(a[i], Bv, bu[i]);
+            A *= a[i];
+          }
+          wave_scan_prefix(A, Bv);
+          const float EA = prev_lane(1.f, A), EB = prev_lane(0.f, Bv);
+          const float h0 = (c == 0) ? 0.f : hs[n];
+          const float hin = fmaf(EA, h0, EB);  // h_{t-1} of this lane's first step
+          float hp = hin;
+#pragma unroll
+          for (int i = 0; i < ITEMS; ++i) { hp = fmaf(a[i], hp, bu[i]); hh[i] = hp; }
+          // ---- dL/dh suffix scan:  gh_i = cc_i*g_i + a_{i+1} * gh_{i+1}
+          // a of the next lane's first step; the chunk's last step takes `carry` (= a*gh of the next chunk) with factor 1
+          float al[ITEMS];
+#pragma unroll
+          for (int i = 0; i < ITEMS - 1; ++i) al[i] = a[i + 1];
+          al[ITEMS - 1] = next_lane(1.f, a[0]);
+          float SA = 1.f, SB = 0.f;
+#pragma unroll
+          for (int i = ITEMS - 1; i >= 0; --i) { SB = fmaf(al[i], SB, cg[i]); SA *= al[i]; }
+          wave_scan_suffix(SA, SB, addr1, addr2);
+          const float XA = next_lane(1.f, SA), XB = next_lane(0.f, SB);
+          float gh = fmaf(XA, carry[n], XB);  // gh of the step right after this lane's last one (already times its a)
+          float dA_n = 0.f;
+#pragma unroll
+          for (int i = ITEMS - 1; i >= 0; --i) {
+            gh = fmaf(al[i], gh, cg[i]);  // dL/dh_t
+            const float hprev = (i == 0) ? hin : hh[i - 1];
+            const float da = gh * hprev * a[i];  // dL/d(dt*A) through a = exp(dt*A)
+            dA_n = fmaf(da, dt[i], dA_n);
+            ddt[i] = fmaf(da, An_n, ddt[i]);
+            ddt[i] = fmaf(gh * uu[i], bb[i], ddt[i]);
+            du[i] = fmaf(gh * dt[i], bb[i], du[i]);
+            accB[n][i] = fmaf(gh, dtu[i], accB[n][i]);
+            accC[n][i] = fmaf(g[i], hh[i], accC[n][i]);
+          }
+          if (lane == 0) carry[n] = a[0] * gh;  // a_t * gh_t of this chunk's first step, for the previous chunk
+          dA_n = group_sum<WAVE>(dA_n);
+          if (lane == 0) s_dA[wave][r][n] += dA_n;
+        }
+        float gd[ITEMS];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+          gd[i] = (t + i < L) ? ddt[i] * sigmoid_f(dl[i] + bias) : 0.f;
+          dbs += gd[i];
+        }
+        dD = group_sum<WAVE>(dD);
+        dbs = group_sum<WAVE>(dbs);
+        if (lane == 0) { s_dD[wave][r] += dD; s_db[wave][r] += dbs; }
+        store4<VEC>(gu + row * L, t, L, du);
+        store4<VEC>(gdelta + row * L, t, L, gd);
+      }
+    }
+    // ---- fold the BWD_WAVES register tiles into one LDS tile, one wave at a time (plain LDS traffic, no atomics)
+#pragma unroll 1
+    for (int w = 0; w < BWD_WAVES; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+          float4* pb = reinterpret_cast<float4*>(&s_dB[n][lane * ITEMS]);
+          float4* pc = reinterpret_cast<float4*>(&s_dC[n][lane * ITEMS]);
+          float4 vb = make_float4(accB[n][0], accB[n][1], accB[n][2], accB[n][3]);
+          float4 vc = make_float4(accC[n][0], accC[n][1], accC[n][2], accC[n][3]);
+          if (w > 0) {
+            const float4 ob = *pb, oc = *pc;
+            vb.x += ob.x; vb.y += ob.y; vb.z += ob.z; vb.w += ob.w;
+            vc.x += oc.x; vc.y += oc.y; vc.z += oc.z; vc.w += oc.w;
+          }
+          *pb = vb;
+          *pc = vc;
         }
       }
-      float gd[ITEMS];
-#pragma unroll
-      for (int i = 0; i < ITEMS; ++i) {
-        gd[i] = (t + i < L) ? ddt[i] * sigmoid_f(dl[i] + bias) : 0.f;
-        dbs += gd[i];
-      }
-      store4<VEC>(gu + row * L, t, L, du);
-      store4<VEC>(gdelta + row * L, t, L, gd);
+      __syncthreads();
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < NS * CHUNK; i += BWD_ROWS * WAVE) {
-      const int n = i / CHUNK, tt = c * CHUNK + (i % CHUNK);
-      if (tt < L) {
-        atomicAdd(gB + ((size_t)bk * NS + n) * L + tt, (&s_dB[0][0])[i]);
-        atomicAdd(gC + ((size_t)bk * NS + n) * L + tt, (&s_dC[0][0])[i]);
+    // ---- plain, coalesced stores of this workgroup's partial dB/dC tile into its slab
+    if (VEC) {
+      for (int i = threadIdx.x; i < NS * CHUNK / 4; i += BWD_WAVES * WAVE) {
+        const int n = i / (CHUNK / 4), tt = (i % (CHUNK / 4)) * 4, tg = c * CHUNK + tt;
+        if (tg < L) {
+          *reinterpret_cast<float4*>(slabB + (size_t)n * L + tg) = *reinterpret_cast<const float4*>(&s_dB[n][tt]);
+          *reinterpret_cast<float4*>(slabC + (size_t)n * L + tg) = *reinterpret_cast<const float4*>(&s_dC[n][tt]);
+        }
+      }
+    } else {
+      for (int i = threadIdx.x; i < NS * CHUNK; i += BWD_WAVES * WAVE) {
+        const int n = i / CHUNK, tg = c * CHUNK + (i % CHUNK);
+        if (tg < L) { slabB[(size_t)n * L + tg] = s_dB[n][i % CHUNK]; slabC[(size_t)n * L + tg] = s_dC[n][i % CHUNK]; }
       }
     }
-    __syncthreads();
   }
-  if (live) {
-    for (int n = 0; n < NS; ++n) {
-      const float s = group_sum<WAVE>(s_dA[wave][n][lane]);
-      if (lane == 0) atomicAdd(gA + (size_t)kd * NS + n, s);
+#pragma unroll
+  for (int r = 0; r < BWD_RPW; ++r) {
+    const int d = d0 + r;
+    if (d < Dk) {
+      const int kd = k * Dk + d;
+      if (lane < NS) atomicAdd(gA + (size_t)kd * NS + lane, s_dA[wave][r][lane]);  // summed over the batch only: no contention
+      if (lane == 0) { atomicAdd(gD + kd, s_dD[wave][r]); atomicAdd(gdbias + kd, s_db[wave][r]); }
     }
-    dD = group_sum<WAVE>(dD);
-    dbs = group_sum<WAVE>(dbs);
-    if (lane == 0) { atomicAdd(gD + kd, dD); atomicAdd(gdbias + kd, dbs); }
+  }
+}
+
+// out[i] = sum_s ws[s][i]
+__global__ void slab_sum_kernel(const float* __restrict__ wsB, const float* __restrict__ wsC, float* __restrict__ gB,
+                                float* __restrict__ gC, size_t n4, int nslab) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), sc = sb;
+    for (int s = 0; s < nslab; ++s) {
+      const float4 b = reinterpret_cast<const float4*>(wsB)[(size_t)s * n4 + i];
+      const float4 c = reinterpret_cast<const float4*>(wsC)[(size_t)s * n4 + i];
+      sb.x += b.x; sb.y += b.y; sb.z += b.z; sb.w += b.w;
+      sc.x += c.x; sc.y += c.y; sc.z += c.z; sc.w += c.w;
+    }
+    reinterpret_cast<float4*>(gB)[i] = sb;
+    reinterpret_cast<float4*>(gC)[i] = sc;
   }
 }
 
 }  // namespace
 
 extern "C" int tamtr_selective_scan_chunk(void) { return CHUNK; }
+extern "C" int tamtr_selective_scan_bwd_slabs(int Dk) { return Dk > 0 ? (Dk + BWD_ROWS - 1) / BWD_ROWS : 0; }
 
 extern "C" int tamtr_selective_scan_fwd(const float* u, const float* delta, const float* A, const float* Bm, const float* Cm,
                                         const float* D, const float* dbias, float* y, float* hstate, int B, int K, int Dk, int N,
                                         int L, void* stream) {
   if (!u || !delta || !A || !Bm || !Cm || !D || !dbias || !y || !hstate || B <= 0 || K <= 0 || Dk <= 0 || L <= 0)
     return TAMTR_EINVAL;
-  if (N != NS) return TAMTR_EUNSUP;
-  const long long rows = (long long)B * K * Dk;
-  if (rows > (1ll << 30)) return TAMTR_EUNSUP;
+  if (N != NS || (long long)B * K > 65535) return TAMTR_EUNSUP;
   const int nchunk = (L + CHUNK - 1) / CHUNK;
-  dim3 grid((unsigned)((rows + FWD_ROWS - 1) / FWD_ROWS));
+  dim3 grid((Dk + FWD_ROWS - 1) / FWD_ROWS, B * K);
   hipStream_t s = (hipStream_t)stream;
   if (L % 4 == 0)
-    hipLaunchKernelGGL(selscan_fwd_kernel<true>, grid, dim3(FWD_ROWS * WAVE), 0, s, u, delta, A, Bm, Cm, D, dbias, y, hstate,
-                       (int)rows, K, Dk, L, nchunk);
+    hipLaunchKernelGGL(selscan_fwd_kernel<true>, grid, dim3(FWD_ROWS * WAVE), 0, s, u, delta, A, Bm, Cm, D, dbias, y, hstate, K, Dk, L,
+                       nchunk);
   else
-    hipLaunchKernelGGL(selscan_fwd_kernel<false>, grid, dim3(FWD_ROWS * WAVE), 0, s, u, delta, A, Bm, Cm, D, dbias, y, hstate,
-                       (int)rows, K, Dk, L, nchunk);
+    hipLaunchKernelGGL(selscan_fwd_kernel<false>, grid, dim3(FWD_ROWS * WAVE), 0, s, u, delta, A, Bm, Cm, D, dbias, y, hstate, K, Dk, L,
+                       nchunk);
   return tamtr_launch_status();
 }
 
 extern "C" int tamtr_selective_scan_bwd(const float* gy, const float* u, const float* delta, const float* A, const float* Bm,
                                         const float* Cm, const float* D, const float* dbias, const float* hstate, float* gu,
-                                        float* gdelta, float* gA, float* gB, float* gC, float* gD, float* gdbias, int B, int K,
-                                        int Dk, int N, int L, void* stream) {
+                                        float* gdelta, float* gA, float* gB, float* gC, float* gD, float* gdbias, float* ws, int B,
+                                        int K, int Dk, int N, int L, void* stream) {
   if (!gy || !u || !delta || !A || !Bm || !Cm || !D || !dbias || !hstate || !gu || !gdelta || !gA || !gB || !gC || !gD ||
-      !gdbias || B <= 0 || K <= 0 || Dk <= 0 || L <= 0)
+      !gdbias || !ws || B <= 0 || K <= 0 || Dk <= 0 || L <= 0)
     return TAMTR_EINVAL;
   if (N != NS || (long long)B * K > 65535) return TAMTR_EUNSUP;
   const int nchunk = (L + CHUNK - 1) / CHUNK;
-  dim3 grid((Dk + BWD_ROWS - 1) / BWD_ROWS, B * K);
+  const int nslab = (Dk + BWD_ROWS - 1) / BWD_ROWS;
+  const size_t slab = (size_t)B * K * NS * L;
+  float* wsB = ws;
+  float* wsC = ws + (size_t)nslab * slab;
+  dim3 grid(nslab, B * K);
   hipStream_t s = (hipStream_t)stream;
   if (L % 4 == 0)
-    hipLaunchKernelGGL(selscan_bwd_kernel<true>, grid, dim3(BWD_ROWS * WAVE), 0, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu,
-                       gdelta, gA, gB, gC, gD, gdbias, K, Dk, L, nchunk);
+    hipLaunchKernelGGL(selscan_bwd_kernel<true>, grid, dim3(BWD_WAVES * WAVE), 0, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu,
+                       gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab);
   else
-    hipLaunchKernelGGL(selscan_bwd_kernel<false>, grid, dim3(BWD_ROWS * WAVE), 0, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu,
-                       gdelta, gA, gB, gC, gD, gdbias, K, Dk, L, nchunk);
+    hipLaunchKernelGGL(selscan_bwd_kernel<false>, grid, dim3(BWD_WAVES * WAVE), 0, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu,
+                       gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab);
+  const size_t n4 = slab / 4;  // N = 16 makes slab a multiple of 4
+  const unsigned blocks = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, s, wsB, wsC, gB, gC, n4, nslab);
   return tamtr_launch_status();
 }

@@ -264,10 +264,12 @@ class _SelectiveScan(torch.autograd.Function):
         K, N = Bm.shape[1], Bm.shape[2]
         gy = _c(gy.float())
         gu, gdelta = torch.empty_like(u), torch.empty_like(u)
-        gA, gB, gC = torch.zeros_like(A), torch.zeros_like(Bm), torch.zeros_like(Cm)
+        gA, gB, gC = torch.zeros_like(A), torch.empty_like(Bm), torch.empty_like(Cm)
         gD, gbias = torch.zeros_like(D), torch.zeros_like(dbias)
+        nslab = _lib.lib().tamtr_selective_scan_bwd_slabs(KD // K)
+        ws = torch.empty(2 * nslab * Bm.numel(), device=u.device, dtype=torch.float32)  # per-workgroup dB/dC slabs
         call('tamtr_selective_scan_bwd', ptr(gy), ptr(u), ptr(delta), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(dbias), ptr(hstate), ptr(gu),
-             ptr(gdelta), ptr(gA), ptr(gB), ptr(gC), ptr(gD), ptr(gbias), Bn, K, KD // K, N, L, stream_ptr())
+             ptr(gdelta), ptr(gA), ptr(gB), ptr(gC), ptr(gD), ptr(gbias), ptr(ws), Bn, K, KD // K, N, L, stream_ptr())
         return gu, gdelta, gA, gB, gC, gD, gbias
 
 

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the individual HIP kernels at the BASELINE shapes (640^2, bs 16).  Prints one line per kernel:
+avg ms over interleaved rounds, algorithmic GB/s or TFLOP/s.   python tools/bench_kernels.py [scan|gemm|gate|msda|attn|all]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tamtr_amd.ops as ops  # noqa: E402
+
+
+def timeit(fn, n=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in ev)
+    return sum(ms) / len(ms), ms[0]
+
+
+def bench_scan():
+    for lvl, (d_inner, L) in enumerate([(256, 25600), (512, 6400), (1024, 1600)]):
+        B, K, N = 16, 4, 16
+        g = torch.Generator(device='cuda').manual_seed(0)
+        u = torch.randn(B, K * d_inner, L, device='cuda', generator=g)
+        dl = torch.randn(B, K * d_inner, L, device='cuda', generator=g)
+        A = -torch.exp(torch.randn(K * d_inner, N, device='cuda', generator=g) * 0.3)
+        Bm = torch.randn(B, K, N, L, device='cuda', generator=g)
+        Cm = torch.randn(B, K, N, L, device='cuda', generator=g)
+        D = torch.randn(K * d_inner, device='cuda', generator=g)
+        bias = torch.randn(K * d_inner, device='cuda', generator=g) - 3
+        ins = [t.requires_grad_() for t in (u, dl, A, Bm, Cm, D, bias)]
+        y = ops.selective_scan(*ins)
+        gy = torch.randn_like(y)
+        f_avg, f_min = timeit(lambda: ops.selective_scan(*ins))
+        def fb():
+            yy = ops.selective_scan(*ins)
+            torch.autograd.grad(yy, ins, gy)
+        fb_avg, fb_min = timeit(fb)
+        byt = u.numel() * 4
+        print(f'scan level {lvl} d_inner={d_inner} L={L}: fwd {f_avg:.2f} ms ({3 * byt / f_avg / 1e6:.0f} GB/s algorithmic), '
+              f'bwd {fb_avg - f_avg:.2f} ms ({5 * byt / (fb_avg - f_avg) / 1e6:.0f} GB/s)')
+
+
+def bench_gemm():
+    M, N, K = 16 * 33600, 512, 512
+    x = torch.randn(M, K, device='cuda').bfloat16()
+    w = (torch.randn(N, K, device='cuda') * K ** -0.5)
+    b = torch.randn(N, device='cuda')
+    w16 = w.bfloat16()
+    a, mn = timeit(lambda: ops.linear_bf16(x, w, b), n=10)
+    print(f'linear_bf16 M={M}: {a * 1e3:.0f} us avg, {mn * 1e3:.0f} us min, {2 * M * N * K / a / 1e9:.0f} TFLOP/s avg, '
+          f'{(M * K + M * N) * 2 / a / 1e6:.0f} GB/s')
+    a, mn = timeit(lambda: torch.nn.functional.linear(x, w16, b.bfloat16()), n=10)
+    print(f'torch/hipBLASLt same shape: {a * 1e3:.0f} us avg, {2 * M * N * K / a / 1e9:.0f} TFLOP/s')
+
+
+def bench_gate():
+    for (C, nh, H) in [(256, 8, 40), (128, 4, 80), (64, 2, 160)]:
+        for dt in (torch.float32, torch.bfloat16):
+            x = torch.randn(16, C, H, H, device='cuda').to(dt)
+            v = torch.randn(16, C, H, H, device='cuda').to(dt)
+            gk = torch.randn(16, 10, C, device='cuda')
+            bias = torch.zeros(nh, device='cuda')
+            a, mn = timeit(lambda: ops.maxsigmoid_gate(x, gk, bias, v, nh), n=10)
+            byt = 3 * x.numel() * x.element_size()
+            print(f'gate C={C} {H}x{H} {str(dt)[6:]}: {a * 1e3:.0f} us, {byt / a / 1e6:.0f} GB/s (x + v + out)')
+
+
+def bench_msda():
+    B, Q, M, D = 16, 292, 8, 64
+    shapes = [(160, 160), (80, 80), (40, 40)]
+    L = sum(h * w for h, w in shapes)
+    for dt in (torch.float32, torch.bfloat16):
+        v = torch.randn(B, L, M, D, device='cuda').to(dt).requires_grad_()
+        loc = (0.5 + 0.15 * torch.randn(B, Q, M, 3, 4, 2, device='cuda')).requires_grad_()
+        aw = torch.softmax(torch.randn(B, Q, M, 12, device='cuda'), -1).view(B, Q, M, 3, 4).requires_grad_()
+        a, _ = timeit(lambda: ops.ms_deform_attn_core(v, shapes, loc, aw), n=10)
+        out = ops.ms_deform_attn_core(v, shapes, loc, aw)
+        go = torch.randn_like(out)
+        def fb():
+            o = ops.ms_deform_attn_core(v, shapes, loc, aw)
+            torch.autograd.grad(o, [v, loc, aw], go)
+        ab, _ = timeit(fb, n=10)
+        gathered = B * Q * M * 12 * 4 * D * v.element_size()
+        print(f'msda {str(dt)[6:]}: fwd {a * 1e3:.0f} us ({gathered / a / 1e6:.0f} GB/s gathered), fwd+bwd {ab * 1e3:.0f} us')
+
+
+def bench_attn():
+    B, Q, nh, dh = 16, 292, 8, 64
+    for dt in (torch.float32, torch.bfloat16):
+        p = torch.randn(B, Q, 3 * nh * dh, device='cuda').to(dt).requires_grad_()
+        C = nh * dh
+        mask = torch.zeros(Q, Q, dtype=torch.bool, device='cuda')
+        mask[192:, :192] = True
+        f = lambda: ops.self_attention(p[..., :C], p[..., C:2 * C], p[..., 2 * C:], nh, mask)
+        a, _ = timeit(f, n=10)
+        go = torch.randn(B, Q, C, device='cuda').to(dt)
+        def fb():
+            torch.autograd.grad(f(), [p], go)
+        ab, _ = timeit(fb, n=10)
+        print(f'self-attn {str(dt)[6:]}: fwd {a * 1e3:.0f} us, fwd+bwd {ab * 1e3:.0f} us ({4 * B * nh * Q * Q * dh / a / 1e9:.1f} TFLOP/s fwd)')
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['all']
+    for name in ('scan', 'gemm', 'gate', 'msda', 'attn'):
+        if name in which or 'all' in which:
+            globals()['bench_' + name]()
