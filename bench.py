@@ -74,32 +74,53 @@ class KernelTimer:
         return {'launches': len(ms), 'avg_ms': avg, 'min_ms': ms[0], 'tflops': self.flops / (avg * 1e-3) / 1e12}
 
 
+def host_cores():
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota (the GPU boxes give a 1-GPU job a
+    share of a large host) and by 32."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
 def cpu_baseline(n_img=2, S=640):
     """The CPU oracle (port) on this box's host cores: one fwd+bwd of the same graph on n_img images."""
+    cores = host_cores()
+    os.environ['OMP_NUM_THREADS'] = str(cores)  # the C scan twin's OpenMP runtime (loaded lazily below)
+    torch.set_num_threads(cores)
     from oracle import selscan_c, specs, tamtr_oracle as O
     sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
     from weights import fill_state
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    torch.set_num_threads(cores)
+    print(f'[bench] cpu_baseline: CPU oracle on {cores} host threads, {n_img} image(s) {S}x{S}', file=sys.stderr, flush=True)
     st = fill_state(specs.tamtr_model(10, vss=True), 7)
     for k, v in st.items():
         if v.dtype.is_floating_point and not k.endswith(('running_mean', 'running_var')):
             v.requires_grad_()
-    b = synth_batch(n_img, S, 1, 'cpu')
-    tiny = synth_batch(n_img, 64, 1, 'cpu')
+    b = synth_batch(max(n_img, 2), S, 1, 'cpu')  # BatchNorm in train mode needs > 1 value per channel at the deepest maps
+    keep = b['batch_idx'] < n_img
+    b = {'img': b['img'][:n_img], 'txt_feats': b['txt_feats'][:n_img], 'cls': b['cls'][keep], 'bboxes': b['bboxes'][keep],
+         'batch_idx': b['batch_idx'][keep]}
+    tiny = synth_batch(2, 64, 1, 'cpu')
     torch.manual_seed(0)
     O.tamtr_loss(st, tiny, True, scan_fn=selscan_c.scan)[0].backward()  # thread-pool / allocator warm-up, untimed
+    print('[bench] cpu_baseline: warm-up done, timing', file=sys.stderr, flush=True)
     t0 = time.time()
     torch.manual_seed(0)
     loss = O.tamtr_loss(st, b, True, scan_fn=selscan_c.scan)[0]
+    t1 = time.time()
+    print(f'[bench] cpu_baseline: forward {t1 - t0:.1f} s', file=sys.stderr, flush=True)
     loss.backward()
     dt = time.time() - t0
     return {'value': n_img / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'{n_img} images 640x640, 1 fwd+bwd step of the fp32 CPU oracle (C scan twin, torch CPU ops), {dt:.1f} s'}
+            'sample': f'{n_img} image(s) 640x640, 1 fwd+bwd step of the fp32 CPU oracle (torch CPU ops + C scan twin), {dt:.1f} s'}
 
 
 def main():
