@@ -44,34 +44,30 @@ def synth_batch(B, S, seed, device):
 
 
 class KernelTimer:
-    """Wraps tamtr_amd.ops.linear_bf16 with a pair of events on the launch stream (torch's current stream)."""
+    """Events on the launch stream (torch's current stream) tightly around the tamtr_linear_bf16 C call (ops.KERNEL_EVENTS)."""
 
     def __init__(self):
-        self.events, self.flops, self.enabled = [], 0.0, False
+        self.enabled = False
 
     def install(self):
-        import tamtr_amd.modules as M
         import tamtr_amd.ops as ops
-        inner = ops.linear_bf16
+        self.ops = ops
 
-        def timed(x, w, b=None):
-            if not self.enabled:
-                return inner(x, w, b)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            y = inner(x, w, b)
-            e1.record()
-            self.events.append((e0, e1))
-            self.flops = 2.0 * x.numel() * w.shape[0]
-            return y
-        M.ops.linear_bf16 = timed
+    def __setattr__(self, k, v):
+        object.__setattr__(self, k, v)
+        if k == 'enabled' and hasattr(self, 'ops'):
+            if v:
+                self.ops.KERNEL_EVENTS['tamtr_linear_bf16'] = []
+            else:
+                self.events = self.ops.KERNEL_EVENTS.pop('tamtr_linear_bf16', getattr(self, 'events', []))
 
     def summary(self):
-        if not self.events:
+        ev = getattr(self, 'events', [])
+        if not ev:
             return None
-        ms = sorted(a.elapsed_time(b) for a, b in self.events)
+        ms = sorted(a.elapsed_time(b) for a, b, _ in ev)
         avg = sum(ms) / len(ms)
-        return {'launches': len(ms), 'avg_ms': avg, 'min_ms': ms[0], 'tflops': self.flops / (avg * 1e-3) / 1e12}
+        return {'launches': len(ms), 'avg_ms': avg, 'min_ms': ms[0], 'tflops': ev[0][2] / (avg * 1e-3) / 1e12}
 
 
 def host_cores():

@@ -144,11 +144,403 @@ __global__ __launch_bounds__(GT, 2) void linear_bf16_kernel(const bf16_t* __rest
   }
 }
 
+// =====================================================================================================================
+// N-tile = 512 variant (the value projection itself: N = K = 512).  A workgroup owns 128 rows x ALL 512 columns, so X is
+// read from HBM exactly once by construction and the operand that is re-read per workgroup is the small one (W, 512 KB,
+// always L2-resident).  8 waves (2 along M x 4 along N), each 64 x 128 outputs = 4x2 MFMA tiles (128 accumulator
+// registers); K runs in 32-deep steps through a 3-stage LDS ring filled by global_load_lds (16 B per lane, 1 KiB per
+// wave-instruction, no staging registers); the XOR swizzle (chunk ^ ((row >> 2) & 3) on 64-B rows, conflict-free for
+// ds_read_b128's 16-lane groups) is applied on the SOURCE address because LDS-DMA writes lane-linear; loads of step k+2
+// are in flight across the barrier of step k+1 (counted vmcnt, raw s_barrier).
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gl_void;
+
+constexpr int TM = 128, TN = 512, TK = 32, NST = 4, T5 = 512;
+constexpr int ROWB = TK * 2;                       // 64 B per staged row
+constexpr int W_BYTES = TN * ROWB;                 // 32 KB
+constexpr int ST_BYTES = (TN + TM) * ROWB;         // 40 KB per stage
+constexpr int GROUPS = (TN + TM) / 16;             // 1-KiB row groups per stage = 40
+constexpr int GPW = GROUPS / (T5 / 64);            // groups per wave = 5
+
+__device__ __forceinline__ uint32_t swz64(int row, int chunk) { return (uint32_t)row * ROWB + (uint32_t)((chunk ^ ((row >> 2) & 3)) << 4); }
+
+constexpr int EPQ = 32 + 8;                        // epilogue quarter pitch (bf16 elements): 32 columns + pad
+constexpr int EP_BYTES = 8 * 64 * EPQ * 2;         // 40 KB, outside the ring so that the next tile's loads keep flowing
+
+// PERSISTENT: one workgroup per CU walks tiles t = blockIdx.x, += gridDim.x.  The k-step stream is continuous across
+// tiles (step s+2 is always in flight, also over a tile boundary), so only the very first tile pays a cold prologue;
+// the epilogue goes through its own LDS region while the next tile's first stages are already landing in the ring.
+__global__ __launch_bounds__(T5, 1) void linear_bf16_n512_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                                  const float* __restrict__ bias, bf16_t* __restrict__ Y, int M,
+                                                                  int N, int K, int n_blocks, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [NST stages][W tile | X tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int nk = K / TK;
+  const int my_tiles = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_tiles * nk;
+
+  // ---- LDS-DMA assignment: wave w fills row groups w*5 .. w*5+4 of every stage; lane -> (row lane>>2, physical chunk lane&3)
+  const int srow = lane >> 2;
+  const int slog = (lane & 3) ^ ((lane >> 4) & 3);  // logical 16-B chunk this lane must fetch (row & 15 == lane >> 2)
+  auto issue = [&](int s) {
+    const int tile = (int)blockIdx.x + (s / nk) * (int)gridDim.x;
+    const int m0 = (tile / n_blocks) * TM, n0 = (tile % n_blocks) * TN;
+    const int k0 = (s % nk) * TK;
+    unsigned char* stage = smem + (s % NST) * ST_BYTES;
+#pragma unroll
+    for (int j = 0; j < GPW; ++j) {
+      const int g = wave * GPW + j;
+      const bf16_t* src;
+      if (g < TN / 16) src = W + (size_t)(n0 + g * 16 + srow) * K + slog * 8 + k0;
+      else src = X + (size_t)min(m0 + (g - TN / 16) * 16 + srow, M - 1) * K + slog * 8 + k0;  // rows >= M: re-read row M-1
+#ifdef GEMM_ABL_NO_W
+      if (g < TN / 16) continue;
+#endif
+#ifdef GEMM_ABL_NO_X
+      if (g >= TN / 16) src = X + (size_t)srow * K + slog * 8;
+#endif
+      __builtin_amdgcn_global_load_lds((gl_void*)src, (lds_void*)(stage + g * 1024), 16, 0, 0);
+    }
+  };
+
+  if (total > 0) issue(0);
+  if (total > 1) issue(1);
+  if (total > 2) issue(2);
+  int s = 0;
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    const int tile = (int)blockIdx.x + ti * (int)gridDim.x;
+    const int m0 = (tile / n_blocks) * TM, n0 = (tile % n_blocks) * TN;
+    // accumulators start at the bias (rows of D = n): no global load is left in the epilogue, where its s_waitcnt vmcnt(0)
+    // would also wait for every store issued before it (measured: 16 serialised L2 round trips per tile, ~55 % of the kernel)
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bv = *reinterpret_cast<const float4*>(bias + n0 + wn * 128 + i * 32 + 8 * g + 4 * lh);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j][4 * g] = bv.x; acc[i][j][4 * g + 1] = bv.y; acc[i][j][4 * g + 2] = bv.z; acc[i][j][4 * g + 3] = bv.w;
+        }
+      }
+
+    for (int kt = 0; kt < nk; ++kt, ++s) {
+      // step s has landed for this wave once at most the two newer groups (steps s+1, s+2) are outstanding: the ring is 4
+      // deep so that 3 steps = 120 KB are in flight per CU (ingest rate = bytes in flight / latency: with 80 KB in flight
+      // the LDS-DMA stream alone took 248 us for this GEMM)
+      if (s + 2 < total) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if (s + 1 < total) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave's part of step s is in LDS; everyone is done reading step s-1
+      const unsigned char* sw = smem + (s % NST) * ST_BYTES;
+      const unsigned char* sx = sw + W_BYTES;
+      // all 12 fragments of the step first (48 VGPRs), then the LDS-DMA issue for step s+2 (its ~60-100 cycles per piece
+      // run while the reads are in flight), then 16 MFMAs back to back
+      s16x8 fw[2][4], fx[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int c = ks * 2 + lh;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fw[ks][i] = *reinterpret_cast<const s16x8*>(sw + swz64(wn * 128 + i * 32 + lr, c));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fx[ks][j] = *reinterpret_cast<const s16x8*>(sx + swz64(wm * 64 + j * 32 + lr, c));
+      }
+      if (s + 3 < total) issue(s + 3);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks][i], fx[ks][j], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- epilogue (wave-private LDS image): D[i][j]: n = wn*128 + i*32 + (r&3) + 8*(r>>2) + 4*lh, m = wm*64 + j*32 + lr
+    // image aliased onto the stage the tile's last step consumed (free until issue(s+3) at the next step's barrier)
+    __builtin_amdgcn_s_barrier();  // all waves done reading that stage
+    bf16_t* ep = reinterpret_cast<bf16_t*>(smem + ((s - 1) % NST) * ST_BYTES) + wave * 64 * EPQ;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // one 32-column quarter of the wave's 128 columns at a time
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nn = 8 * g + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          uint2 pk;
+          pk.x = (uint32_t)f2bf(acc[i][j][4 * g]) | ((uint32_t)f2bf(acc[i][j][4 * g + 1]) << 16);
+          pk.y = (uint32_t)f2bf(acc[i][j][4 * g + 2]) | ((uint32_t)f2bf(acc[i][j][4 * g + 3]) << 16);
+          *reinterpret_cast<uint2*>(ep + (j * 32 + lr) * EPQ + nn) = pk;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {  // 64 rows x 64 B: 4 lanes per row, 16 rows per instruction
+        const int row = it * 16 + (lane >> 2), cc = (lane & 3) * 8;
+        const int gm = m0 + wm * 64 + row;
+        const uint4 vv = *reinterpret_cast<const uint4*>(ep + row * EPQ + cc);
+#ifdef GEMM_ABL_NO_STORE
+        if (gm < M && vv.x == 0x12345678u)
+#else
+        if (gm < M)
+#endif
+          *reinterpret_cast<uint4*>(Y + (size_t)gm * N + n0 + wn * 128 + i * 32 + cc) = vv;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// TK = 64 variant: 128-B row pieces (whole cache lines per LDS-DMA request), 2-stage ring of 80 KB, epilogue image aliased
+// onto the stage that was just consumed.
+constexpr int K6 = 64, ROW6 = 128, W6_BYTES = TN * ROW6, ST6 = (TN + TM) * ROW6, G6 = ST6 / 1024, GPW6 = G6 / 8;
+__device__ __forceinline__ uint32_t swz128(int row, int chunk) { return (uint32_t)row * ROW6 + (uint32_t)((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__global__ __launch_bounds__(T5, 1) void linear_bf16_n512_k64_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                                      const float* __restrict__ bias, bf16_t* __restrict__ Y, int M,
+                                                                      int N, int K, int n_blocks, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][W tile | X tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int nk = K / K6;
+  const int my_tiles = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_tiles * nk;
+  const int srow = lane >> 3;  // 8 rows of 128 B per 1-KiB piece
+  // ---- LDS-DMA addressing, all hoisted: per lane a 32-bit byte offset per piece (relative to the tile's W / X row 0),
+  // per wave a running step cursor (tile index, k offset) advanced by addition only.  (A first version recomputed
+  // tile = s / nk, m0, min(row, M-1) and 64-bit products inside every step: in-kernel stamps put 35 % of the wave time there.)
+  uint32_t poff[GPW6];
+  bool px[GPW6];
+#pragma unroll
+  for (int j = 0; j < GPW6; ++j) {
+    const int g = wave * GPW6 + j;
+    const int slog = (lane & 7) ^ ((4 * g + (lane >> 4)) & 7);  // logical chunk: row = 8g + lane>>3, swizzle (row>>1)&7
+    px[j] = g >= W6_BYTES / 1024;
+    const int row = (px[j] ? g - W6_BYTES / 1024 : g) * 8 + srow;
+    poff[j] = ((uint32_t)row * (uint32_t)K + (uint32_t)slog * 8u) * 2u;
+  }
+  int is_tile = (int)blockIdx.x, is_k = 0, is_s = 0;  // issue cursor
+  const uint32_t xlast = ((uint32_t)(M - 1) * (uint32_t)K) * 2u;  // byte offset of the last valid X row
+  // a step's GPW6 pieces are emitted a few at a time between the MFMA groups (issue_begin / issue_piece x GPW6 /
+  // issue_end): all 80 pieces of a CU fired back to back right after the barrier queue up in the CU's one vector-memory
+  // pipe (measured 266 cycles of issue stall per piece, 35-44 % of the wave time) and nothing overlaps them
+  const unsigned char *is_wb = nullptr, *is_xb = nullptr;
+  unsigned char* is_stage = nullptr;
+  bool is_tail = false;
+  uint32_t is_lim = 0;
+  auto issue_begin = [&]() {
+    const int m0 = (is_tile / n_blocks) * TM, n0 = (is_tile % n_blocks) * TN;  // n_blocks == 1 for N = 512: folds away
+    is_wb = reinterpret_cast<const unsigned char*>(W) + ((size_t)n0 * K + is_k) * 2;
+    is_xb = reinterpret_cast<const unsigned char*>(X) + ((size_t)m0 * K + is_k) * 2;
+    is_tail = m0 + TM > M;
+    is_lim = xlast - (uint32_t)m0 * (uint32_t)K * 2u;
+    is_stage = smem + (is_s & 1) * ST6 + wave * GPW6 * 1024;
+  };
+  auto issue_piece = [&](int j) {
+    const unsigned char* src;
+    if (!px[j]) src = is_wb + poff[j];
+    else if (!is_tail) src = is_xb + poff[j];
+    else {  // rows >= M re-read row M-1 (never stored)
+      const uint32_t rowoff = poff[j] - (poff[j] % ((uint32_t)K * 2u));
+      src = is_xb + (rowoff > is_lim ? is_lim + (poff[j] - rowoff) : poff[j]);
+    }
+#ifdef GEMM_ABL_NO_LOAD
+    if (is_s < 2)  // timing-only build: only the first two steps are actually loaded
+#endif
+    __builtin_amdgcn_global_load_lds((gl_void*)src, (lds_void*)(is_stage + j * 1024), 16, 0, 0);
+  };
+  auto issue_end = [&]() {
+    ++is_s;
+    is_k += K6;
+    if (is_k == K) { is_k = 0; is_tile += (int)gridDim.x; }
+  };
+  auto issue = [&]() {
+    issue_begin();
+#pragma unroll
+    for (int j = 0; j < GPW6; ++j) issue_piece(j);
+    issue_end();
+  };
+  if (total > 0) issue();
+  int s = 0;
+#ifdef GEMM_STAMP
+  unsigned long long sw_ = 0, si_ = 0, sc_ = 0, se_ = 0, tstart;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstart)::"memory");
+#endif
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    const int tile = (int)blockIdx.x + ti * (int)gridDim.x;
+    const int m0 = (tile / n_blocks) * TM, n0 = (tile % n_blocks) * TN;
+    // accumulators start at the bias (rows of D = n): no global load is left in the epilogue, where its s_waitcnt vmcnt(0)
+    // would also wait for every store issued before it (measured: 16 serialised L2 round trips per tile, ~55 % of the kernel)
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bv = *reinterpret_cast<const float4*>(bias + n0 + wn * 128 + i * 32 + 8 * g + 4 * lh);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j][4 * g] = bv.x; acc[i][j][4 * g + 1] = bv.y; acc[i][j][4 * g + 2] = bv.z; acc[i][j][4 * g + 3] = bv.w;
+        }
+      }
+    s16x8 fw[2][4], fx[2][2];
+    for (int kt = 0; kt < nk; ++kt, ++s) {
+#ifdef GEMM_STAMP
+      unsigned long long st0, st1, st2, st3;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st0)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of step s have landed
+      __builtin_amdgcn_s_barrier();                      // ... and everybody's; everyone is done with step s-1's stage
+#ifdef GEMM_STAMP
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st1)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      // HALF-STEP STAGGER between the two wave halves (each SIMD hosts one wave of each): waves 0-3 fire their LDS-DMA pieces
+      // for step s+1 right after the barrier and then compute; waves 4-7 compute first and fire afterwards.  While one half is
+      // parked in the vector-memory pipe the other half owns the matrix pipe - no extra synchronisation involved.
+      const bool more = s + 1 < total;
+      const bool late = wave >= 4;
+      if (more && !late) issue();
+#ifdef GEMM_STAMP
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st2)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      const unsigned char* sw = smem + (s & 1) * ST6;
+      const unsigned char* sx = sw + W6_BYTES;
+      // software-pipelined fragments: the reads of k16-step q+1 are issued BEFORE the 8 MFMAs of step q (two register sets,
+      // pinned with sched_barrier: left alone, hipcc re-serialises this into read -> lgkmcnt(0) -> MFMA groups and
+      // every group pays the full LDS latency - 55 % of the wave time was spent parked on those waits)
+      // ---- software pipeline ACROSS the barrier: the fragments of the step's last k16 group are read but their 8 MFMAs are
+      // deferred to the top of the next step, where they cover the LDS latency of the new stage's first fragment reads
+      // (without this, both waves of a SIMD sit in lgkmcnt waits right after every barrier: the compute loop alone, no
+      // global traffic at all, ran at 2.2x its MFMA time).  Two register sets, order pinned with sched_barrier.
+#define LDFRAG(buf, q)                                                                                            \
+  {                                                                                                               \
+    const int c_ = (q) * 2 + lh;                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+        fw[buf][i] = *reinterpret_cast<const s16x8*>(sw + swz128(wn * 128 + i * 32 + lr, c_));                    \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
+        fx[buf][j] = *reinterpret_cast<const s16x8*>(sx + swz128(wm * 64 + j * 32 + lr, c_));                     \
+  }
+#define MMA8(buf)                                                                                                 \
+  {                                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[buf][i], fx[buf][j], acc[i][j], 0, 0, 0);          \
+  }
+      LDFRAG(0, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt > 0) MMA8(1)  // deferred group of the previous step (wave-uniform)
+      __builtin_amdgcn_sched_barrier(0);
+      LDFRAG(1, 1)
+      __builtin_amdgcn_sched_barrier(0);
+      MMA8(0)
+      __builtin_amdgcn_sched_barrier(0);
+      LDFRAG(0, 2)
+      __builtin_amdgcn_sched_barrier(0);
+      MMA8(1)
+      __builtin_amdgcn_sched_barrier(0);
+      LDFRAG(1, 3)
+      __builtin_amdgcn_sched_barrier(0);
+      MMA8(0)
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt == nk - 1) MMA8(1)  // last step of the tile: nothing to hide behind, flush
+      if (more && late) issue();
+#undef LDFRAG
+#undef MMA8
+#ifdef GEMM_STAMP
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st3)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      sw_ += st1 - st0; si_ += st2 - st1; sc_ += st3 - st2;
+#endif
+    }
+    // ---- epilogue: image aliased onto the stage consumed by the tile's last step (free until issue(s+1) of the next step)
+#ifdef GEMM_STAMP
+    unsigned long long se0, se1;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(se0)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    __builtin_amdgcn_s_barrier();  // all waves done reading that stage
+    bf16_t* ep = reinterpret_cast<bf16_t*>(smem + ((s - 1) & 1) * ST6) + wave * 64 * EPQ;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nn = 8 * g + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          uint2 pk;
+          pk.x = (uint32_t)f2bf(acc[i][j][4 * g]) | ((uint32_t)f2bf(acc[i][j][4 * g + 1]) << 16);
+          pk.y = (uint32_t)f2bf(acc[i][j][4 * g + 2]) | ((uint32_t)f2bf(acc[i][j][4 * g + 3]) << 16);
+          *reinterpret_cast<uint2*>(ep + (j * 32 + lr) * EPQ + nn) = pk;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 16 + (lane >> 2), cc = (lane & 3) * 8;
+        const int gm = m0 + wm * 64 + row;
+        const uint4 vv = *reinterpret_cast<const uint4*>(ep + row * EPQ + cc);
+#ifdef GEMM_ABL_NO_STORE
+        if (gm < M && vv.x == 0x12345678u)
+#else
+        if (gm < M)
+#endif
+          *reinterpret_cast<uint4*>(Y + (size_t)gm * N + n0 + wn * 128 + i * 32 + cc) = vv;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+#ifdef GEMM_STAMP
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(se1)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    se_ += se1 - se0;
+#endif
+  }
+#ifdef GEMM_STAMP
+  unsigned long long tend;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tend)::"memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (lane == 0) {  // diagnostic build only: the stamp sums overwrite the head of Y (its outputs are not used)
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(Y) + ((size_t)blockIdx.x * 8 + wave) * 8;
+    dbg[0] = sw_; dbg[1] = si_; dbg[2] = sc_; dbg[3] = se_; dbg[4] = tend - tstart; dbg[5] = (unsigned long long)total;
+  }
+#endif
+}
+
 }  // namespace
 
 extern "C" int tamtr_linear_bf16(const void* X, const void* W, const float* bias, void* Y, int M, int N, int K, void* stream) {
   if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return TAMTR_EINVAL;
   if (K % BK || N % BN) return TAMTR_EUNSUP;
+  if (N % TN == 0 && K % TK == 0) {  // full-row tiles: X read once (the value projection shape)
+    const int mbl = (M + TM - 1) / TM, nbl = N / TN;
+    if ((long long)mbl * nbl > 0x7fffffffLL) return TAMTR_EUNSUP;
+    const size_t lds5 = (size_t)NST * ST_BYTES;  // 4 x 40 KB ring = all 160 KB of a CU (epilogue image aliases a stage)
+    static_assert(NST * ST_BYTES <= 160 * 1024 && EP_BYTES <= ST_BYTES, "LDS budget");
+    (void)hipFuncSetAttribute((const void*)linear_bf16_n512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
+    const int tiles = mbl * nbl;
+    const int grid = tiles < 256 ? tiles : 256;  // one persistent workgroup per CU
+    if (K % K6 == 0) {  // 128-B pieces, 2-stage ring (measured 5 % faster than the 64-B / 4-stage ring below)
+      (void)hipFuncSetAttribute((const void*)linear_bf16_n512_k64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST6);
+      hipLaunchKernelGGL(linear_bf16_n512_k64_kernel, dim3((unsigned)grid), dim3(T5), 2 * ST6, (hipStream_t)stream,
+                         (const bf16_t*)X, (const bf16_t*)W, bias, (bf16_t*)Y, M, N, K, nbl, tiles);
+      return tamtr_launch_status();
+    }
+    hipLaunchKernelGGL(linear_bf16_n512_kernel, dim3((unsigned)grid), dim3(T5), lds5, (hipStream_t)stream, (const bf16_t*)X,
+                       (const bf16_t*)W, bias, (bf16_t*)Y, M, N, K, nbl, tiles);
+    return tamtr_launch_status();
+  }
   const int m_blocks = (M + BM - 1) / BM, n_blocks = N / BN;
   const long long blocks = (long long)((m_blocks + 7) / 8) * 8 * n_blocks;
   if (blocks > 0x7fffffffLL) return TAMTR_EUNSUP;

@@ -13,6 +13,10 @@ from ._lib import call, dtype_code, ptr, require_gpu, stream_ptr
 
 _I, _F = ctypes.c_int, ctypes.c_float
 
+# measurement hook (bench.py): KERNEL_EVENTS['tamtr_linear_bf16'] = [] makes the op bracket the C call itself (not the
+# dtype casts around it) with a pair of events on the launch stream and append (start, end, algorithmic flops)
+KERNEL_EVENTS = {}
+
 
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
@@ -159,7 +163,14 @@ class _LinearBF16(torch.autograd.Function):
         w16 = _c(weight.to(torch.bfloat16))
         b32 = _c(bias.float()) if bias is not None else None
         y = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.bfloat16)
+        rec = KERNEL_EVENTS.get('tamtr_linear_bf16')
+        if rec is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         call('tamtr_linear_bf16', ptr(x2), ptr(w16), ptr(b32), ptr(y), x2.shape[0], N, K, stream_ptr())
+        if rec is not None:
+            e1.record()
+            rec.append((e0, e1, 2.0 * x2.shape[0] * N * K))
         ctx.save_for_backward(x2, w16)
         ctx.cfg = (x.shape, weight.dtype, None if bias is None else bias.dtype)
         return y.view(*x.shape[:-1], N)
