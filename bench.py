@@ -136,6 +136,7 @@ def main():
     rank, local, world = tdist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    local = local % max(torch.cuda.device_count(), 1)  # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 

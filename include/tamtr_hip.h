@@ -129,12 +129,17 @@ int tamtr_selfattn_bwd(const void* go, const void* q, const void* k, const void*
  *      u, delta f32 [B, KD, L]; A f32 [KD, N]; Bm, Cm f32 [B, K, N, L]; D, dbias f32 [KD]; y f32 [B, KD, L].
  *      N == 16.  hstate f32 [B, KD, nchunk, N]: chunk-boundary states saved for _bwd, nchunk = ceil(L / chunk) with
  *      `chunk` returned by tamtr_selective_scan_chunk().
+ *      xmode = 0: plain contract above.  xmode = 1 ("cross-scan layout", K must be 4; replaces the 4x materialisation of
+ *      CrossScan, csms6s.py:4-14): u is [B, 2, Dk, L] = (row-major, column-major) flattenings of the map, direction k reads
+ *      u[:, k & 1]; directions k >= 2 are the reversed scans and walk EVERY time-indexed buffer (u, delta, B, C, y and the
+ *      gradients) back to front, i.e. those buffers are stored in the un-reversed order of direction k - 2.
  */
 int tamtr_selective_scan_chunk(void);
 int tamtr_selective_scan_fwd(const float* u, const float* delta, const float* A, const float* Bm, const float* Cm,
                              const float* D, const float* dbias, float* y, float* hstate, int B, int K, int Dk, int N, int L,
-                             void* stream);
-/*      Backward: gy f32 [B,KD,L] -> gu, gdelta f32 [B,KD,L]; gB, gC f32 [B,K,N,L] (plain stores); gA f32 [KD,N], gD,
+                             int xmode, void* stream);
+/*      Backward: gy f32 [B,KD,L] -> gu, gdelta f32 [B,KD,L] (in xmode gu is per direction, stored un-reversed: the host adds
+ *      gu[:, k] + gu[:, k+2] to get the gradient of u[:, k]); gB, gC f32 [B,K,N,L] (plain stores); gA f32 [KD,N], gD,
  *      gdbias f32 [KD] (ACCUMULATED over the batch: caller zeroes).  ws: caller workspace of
  *      2 * tamtr_selective_scan_bwd_slabs(Dk) * B*K*N*L floats (per-workgroup partial dB/dC slabs, summed by a second kernel).
  */
@@ -142,7 +147,7 @@ int tamtr_selective_scan_bwd_slabs(int Dk);
 int tamtr_selective_scan_bwd(const float* gy, const float* u, const float* delta, const float* A, const float* Bm,
                              const float* Cm, const float* D, const float* dbias, const float* hstate, float* gu,
                              float* gdelta, float* gA, float* gB, float* gC, float* gD, float* gdbias, float* ws, int B, int K,
-                             int Dk, int N, int L, void* stream);
+                             int Dk, int N, int L, int xmode, void* stream);
 
 #ifdef __cplusplus
 }

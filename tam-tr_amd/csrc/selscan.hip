@@ -41,28 +41,38 @@ __device__ __forceinline__ float softplus_f(float x) {
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __builtin_amdgcn_exp2f(-x * LOG2E)); }
 
+// scan step t lives at memory position t (rev = false) or L-1-t (rev = true: the two reversed scan directions of the
+// cross-scan read and write the SAME buffers as the forward ones, back to front - still 16-B coalesced, descending)
 template <bool VEC>
-__device__ __forceinline__ void load4(const float* __restrict__ p, int t, int L, float (&o)[ITEMS], float fill) {
+__device__ __forceinline__ void load4(const float* __restrict__ p, int t, int L, float (&o)[ITEMS], float fill, bool rev = false) {
   if (VEC) {
     if (t < L) {  // L % 4 == 0 and t % 4 == 0: all-or-nothing
-      const float4 v = *reinterpret_cast<const float4*>(p + t);
-      o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+      if (!rev) {
+        const float4 v = *reinterpret_cast<const float4*>(p + t);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+      } else {
+        const float4 v = *reinterpret_cast<const float4*>(p + (L - 4 - t));
+        o[0] = v.w; o[1] = v.z; o[2] = v.y; o[3] = v.x;
+      }
     } else {
       o[0] = o[1] = o[2] = o[3] = fill;
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) o[i] = (t + i < L) ? p[t + i] : fill;
+    for (int i = 0; i < ITEMS; ++i) o[i] = (t + i < L) ? p[rev ? L - 1 - t - i : t + i] : fill;
   }
 }
 template <bool VEC>
-__device__ __forceinline__ void store4(float* __restrict__ p, int t, int L, const float (&v)[ITEMS]) {
+__device__ __forceinline__ void store4(float* __restrict__ p, int t, int L, const float (&v)[ITEMS], bool rev = false) {
   if (VEC) {
-    if (t < L) *reinterpret_cast<float4*>(p + t) = make_float4(v[0], v[1], v[2], v[3]);
+    if (t < L) {
+      if (!rev) *reinterpret_cast<float4*>(p + t) = make_float4(v[0], v[1], v[2], v[3]);
+      else *reinterpret_cast<float4*>(p + (L - 4 - t)) = make_float4(v[3], v[2], v[1], v[0]);
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i)
-      if (t + i < L) p[t + i] = v[i];
+      if (t + i < L) p[rev ? L - 1 - t - i : t + i] = v[i];
   }
 }
 
@@ -108,14 +118,21 @@ __device__ __forceinline__ void wave_scan_suffix(float& A, float& Bv, int addr1,
 // cooperative load of the chunk's B and C tiles ([NS][CHUNK] each) into LDS, zero beyond L
 template <int THREADS>
 __device__ __forceinline__ void stage_bc(const float* __restrict__ Bp, const float* __restrict__ Cp, int t0, int L,
-                                         float (*sB)[CHUNK], float (*sC)[CHUNK], bool vec) {
+                                         float (*sB)[CHUNK], float (*sC)[CHUNK], bool vec, bool rev) {
   if (vec) {
     for (int i = threadIdx.x; i < NS * CHUNK / 4; i += THREADS) {
       const int n = i / (CHUNK / 4), tt = (i % (CHUNK / 4)) * 4;
       float4 b = make_float4(0.f, 0.f, 0.f, 0.f), c = b;
       if (t0 + tt < L) {
-        b = *reinterpret_cast<const float4*>(Bp + (size_t)n * L + t0 + tt);
-        c = *reinterpret_cast<const float4*>(Cp + (size_t)n * L + t0 + tt);
+        if (!rev) {
+          b = *reinterpret_cast<const float4*>(Bp + (size_t)n * L + t0 + tt);
+          c = *reinterpret_cast<const float4*>(Cp + (size_t)n * L + t0 + tt);
+        } else {
+          const float4 rb = *reinterpret_cast<const float4*>(Bp + (size_t)n * L + (L - 4 - t0 - tt));
+          const float4 rc = *reinterpret_cast<const float4*>(Cp + (size_t)n * L + (L - 4 - t0 - tt));
+          b = make_float4(rb.w, rb.z, rb.y, rb.x);
+          c = make_float4(rc.w, rc.z, rc.y, rc.x);
+        }
       }
       *reinterpret_cast<float4*>(&sB[n][tt]) = b;
       *reinterpret_cast<float4*>(&sC[n][tt]) = c;
@@ -124,8 +141,9 @@ __device__ __forceinline__ void stage_bc(const float* __restrict__ Bp, const flo
     for (int i = threadIdx.x; i < NS * CHUNK; i += THREADS) {
       const int n = i / CHUNK, tt = i % CHUNK;
       const bool ok = t0 + tt < L;
-      sB[n][tt] = ok ? Bp[(size_t)n * L + t0 + tt] : 0.f;
-      sC[n][tt] = ok ? Cp[(size_t)n * L + t0 + tt] : 0.f;
+      const int pos = rev ? L - 1 - t0 - tt : t0 + tt;
+      sB[n][tt] = ok ? Bp[(size_t)n * L + pos] : 0.f;
+      sC[n][tt] = ok ? Cp[(size_t)n * L + pos] : 0.f;
     }
   }
 }
@@ -136,7 +154,8 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
                                                                       const float* __restrict__ Am, const float* __restrict__ Bm,
                                                                       const float* __restrict__ Cm, const float* __restrict__ Dv,
                                                                       const float* __restrict__ dbias, float* __restrict__ y,
-                                                                      float* __restrict__ hstate, int K, int Dk, int L, int nchunk) {
+                                                                      float* __restrict__ hstate, int K, int Dk, int L, int nchunk,
+                                                                      int xmode) {
   __shared__ float sB[NS][CHUNK];
   __shared__ float sC[NS][CHUNK];
   __shared__ float s_A[FWD_ROWS][NS], s_h[FWD_ROWS][NS];  // wave-private, wave-uniform per-state values (A*log2e, carried h)
@@ -146,7 +165,10 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
   const int bk = blockIdx.y, k = bk % K;
   const int kd = k * Dk + (live ? d : 0);
   const size_t row = (size_t)(bk / K) * K * Dk + kd;
-  const float* up = u + row * L;
+  // cross-scan layout (xmode): u is [B, 2, Dk, L] (k & 1 picks the row-major / column-major copy) and directions k >= 2
+  // walk every time-indexed buffer back to front
+  const bool rev = xmode && k >= 2;
+  const float* up = xmode ? u + (((size_t)(bk / K) * 2 + (k & 1)) * Dk + (live ? d : 0)) * L : u + row * L;
   const float* dp = delta + row * L;
   const float* Bp = Bm + (size_t)bk * NS * L;
   const float* Cp = Cm + (size_t)bk * NS * L;
@@ -158,13 +180,13 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
 
   for (int c = 0; c < nchunk; ++c) {
     __syncthreads();  // previous chunk's tile fully consumed
-    stage_bc<FWD_ROWS * WAVE>(Bp, Cp, c * CHUNK, L, sB, sC, VEC);
+    stage_bc<FWD_ROWS * WAVE>(Bp, Cp, c * CHUNK, L, sB, sC, VEC, rev);
     __syncthreads();
     if (!live) continue;
     const int t = c * CHUNK + lane * ITEMS;
     float uu[ITEMS], dt[ITEMS], dtu[ITEMS], yy[ITEMS];
-    load4<VEC>(up, t, L, uu, 0.f);
-    load4<VEC>(dp, t, L, dt, 0.f);
+    load4<VEC>(up, t, L, uu, 0.f, rev);
+    load4<VEC>(dp, t, L, dt, 0.f, rev);
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       dt[i] = (t + i < L) ? softplus_f(dt[i] + bias) : 0.f;  // steps beyond L become the identity map (a = 1, b = 0)
@@ -195,7 +217,7 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
       }
       if (lane == WAVE - 1) h[n] = hh;  // state after the chunk
     }
-    store4<VEC>(yp, t, L, yy);
+    store4<VEC>(yp, t, L, yy, rev);
     if (lane < NS) hstate[(row * nchunk + c) * NS + lane] = h[lane];
   }
 }
@@ -207,7 +229,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE) void selscan_bwd_kernel(
     const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ Dv, const float* __restrict__ dbias,
     const float* __restrict__ hstate, float* __restrict__ gu, float* __restrict__ gdelta, float* __restrict__ gA,
     float* __restrict__ wsB, float* __restrict__ wsC, float* __restrict__ gD, float* __restrict__ gdbias, int K, int Dk, int L,
-    int nchunk, size_t slab_elems) {
+    int nchunk, size_t slab_elems, int xmode) {
   __shared__ float sB[NS][CHUNK];
   __shared__ float sC[NS][CHUNK];
   __shared__ float s_dB[NS][CHUNK];
@@ -221,6 +243,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE) void selscan_bwd_kernel(
   float* slabB = wsB + (size_t)blockIdx.x * slab_elems + (size_t)bk * NS * L;
   float* slabC = wsC + (size_t)blockIdx.x * slab_elems + (size_t)bk * NS * L;
   const int d0 = blockIdx.x * BWD_ROWS + wave * BWD_RPW;
+  const bool rev = xmode && k >= 2;
   // ds_bpermute byte addresses of the first lane of the next / next-but-one 16-lane row (suffix scan, cross-row levels)
   const int rowi = lane >> 4;
   const int addr1 = rowi + 1 < 4 ? (rowi + 1) * 64 : -1;
@@ -233,7 +256,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE) void selscan_bwd_kernel(
 
   for (int c = nchunk - 1; c >= 0; --c) {
     __syncthreads();  // previous chunk's tiles fully consumed / flushed
-    stage_bc<BWD_WAVES * WAVE>(Bp, Cp, c * CHUNK, L, sB, sC, VEC);
+    stage_bc<BWD_WAVES * WAVE>(Bp, Cp, c * CHUNK, L, sB, sC, VEC, rev);
     __syncthreads();
     const int t = c * CHUNK + lane * ITEMS;
     float accB[NS][ITEMS], accC[NS][ITEMS];  // this wave's rows' dB/dC for the chunk, summed in registers
@@ -253,9 +276,10 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE) void selscan_bwd_kernel(
         float* carry = s_carry[wave][r];
         float uu[ITEMS], dl[ITEMS], dt[ITEMS], g[ITEMS], ddt[ITEMS], du[ITEMS], dtu[ITEMS];
         float dD = 0.f, dbs = 0.f;
-        load4<VEC>(u + row * L, t, L, uu, 0.f);
-        load4<VEC>(delta + row * L, t, L, dl, 0.f);
-        load4<VEC>(gy + row * L, t, L, g, 0.f);
+        const float* up = xmode ? u + (((size_t)(bk / K) * 2 + (k & 1)) * Dk + d) * L : u + row * L;
+        load4<VEC>(up, t, L, uu, 0.f, rev);
+        load4<VEC>(delta + row * L, t, L, dl, 0.f, rev);
+        load4<VEC>(gy + row * L, t, L, g, 0.f, rev);
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
           dt[i] = (t + i < L) ? softplus_f(dl[i] + bias) : 0.f;
@@ -328,8 +352,8 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE) void selscan_bwd_kernel(
         dD = group_sum<WAVE>(dD);
         dbs = group_sum<WAVE>(dbs);
         if (lane == 0) { s_dD[wave][r] += dD; s_db[wave][r] += dbs; }
-        store4<VEC>(gu + row * L, t, L, du);
-        store4<VEC>(gdelta + row * L, t, L, gd);
+        store4<VEC>(gu + row * L, t, L, du, rev);  // gu is always [B, K*Dk, L]; the host folds direction pairs in xmode
+        store4<VEC>(gdelta + row * L, t, L, gd, rev);
       }
     }
     // ---- fold the BWD_WAVES register tiles into one LDS tile, one wave at a time (plain LDS traffic, no atomics)
@@ -358,14 +382,18 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE) void selscan_bwd_kernel(
       for (int i = threadIdx.x; i < NS * CHUNK / 4; i += BWD_WAVES * WAVE) {
         const int n = i / (CHUNK / 4), tt = (i % (CHUNK / 4)) * 4, tg = c * CHUNK + tt;
         if (tg < L) {
-          *reinterpret_cast<float4*>(slabB + (size_t)n * L + tg) = *reinterpret_cast<const float4*>(&s_dB[n][tt]);
-          *reinterpret_cast<float4*>(slabC + (size_t)n * L + tg) = *reinterpret_cast<const float4*>(&s_dC[n][tt]);
+          float4 vb = *reinterpret_cast<const float4*>(&s_dB[n][tt]), vc = *reinterpret_cast<const float4*>(&s_dC[n][tt]);
+          if (rev) { vb = make_float4(vb.w, vb.z, vb.y, vb.x); vc = make_float4(vc.w, vc.z, vc.y, vc.x); }
+          const int pos = rev ? L - 4 - tg : tg;
+          *reinterpret_cast<float4*>(slabB + (size_t)n * L + pos) = vb;
+          *reinterpret_cast<float4*>(slabC + (size_t)n * L + pos) = vc;
         }
       }
     } else {
       for (int i = threadIdx.x; i < NS * CHUNK; i += BWD_WAVES * WAVE) {
         const int n = i / CHUNK, tg = c * CHUNK + (i % CHUNK);
-        if (tg < L) { slabB[(size_t)n * L + tg] = s_dB[n][i % CHUNK]; slabC[(size_t)n * L + tg] = s_dC[n][i % CHUNK]; }
+        const int pos = rev ? L - 1 - tg : tg;
+        if (tg < L) { slabB[(size_t)n * L + pos] = s_dB[n][i % CHUNK]; slabC[(size_t)n * L + pos] = s_dC[n][i % CHUNK]; }
       }
     }
   }
@@ -403,30 +431,30 @@ extern "C" int tamtr_selective_scan_bwd_slabs(int Dk) { return Dk > 0 ? (Dk + BW
 
 extern "C" int tamtr_selective_scan_fwd(const float* u, const float* delta, const float* A, const float* Bm, const float* Cm,
                                         const float* D, const float* dbias, float* y, float* hstate, int B, int K, int Dk, int N,
-                                        int L, void* stream) {
+                                        int L, int xmode, void* stream) {
   if (!u || !delta || !A || !Bm || !Cm || !D || !dbias || !y || !hstate || B <= 0 || K <= 0 || Dk <= 0 || L <= 0)
     return TAMTR_EINVAL;
-  if (N != NS || (long long)B * K > 65535) return TAMTR_EUNSUP;
+  if (N != NS || (long long)B * K > 65535 || (xmode && K != 4)) return TAMTR_EUNSUP;
   const int nchunk = (L + CHUNK - 1) / CHUNK;
   dim3 grid((Dk + FWD_ROWS - 1) / FWD_ROWS, B * K);
   hipStream_t s = (hipStream_t)stream;
   if (L % 4 == 0)
     hipLaunchKernelGGL(selscan_fwd_kernel<true>, grid, dim3(FWD_ROWS * WAVE), 0, s, u, delta, A, Bm, Cm, D, dbias, y, hstate, K, Dk, L,
-                       nchunk);
+                       nchunk, xmode);
   else
     hipLaunchKernelGGL(selscan_fwd_kernel<false>, grid, dim3(FWD_ROWS * WAVE), 0, s, u, delta, A, Bm, Cm, D, dbias, y, hstate, K, Dk, L,
-                       nchunk);
+                       nchunk, xmode);
   return tamtr_launch_status();
 }
 
 extern "C" int tamtr_selective_scan_bwd(const float* gy, const float* u, const float* delta, const float* A, const float* Bm,
                                         const float* Cm, const float* D, const float* dbias, const float* hstate, float* gu,
                                         float* gdelta, float* gA, float* gB, float* gC, float* gD, float* gdbias, float* ws, int B,
-                                        int K, int Dk, int N, int L, void* stream) {
+                                        int K, int Dk, int N, int L, int xmode, void* stream) {
   if (!gy || !u || !delta || !A || !Bm || !Cm || !D || !dbias || !hstate || !gu || !gdelta || !gA || !gB || !gC || !gD ||
       !gdbias || !ws || B <= 0 || K <= 0 || Dk <= 0 || L <= 0)
     return TAMTR_EINVAL;
-  if (N != NS || (long long)B * K > 65535) return TAMTR_EUNSUP;
+  if (N != NS || (long long)B * K > 65535 || (xmode && K != 4)) return TAMTR_EUNSUP;
   const int nchunk = (L + CHUNK - 1) / CHUNK;
   const int nslab = (Dk + BWD_ROWS - 1) / BWD_ROWS;
   const size_t slab = (size_t)B * K * NS * L;
@@ -436,10 +464,10 @@ extern "C" int tamtr_selective_scan_bwd(const float* gy, const float* u, const f
   hipStream_t s = (hipStream_t)stream;
   if (L % 4 == 0)
     hipLaunchKernelGGL(selscan_bwd_kernel<true>, grid, dim3(BWD_WAVES * WAVE), 0, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu,
-                       gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab);
+                       gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab, xmode);
   else
     hipLaunchKernelGGL(selscan_bwd_kernel<false>, grid, dim3(BWD_WAVES * WAVE), 0, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu,
-                       gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab);
+                       gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab, xmode);
   const size_t n4 = slab / 4;  // N = 16 makes slab a multiple of 4
   const unsigned blocks = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
   hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, s, wsB, wsC, gB, gC, n4, nslab);

@@ -254,36 +254,46 @@ def self_attention(q, k, v, nh, attn_mask=None):
 # ------------------------------------------------------------------------------------------------ a-9 selective scan
 class _SelectiveScan(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, u, delta, A, Bm, Cm, D, dbias):
+    def forward(ctx, u, delta, A, Bm, Cm, D, dbias, xmode):
         require_gpu(u, delta, A, Bm, Cm, D, dbias)
-        Bn, KD, L = u.shape
+        Bn, KD, L = delta.shape
         K, N = Bm.shape[1], Bm.shape[2]
         u, delta, A, Bm, Cm, D, dbias = (_c(t.float()) for t in (u, delta, A, Bm, Cm, D, dbias))
         chunk = _lib.lib().tamtr_selective_scan_chunk()
         nchunk = (L + chunk - 1) // chunk
-        y = torch.empty_like(u)
+        y = torch.empty_like(delta)
         hstate = torch.empty(Bn, KD, nchunk, N, device=u.device, dtype=torch.float32)
         call('tamtr_selective_scan_fwd', ptr(u), ptr(delta), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(dbias), ptr(y), ptr(hstate), Bn, K,
-             KD // K, N, L, stream_ptr())
+             KD // K, N, L, int(xmode), stream_ptr())
         ctx.save_for_backward(u, delta, A, Bm, Cm, D, dbias, hstate)
+        ctx.xmode = int(xmode)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         u, delta, A, Bm, Cm, D, dbias, hstate = ctx.saved_tensors
-        Bn, KD, L = u.shape
+        Bn, KD, L = delta.shape
         K, N = Bm.shape[1], Bm.shape[2]
         gy = _c(gy.float())
-        gu, gdelta = torch.empty_like(u), torch.empty_like(u)
+        gu, gdelta = torch.empty_like(delta), torch.empty_like(delta)
         gA, gB, gC = torch.zeros_like(A), torch.empty_like(Bm), torch.empty_like(Cm)
         gD, gbias = torch.zeros_like(D), torch.zeros_like(dbias)
         nslab = _lib.lib().tamtr_selective_scan_bwd_slabs(KD // K)
         ws = torch.empty(2 * nslab * Bm.numel(), device=u.device, dtype=torch.float32)  # per-workgroup dB/dC slabs
         call('tamtr_selective_scan_bwd', ptr(gy), ptr(u), ptr(delta), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(dbias), ptr(hstate), ptr(gu),
-             ptr(gdelta), ptr(gA), ptr(gB), ptr(gC), ptr(gD), ptr(gbias), ptr(ws), Bn, K, KD // K, N, L, stream_ptr())
-        return gu, gdelta, gA, gB, gC, gD, gbias
+             ptr(gdelta), ptr(gA), ptr(gB), ptr(gC), ptr(gD), ptr(gbias), ptr(ws), Bn, K, KD // K, N, L, ctx.xmode, stream_ptr())
+        if ctx.xmode:  # [B, 4*Dk, L] per direction (un-reversed) -> gradient of the two stored copies [B, 2, Dk, L]
+            g4 = gu.view(Bn, 4, KD // 4, L)
+            gu = g4[:, :2] + g4[:, 2:]
+        return gu, gdelta, gA, gB, gC, gD, gbias, None
 
 
 def selective_scan(u, delta, A, Bm, Cm, D, delta_bias):
     """S6 scan with softplus(delta + bias): u, delta [B,K*Dk,L]; A [K*Dk,16]; Bm, Cm [B,K,16,L]; D, delta_bias [K*Dk]."""
-    return _SelectiveScan.apply(u, delta, A, Bm, Cm, D, delta_bias)
+    return _SelectiveScan.apply(u, delta, A, Bm, Cm, D, delta_bias, 0)
+
+
+def selective_scan_cross(u2, delta, A, Bm, Cm, D, delta_bias):
+    """Cross-scan layout (no 4x materialisation): u2 [B,2,Dk,L] = (row-major, column-major) flattenings; delta [B,4*Dk,L],
+    Bm, Cm [B,4,16,L] and the result are stored UN-reversed (directions 2, 3 share the order of 0, 1 and are walked backwards)."""
+    return _SelectiveScan.apply(u2, delta, A, Bm, Cm, D, delta_bias, 1)

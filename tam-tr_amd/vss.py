@@ -72,16 +72,27 @@ class SS2D(nn.Module):
         xz = self.in_proj(x)
         xi, z = xz.chunk(2, -1)
         z = F.silu(z)
-        xi = F.silu(self.conv2d(xi.permute(0, 3, 1, 2).contiguous()))
-        K, R, N, L = 4, self.dt_rank, self.d_state, H * W
-        xs = cross_scan(xi.float())  # the scan runs in fp32 (force_fp32, vmamba.py:980-981)
-        x_dbl = torch.einsum('bkdl,kcd->bkcl', xs, self.x_proj_weight.float())
+        xi = F.silu(self.conv2d(xi.permute(0, 3, 1, 2).contiguous())).float()  # [B,D,H,W]; the scan runs in fp32 (vmamba.py:980)
+        K, R, N, L, D = 4, self.dt_rank, self.d_state, H * W, self.d_inner
+        # Cross-scan WITHOUT materialising the four sequences (csms6s.py:4-14): directions 0/2 walk the row-major flattening
+        # forwards/backwards, 1/3 the column-major one; the kernel reads the two stored copies and reverses on the fly, and all
+        # per-direction operands are kept in the un-reversed order of their base copy.
+        u2 = torch.stack([xi.flatten(2), xi.transpose(2, 3).flatten(2)], 1)  # [B,2,D,L]
+        wx = self.x_proj_weight.float()  # [4, R+2N, D]
+        xd_a = torch.matmul(torch.cat([wx[0], wx[2]], 0), u2[:, 0])  # [B, 2C, L]: directions 0 and 2 (same base order)
+        xd_b = torch.matmul(torch.cat([wx[1], wx[3]], 0), u2[:, 1])  # directions 1 and 3
+        C = R + 2 * N
+        x_dbl = torch.stack([xd_a[:, :C], xd_b[:, :C], xd_a[:, C:], xd_b[:, C:]], 1)  # [B,4,C,L]
         dts, Bs, Cs = torch.split(x_dbl, [R, N, N], 2)
+        # (folding dt_proj into x_proj as one [D,D] GEMM per direction was tried: -30 ms of GPU time but +11 ms of wall, the
+        #  step is host-launch-bound; the real fix is computing delta inside the scan kernel - DESIGN.md "next")
         dts = torch.einsum('bkrl,kdr->bkdl', dts, self.dt_projs_weight.float())
+        Bs, Cs = Bs.contiguous(), Cs.contiguous()
         As = -torch.exp(self.A_logs.float())
-        ys = ops.selective_scan(xs.reshape(B, -1, L), dts.reshape(B, -1, L), As, Bs.contiguous(), Cs.contiguous(),
-                                self.Ds.float(), self.dt_projs_bias.float().reshape(-1))
-        y = cross_merge(ys.view(B, K, -1, L), H, W)
+        ys = ops.selective_scan_cross(u2, dts.reshape(B, -1, L), As, Bs, Cs, self.Ds.float(),
+                                      self.dt_projs_bias.float().reshape(-1)).view(B, K, D, L)
+        # cross-merge (csms6s.py:26-34) on un-reversed outputs: no flips left
+        y = ys[:, 0] + ys[:, 2] + (ys[:, 1] + ys[:, 3]).view(B, D, W, H).transpose(2, 3).reshape(B, D, L)
         y = self.out_norm(y.transpose(1, 2)).view(B, H, W, -1)
         return self.out_proj((y * z).to(x.dtype))
 

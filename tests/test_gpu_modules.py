@@ -63,6 +63,35 @@ def test_selective_scan_vs_sequential_oracle(pkg, Bn, K, Dk, L):
         assert_close(a.grad, b.grad, 2e-3, 2e-4 * max(scale, 1.0), 'grad ' + n)
 
 
+@pytest.mark.parametrize('Bn,Dk,H,W', [(2, 5, 4, 6), (1, 16, 20, 16), (1, 3, 7, 9)])
+def test_selective_scan_cross_layout(pkg, Bn, Dk, H, W):
+    """Cross-scan layout (xmode=1: two stored copies, reversed directions walk the buffers backwards) vs the oracle's
+    explicit CrossScan + scan + flip-back, values and gradients."""
+    L, K, N = H * W, 4, 16
+    xi = rnd((Bn, Dk, H, W), 1)
+    dl, A = rnd((Bn, K * Dk, L), 2), -torch.exp(rnd((K * Dk, N), 3, 0.5))
+    Bm, Cm = rnd((Bn, K, N, L), 4), rnd((Bn, K, N, L), 5)
+    D, bias = rnd((K * Dk,), 6), rnd((K * Dk,), 7) - 2.0
+    cot = rnd((Bn, K * Dk, L), 8)
+
+    def flip_rev(t, dim_k, kd):  # flip the time axis of directions 2, 3
+        v = t.view(Bn, K, kd, L)
+        return torch.cat([v[:, :2], v[:, 2:].flip(-1)], 1).reshape(t.shape)
+
+    r = [t.clone().requires_grad_() for t in (xi, dl, A, Bm, Cm, D, bias)]
+    xs = O.cross_scan(r[0]).reshape(Bn, K * Dk, L)  # scan order
+    y_scan = O.selective_scan(xs, flip_rev(r[1], 1, Dk), r[2], flip_rev(r[3], 1, N), flip_rev(r[4], 1, N), r[5], r[6])
+    ref = flip_rev(y_scan, 1, Dk)  # stored un-reversed
+    (ref * cot).sum().backward()
+    g = [dev(t).requires_grad_() for t in (xi, dl, A, Bm, Cm, D, bias)]
+    u2 = torch.stack([g[0].flatten(2), g[0].transpose(2, 3).flatten(2)], 1)
+    out = pkg.ops.selective_scan_cross(u2, g[1], g[2], g[3], g[4], g[5], g[6])
+    (out * dev(cot)).sum().backward()
+    assert_close(out, ref, 1e-3, 1e-4, 'y (cross layout)')
+    for n, a, b in zip('xi delta A B C D bias'.split(), g, r):
+        assert_close(a.grad, b.grad, 2e-3, 2e-4 * max(float(b.grad.abs().max()), 1.0), 'grad ' + n)
+
+
 def _attn_ref(q, k, v, nh, mask):
     B, Q, C = q.shape
     dh = C // nh
