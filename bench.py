@@ -140,6 +140,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
+    torch.set_num_threads(min(8, host_cores()))  # host side = launch issue + a few tiny CPU ops (dn RNG, scipy LSA): no 128-thread pools
     torch.manual_seed(0)
     model = RTDETRDetectionWorldModel(nc=10).to(dev).train()
     model.autocast_dtype = torch.bfloat16 if args.dtype == 'bf16' else None

@@ -149,6 +149,19 @@ int tamtr_selective_scan_bwd(const float* gy, const float* u, const float* delta
                              float* gdelta, float* gA, float* gB, float* gC, float* gD, float* gdbias, float* ws, int B, int K,
                              int Dk, int N, int L, int xmode, void* stream);
 
+/*      Fused dt projection (replaces the `dts = einsum("bkrl,kdr->bkdl")` of SS2D.forward_corev2, vmamba.py:972, whose
+ *      [B, 4*d_inner, L] result is never materialised): delta[b, k*Dk+d, t] = sum_r Wdt[k*Dk+d, r] * dtr[b, k, r, t] is formed
+ *      inside the scan.  dtr f32 [B, K, R, L], Wdt f32 [KD, R], R <= 32.  Backward additionally returns gdtr f32 [B,K,R,L]
+ *      (plain stores), gWdt f32 [KD, R] (ACCUMULATED over the batch: caller zeroes); gdelta_ws: caller workspace [B,KD,L].
+ */
+int tamtr_selective_scan_dtproj_fwd(const float* u, const float* dtr, const float* Wdt, const float* A, const float* Bm,
+                                    const float* Cm, const float* D, const float* dbias, float* y, float* hstate, int B, int K,
+                                    int Dk, int N, int R, int L, int xmode, void* stream);
+int tamtr_selective_scan_dtproj_bwd(const float* gy, const float* u, const float* dtr, const float* Wdt, const float* A,
+                                    const float* Bm, const float* Cm, const float* D, const float* dbias, const float* hstate,
+                                    float* gu, float* gdelta_ws, float* gdtr, float* gWdt, float* gA, float* gB, float* gC, float* gD,
+                                    float* gdbias, float* ws, int B, int K, int Dk, int N, int R, int L, int xmode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

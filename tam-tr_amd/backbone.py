@@ -114,8 +114,8 @@ class CPAM(nn.Module):
     def forward(self, x):
         c = torch.sigmoid(F.interpolate(F.max_pool2d(x, 3, 2, 1), scale_factor=2, mode='bilinear', align_corners=False)) * x
         B, C, H, W = c.shape
-        g = c.view(B, 8, C // 8, H, W)
-        return (torch.sigmoid(g.amax(2, keepdim=True)) * g).view(B, C, H, W)
+        g = c.reshape(B, 8, C // 8, H, W)
+        return (torch.sigmoid(g.amax(2, keepdim=True)) * g).reshape(B, C, H, W)
 
 
 class Concat(nn.Module):

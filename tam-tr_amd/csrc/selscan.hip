@@ -148,6 +148,40 @@ __device__ __forceinline__ void stage_bc(const float* __restrict__ Bp, const flo
   }
 }
 
+constexpr int RMAX = 32;  // largest dt rank built (d_model 512 / 16)
+
+// dt low-rank factors of the chunk: s_dtr[r][tt] = dtr[r][pos(t0 + tt)], zero beyond L
+template <int THREADS>
+__device__ __forceinline__ void stage_dtr(const float* __restrict__ Rp, int R, int t0, int L, float (*s_dtr)[CHUNK], bool vec,
+                                          bool rev) {
+  if (vec) {
+    for (int i = threadIdx.x; i < R * CHUNK / 4; i += THREADS) {
+      const int r = i / (CHUNK / 4), tt = (i % (CHUNK / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t0 + tt < L) {
+        if (!rev) v = *reinterpret_cast<const float4*>(Rp + (size_t)r * L + t0 + tt);
+        else {
+          const float4 w = *reinterpret_cast<const float4*>(Rp + (size_t)r * L + (L - 4 - t0 - tt));
+          v = make_float4(w.w, w.z, w.y, w.x);
+        }
+      }
+      *reinterpret_cast<float4*>(&s_dtr[r][tt]) = v;
+    }
+  } else {
+    for (int i = threadIdx.x; i < R * CHUNK; i += THREADS) {
+      const int r = i / CHUNK, tt = i % CHUNK;
+      s_dtr[r][tt] = (t0 + tt < L) ? Rp[(size_t)r * L + (rev ? L - 1 - t0 - tt : t0 + tt)] : 0.f;
+    }
+  }
+}
+
+// sum over the 64 lanes, valid in lane 63 (row_shr 1,2,4,8 + row_bcast 15,31: no LDS round trip)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp<0x111, 0xf>(0.f, v); v += dpp<0x112, 0xf>(0.f, v); v += dpp<0x114, 0xf>(0.f, v); v += dpp<0x118, 0xf>(0.f, v);
+  v += dpp<0x142, 0xa>(0.f, v); v += dpp<0x143, 0xc>(0.f, v);
+  return v;
+}
+
 // Forward: FWD_ROWS waves = FWD_ROWS rows of ONE (b, k) group per workgroup.
 template <bool VEC>
 __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float* __restrict__ u, const float* __restrict__ delta,
@@ -155,10 +189,14 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
                                                                       const float* __restrict__ Cm, const float* __restrict__ Dv,
                                                                       const float* __restrict__ dbias, float* __restrict__ y,
                                                                       float* __restrict__ hstate, int K, int Dk, int L, int nchunk,
-                                                                      int xmode) {
+                                                                      int xmode, const float* __restrict__ dtr,
+                                                                      const float* __restrict__ Wdt, int R) {
   __shared__ float sB[NS][CHUNK];
   __shared__ float sC[NS][CHUNK];
   __shared__ float s_A[FWD_ROWS][NS], s_h[FWD_ROWS][NS];  // wave-private, wave-uniform per-state values (A*log2e, carried h)
+  extern __shared__ float s_dyn[];                        // fused dt projection: [R][CHUNK] factors + [FWD_ROWS][RMAX] rows of Wdt
+  float(*s_dtr)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(s_dyn);
+  float* s_W = s_dyn + (size_t)R * CHUNK;
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
   const int d = blockIdx.x * FWD_ROWS + wave;
   const bool live = d < Dk;
@@ -176,17 +214,29 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
   float* An = s_A[wave];
   float* h = s_h[wave];
   if (lane < NS) { An[lane] = Am[(size_t)kd * NS + lane] * LOG2E; h[lane] = 0.f; }
+  if (dtr && lane < R) s_W[wave * RMAX + lane] = Wdt[(size_t)kd * R + lane];
+  const float* Rp = dtr ? dtr + (size_t)bk * R * L : nullptr;
   const float Dd = Dv[kd], bias = dbias[kd];
 
   for (int c = 0; c < nchunk; ++c) {
     __syncthreads();  // previous chunk's tile fully consumed
     stage_bc<FWD_ROWS * WAVE>(Bp, Cp, c * CHUNK, L, sB, sC, VEC, rev);
+    if (dtr) stage_dtr<FWD_ROWS * WAVE>(Rp, R, c * CHUNK, L, s_dtr, VEC, rev);
     __syncthreads();
     if (!live) continue;
     const int t = c * CHUNK + lane * ITEMS;
     float uu[ITEMS], dt[ITEMS], dtu[ITEMS], yy[ITEMS];
     load4<VEC>(up, t, L, uu, 0.f, rev);
-    load4<VEC>(dp, t, L, dt, 0.f, rev);
+    if (dtr) {  // delta_t = <Wdt[kd, :], dtr[:, t]>: the [B, 4*d_inner, L] delta tensor of the reference is never materialised
+      dt[0] = dt[1] = dt[2] = dt[3] = 0.f;
+      for (int r = 0; r < R; ++r) {
+        const float w = s_W[wave * RMAX + r];
+        const float4 f = *reinterpret_cast<const float4*>(&s_dtr[r][lane * ITEMS]);
+        dt[0] = fmaf(w, f.x, dt[0]); dt[1] = fmaf(w, f.y, dt[1]); dt[2] = fmaf(w, f.z, dt[2]); dt[3] = fmaf(w, f.w, dt[3]);
+      }
+    } else {
+      load4<VEC>(dp, t, L, dt, 0.f, rev);
+    }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       dt[i] = (t + i < L) ? softplus_f(dt[i] + bias) : 0.f;  // steps beyond L become the identity map (a = 1, b = 0)
@@ -229,13 +279,19 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE) void selscan_bwd_kernel(
     const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ Dv, const float* __restrict__ dbias,
     const float* __restrict__ hstate, float* __restrict__ gu, float* __restrict__ gdelta, float* __restrict__ gA,
     float* __restrict__ wsB, float* __restrict__ wsC, float* __restrict__ gD, float* __restrict__ gdbias, int K, int Dk, int L,
-    int nchunk, size_t slab_elems, int xmode) {
+    int nchunk, size_t slab_elems, int xmode, const float* __restrict__ dtr, const float* __restrict__ Wdt, float* __restrict__ gWdt,
+    int R) {
   __shared__ float sB[NS][CHUNK];
   __shared__ float sC[NS][CHUNK];
-  __shared__ float s_dB[NS][CHUNK];
-  __shared__ float s_dC[NS][CHUNK];
+  // the dB/dC fold tile aliases the B/C tiles: they are dead once the chunk's rows are done (keeps LDS at 2 workgroups per CU)
+  float(*s_dB)[CHUNK] = sB;
+  float(*s_dC)[CHUNK] = sC;
   __shared__ float s_A[BWD_WAVES][BWD_RPW][NS], s_carry[BWD_WAVES][BWD_RPW][NS], s_dA[BWD_WAVES][BWD_RPW][NS];
   __shared__ float s_dD[BWD_WAVES][BWD_RPW], s_db[BWD_WAVES][BWD_RPW];
+  extern __shared__ float s_dyn[];  // fused dt projection: [R][CHUNK] factors | [BWD_ROWS][RMAX] Wdt rows | [BWD_ROWS][RMAX] gWdt sums
+  float(*s_dtr)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(s_dyn);
+  float* s_W = s_dyn + (size_t)R * CHUNK;
+  float* s_gW = s_W + BWD_ROWS * RMAX;
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
   const int bk = blockIdx.y, k = bk % K;
   const float* Bp = Bm + (size_t)bk * NS * L;
@@ -252,11 +308,14 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE) void selscan_bwd_kernel(
     const int kd = k * Dk + min(d0 + r, Dk - 1);
     if (lane < NS) { s_A[wave][r][lane] = Am[(size_t)kd * NS + lane]; s_carry[wave][r][lane] = 0.f; s_dA[wave][r][lane] = 0.f; }
     if (lane == 0) { s_dD[wave][r] = 0.f; s_db[wave][r] = 0.f; }
+    if (dtr && lane < R) { s_W[(wave * BWD_RPW + r) * RMAX + lane] = Wdt[(size_t)kd * R + lane]; s_gW[(wave * BWD_RPW + r) * RMAX + lane] = 0.f; }
   }
+  const float* Rp = dtr ? dtr + (size_t)bk * R * L : nullptr;
 
   for (int c = nchunk - 1; c >= 0; --c) {
     __syncthreads();  // previous chunk's tiles fully consumed / flushed
     stage_bc<BWD_WAVES * WAVE>(Bp, Cp, c * CHUNK, L, sB, sC, VEC, rev);
+    if (dtr) stage_dtr<BWD_WAVES * WAVE>(Rp, R, c * CHUNK, L, s_dtr, VEC, rev);
     __syncthreads();
     const int t = c * CHUNK + lane * ITEMS;
     float accB[NS][ITEMS], accC[NS][ITEMS];  // this wave's rows' dB/dC for the chunk, summed in registers
@@ -278,7 +337,17 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE) void selscan_bwd_kernel(
         float dD = 0.f, dbs = 0.f;
         const float* up = xmode ? u + (((size_t)(bk / K) * 2 + (k & 1)) * Dk + d) * L : u + row * L;
         load4<VEC>(up, t, L, uu, 0.f, rev);
-        load4<VEC>(delta + row * L, t, L, dl, 0.f, rev);
+        const float* Wr = s_W + (wave * BWD_RPW + r) * RMAX;
+        if (dtr) {
+          dl[0] = dl[1] = dl[2] = dl[3] = 0.f;
+          for (int q = 0; q < R; ++q) {
+            const float w = Wr[q];
+            const float4 f = *reinterpret_cast<const float4*>(&s_dtr[q][lane * ITEMS]);
+            dl[0] = fmaf(w, f.x, dl[0]); dl[1] = fmaf(w, f.y, dl[1]); dl[2] = fmaf(w, f.z, dl[2]); dl[3] = fmaf(w, f.w, dl[3]);
+          }
+        } else {
+          load4<VEC>(delta + row * L, t, L, dl, 0.f, rev);
+        }
         load4<VEC>(gy + row * L, t, L, g, 0.f, rev);
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
@@ -340,8 +409,8 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE) void selscan_bwd_kernel(
             accC[n][i] = fmaf(g[i], hh[i], accC[n][i]);
           }
           if (lane == 0) carry[n] = a[0] * gh;  // a_t * gh_t of this chunk's first step, for the previous chunk
-          dA_n = group_sum<WAVE>(dA_n);
-          if (lane == 0) s_dA[wave][r][n] += dA_n;
+          dA_n = wave_sum_dpp(dA_n);
+          if (lane == WAVE - 1) s_dA[wave][r][n] += dA_n;
         }
         float gd[ITEMS];
 #pragma unroll
@@ -349,14 +418,23 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE) void selscan_bwd_kernel(
           gd[i] = (t + i < L) ? ddt[i] * sigmoid_f(dl[i] + bias) : 0.f;
           dbs += gd[i];
         }
-        dD = group_sum<WAVE>(dD);
-        dbs = group_sum<WAVE>(dbs);
-        if (lane == 0) { s_dD[wave][r] += dD; s_db[wave][r] += dbs; }
+        dD = wave_sum_dpp(dD);
+        dbs = wave_sum_dpp(dbs);
+        if (lane == WAVE - 1) { s_dD[wave][r] += dD; s_db[wave][r] += dbs; }
+        if (dtr) {  // gWdt[kd, q] += sum_t gdelta_t * dtr[q, t]
+          float* gWr = s_gW + (wave * BWD_RPW + r) * RMAX;
+          for (int q = 0; q < R; ++q) {
+            const float4 f = *reinterpret_cast<const float4*>(&s_dtr[q][lane * ITEMS]);
+            const float p = wave_sum_dpp(fmaf(gd[0], f.x, fmaf(gd[1], f.y, fmaf(gd[2], f.z, gd[3] * f.w))));
+            if (lane == WAVE - 1) gWr[q] += p;
+          }
+        }
         store4<VEC>(gu + row * L, t, L, du, rev);  // gu is always [B, K*Dk, L]; the host folds direction pairs in xmode
         store4<VEC>(gdelta + row * L, t, L, gd, rev);
       }
     }
     // ---- fold the BWD_WAVES register tiles into one LDS tile, one wave at a time (plain LDS traffic, no atomics)
+    __syncthreads();  // the tile aliases the B/C tiles: every wave must be past its last read of them
 #pragma unroll 1
     for (int w = 0; w < BWD_WAVES; ++w) {
       if (wave == w) {
@@ -404,6 +482,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE) void selscan_bwd_kernel(
       const int kd = k * Dk + d;
       if (lane < NS) atomicAdd(gA + (size_t)kd * NS + lane, s_dA[wave][r][lane]);  // summed over the batch only: no contention
       if (lane == 0) { atomicAdd(gD + kd, s_dD[wave][r]); atomicAdd(gdbias + kd, s_db[wave][r]); }
+      if (dtr && lane < R) atomicAdd(gWdt + (size_t)kd * R + lane, s_gW[(wave * BWD_RPW + r) * RMAX + lane]);
     }
   }
 }
@@ -424,37 +503,129 @@ __global__ void slab_sum_kernel(const float* __restrict__ wsB, const float* __re
   }
 }
 
+// gdtr[b,k,r,l] = sum_d Wdt[k,d,r] * gdelta[b,k,d,l]: one pass over gdelta, lanes along l (16 B per lane), the Dk x R factor
+// matrix streamed through LDS in 64-row tiles, R x 4 accumulators per lane.  Everything is in un-reversed position space.
+// scalar variant for L % 4 != 0 (odd test shapes only)
+__global__ __launch_bounds__(256) void dtproj_gdtr_scalar_kernel(const float* __restrict__ gdelta, const float* __restrict__ Wdt,
+                                                                 float* __restrict__ gdtr, int K, int Dk, int R, int L) {
+  const int bk = blockIdx.y, k = bk % K;
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= L) return;
+  for (int r = 0; r < R; ++r) {
+    float acc = 0.f;
+    for (int d = 0; d < Dk; ++d) acc = fmaf(Wdt[((size_t)k * Dk + d) * R + r], gdelta[((size_t)bk * Dk + d) * L + l], acc);
+    gdtr[((size_t)bk * R + r) * L + l] = acc;
+  }
+}
+
+template <int RT>
+__global__ __launch_bounds__(256) void dtproj_gdtr_kernel(const float* __restrict__ gdelta, const float* __restrict__ Wdt,
+                                                          float* __restrict__ gdtr, int K, int Dk, int R, int L) {
+  __shared__ float sW[64][RT];
+  const int bk = blockIdx.y, k = bk % K;
+  const int l0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const bool live = l0 < L;
+  float acc[RT][4];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f;
+  const float* gp = gdelta + (size_t)bk * Dk * L;
+  for (int d0 = 0; d0 < Dk; d0 += 64) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * RT; i += 256) {
+      const int dd = i / RT, r = i % RT;
+      sW[dd][r] = (d0 + dd < Dk && r < R) ? Wdt[((size_t)k * Dk + d0 + dd) * R + r] : 0.f;
+    }
+    __syncthreads();
+    if (live) {
+      const int dn = min(64, Dk - d0);
+      for (int dd = 0; dd < dn; ++dd) {
+        const float4 g = *reinterpret_cast<const float4*>(gp + (size_t)(d0 + dd) * L + l0);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+          const float w = sW[dd][r];
+          acc[r][0] = fmaf(w, g.x, acc[r][0]); acc[r][1] = fmaf(w, g.y, acc[r][1]);
+          acc[r][2] = fmaf(w, g.z, acc[r][2]); acc[r][3] = fmaf(w, g.w, acc[r][3]);
+        }
+      }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+      if (r < R) *reinterpret_cast<float4*>(gdtr + ((size_t)bk * R + r) * L + l0) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+  }
+}
+
 }  // namespace
 
 extern "C" int tamtr_selective_scan_chunk(void) { return CHUNK; }
 extern "C" int tamtr_selective_scan_bwd_slabs(int Dk) { return Dk > 0 ? (Dk + BWD_ROWS - 1) / BWD_ROWS : 0; }
 
-extern "C" int tamtr_selective_scan_fwd(const float* u, const float* delta, const float* A, const float* Bm, const float* Cm,
-                                        const float* D, const float* dbias, float* y, float* hstate, int B, int K, int Dk, int N,
-                                        int L, int xmode, void* stream) {
-  if (!u || !delta || !A || !Bm || !Cm || !D || !dbias || !y || !hstate || B <= 0 || K <= 0 || Dk <= 0 || L <= 0)
+static int scan_fwd_launch(const float* u, const float* delta, const float* dtr, const float* Wdt, int R, const float* A,
+                           const float* Bm, const float* Cm, const float* D, const float* dbias, float* y, float* hstate, int B,
+                           int K, int Dk, int N, int L, int xmode, void* stream) {
+  if (!u || (!delta && !dtr) || (dtr && !Wdt) || !A || !Bm || !Cm || !D || !dbias || !y || !hstate || B <= 0 || K <= 0 || Dk <= 0 ||
+      L <= 0)
     return TAMTR_EINVAL;
-  if (N != NS || (long long)B * K > 65535 || (xmode && K != 4)) return TAMTR_EUNSUP;
+  if (N != NS || (long long)B * K > 65535 || (xmode && K != 4) || (dtr && (R < 1 || R > RMAX))) return TAMTR_EUNSUP;
   const int nchunk = (L + CHUNK - 1) / CHUNK;
   dim3 grid((Dk + FWD_ROWS - 1) / FWD_ROWS, B * K);
   hipStream_t s = (hipStream_t)stream;
+  const size_t dyn = dtr ? ((size_t)R * CHUNK + FWD_ROWS * RMAX) * sizeof(float) : 0;
   if (L % 4 == 0)
-    hipLaunchKernelGGL(selscan_fwd_kernel<true>, grid, dim3(FWD_ROWS * WAVE), 0, s, u, delta, A, Bm, Cm, D, dbias, y, hstate, K, Dk, L,
-                       nchunk, xmode);
+    hipLaunchKernelGGL(selscan_fwd_kernel<true>, grid, dim3(FWD_ROWS * WAVE), dyn, s, u, delta, A, Bm, Cm, D, dbias, y, hstate, K, Dk,
+                       L, nchunk, xmode, dtr, Wdt, R);
   else
-    hipLaunchKernelGGL(selscan_fwd_kernel<false>, grid, dim3(FWD_ROWS * WAVE), 0, s, u, delta, A, Bm, Cm, D, dbias, y, hstate, K, Dk, L,
-                       nchunk, xmode);
+    hipLaunchKernelGGL(selscan_fwd_kernel<false>, grid, dim3(FWD_ROWS * WAVE), dyn, s, u, delta, A, Bm, Cm, D, dbias, y, hstate, K, Dk,
+                       L, nchunk, xmode, dtr, Wdt, R);
   return tamtr_launch_status();
 }
+
+extern "C" int tamtr_selective_scan_fwd(const float* u, const float* delta, const float* A, const float* Bm, const float* Cm,
+                                        const float* D, const float* dbias, float* y, float* hstate, int B, int K, int Dk, int N,
+                                        int L, int xmode, void* stream) {
+  return scan_fwd_launch(u, delta, nullptr, nullptr, 0, A, Bm, Cm, D, dbias, y, hstate, B, K, Dk, N, L, xmode, stream);
+}
+
+extern "C" int tamtr_selective_scan_dtproj_fwd(const float* u, const float* dtr, const float* Wdt, const float* A, const float* Bm,
+                                               const float* Cm, const float* D, const float* dbias, float* y, float* hstate, int B,
+                                               int K, int Dk, int N, int R, int L, int xmode, void* stream) {
+  if (!dtr) return TAMTR_EINVAL;
+  return scan_fwd_launch(u, nullptr, dtr, Wdt, R, A, Bm, Cm, D, dbias, y, hstate, B, K, Dk, N, L, xmode, stream);
+}
+
+static int scan_bwd_launch(const float* gy, const float* u, const float* delta, const float* dtr, const float* Wdt, int R,
+                           const float* A, const float* Bm, const float* Cm, const float* D, const float* dbias, const float* hstate,
+                           float* gu, float* gdelta, float* gdtr, float* gWdt, float* gA, float* gB, float* gC, float* gD,
+                           float* gdbias, float* ws, int B, int K, int Dk, int N, int L, int xmode, void* stream);
 
 extern "C" int tamtr_selective_scan_bwd(const float* gy, const float* u, const float* delta, const float* A, const float* Bm,
                                         const float* Cm, const float* D, const float* dbias, const float* hstate, float* gu,
                                         float* gdelta, float* gA, float* gB, float* gC, float* gD, float* gdbias, float* ws, int B,
                                         int K, int Dk, int N, int L, int xmode, void* stream) {
-  if (!gy || !u || !delta || !A || !Bm || !Cm || !D || !dbias || !hstate || !gu || !gdelta || !gA || !gB || !gC || !gD ||
+  if (!delta) return TAMTR_EINVAL;
+  return scan_bwd_launch(gy, u, delta, nullptr, nullptr, 0, A, Bm, Cm, D, dbias, hstate, gu, gdelta, nullptr, nullptr, gA, gB, gC, gD,
+                         gdbias, ws, B, K, Dk, N, L, xmode, stream);
+}
+
+extern "C" int tamtr_selective_scan_dtproj_bwd(const float* gy, const float* u, const float* dtr, const float* Wdt, const float* A,
+                                               const float* Bm, const float* Cm, const float* D, const float* dbias,
+                                               const float* hstate, float* gu, float* gdelta_ws, float* gdtr, float* gWdt, float* gA,
+                                               float* gB, float* gC, float* gD, float* gdbias, float* ws, int B, int K, int Dk, int N,
+                                               int R, int L, int xmode, void* stream) {
+  if (!dtr || !Wdt || !gdtr || !gWdt) return TAMTR_EINVAL;
+  return scan_bwd_launch(gy, u, nullptr, dtr, Wdt, R, A, Bm, Cm, D, dbias, hstate, gu, gdelta_ws, gdtr, gWdt, gA, gB, gC, gD, gdbias, ws,
+                         B, K, Dk, N, L, xmode, stream);
+}
+
+static int scan_bwd_launch(const float* gy, const float* u, const float* delta, const float* dtr, const float* Wdt, int R,
+                           const float* A, const float* Bm, const float* Cm, const float* D, const float* dbias, const float* hstate,
+                           float* gu, float* gdelta, float* gdtr, float* gWdt, float* gA, float* gB, float* gC, float* gD,
+                           float* gdbias, float* ws, int B, int K, int Dk, int N, int L, int xmode, void* stream) {
+  if (!gy || !u || (!delta && !dtr) || !A || !Bm || !Cm || !D || !dbias || !hstate || !gu || !gdelta || !gA || !gB || !gC || !gD ||
       !gdbias || !ws || B <= 0 || K <= 0 || Dk <= 0 || L <= 0)
     return TAMTR_EINVAL;
-  if (N != NS || (long long)B * K > 65535 || (xmode && K != 4)) return TAMTR_EUNSUP;
+  if (N != NS || (long long)B * K > 65535 || (xmode && K != 4) || (dtr && (R < 1 || R > RMAX))) return TAMTR_EUNSUP;
   const int nchunk = (L + CHUNK - 1) / CHUNK;
   const int nslab = (Dk + BWD_ROWS - 1) / BWD_ROWS;
   const size_t slab = (size_t)B * K * NS * L;
@@ -462,12 +633,21 @@ extern "C" int tamtr_selective_scan_bwd(const float* gy, const float* u, const f
   float* wsC = ws + (size_t)nslab * slab;
   dim3 grid(nslab, B * K);
   hipStream_t s = (hipStream_t)stream;
+  const size_t dyn = dtr ? ((size_t)R * CHUNK + 2 * BWD_ROWS * RMAX) * sizeof(float) : 0;
   if (L % 4 == 0)
-    hipLaunchKernelGGL(selscan_bwd_kernel<true>, grid, dim3(BWD_WAVES * WAVE), 0, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu,
-                       gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab, xmode);
+    hipLaunchKernelGGL(selscan_bwd_kernel<true>, grid, dim3(BWD_WAVES * WAVE), dyn, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu,
+                       gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab, xmode, dtr, Wdt, gWdt, R);
   else
-    hipLaunchKernelGGL(selscan_bwd_kernel<false>, grid, dim3(BWD_WAVES * WAVE), 0, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu,
-                       gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab, xmode);
+    hipLaunchKernelGGL(selscan_bwd_kernel<false>, grid, dim3(BWD_WAVES * WAVE), dyn, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu,
+                       gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab, xmode, dtr, Wdt, gWdt, R);
+  if (dtr && L % 4) {
+    hipLaunchKernelGGL(dtproj_gdtr_scalar_kernel, dim3((L + 255) / 256, B * K), dim3(256), 0, s, gdelta, Wdt, gdtr, K, Dk, R, L);
+  } else if (dtr) {  // gdtr = Wdt^T gdelta (position space, un-reversed)
+    dim3 g2((L / 4 + 255) / 256, B * K);
+    if (R <= 8) hipLaunchKernelGGL(dtproj_gdtr_kernel<8>, g2, dim3(256), 0, s, gdelta, Wdt, gdtr, K, Dk, R, L);
+    else if (R <= 16) hipLaunchKernelGGL(dtproj_gdtr_kernel<16>, g2, dim3(256), 0, s, gdelta, Wdt, gdtr, K, Dk, R, L);
+    else hipLaunchKernelGGL(dtproj_gdtr_kernel<32>, g2, dim3(256), 0, s, gdelta, Wdt, gdtr, K, Dk, R, L);
+  }
   const size_t n4 = slab / 4;  // N = 16 makes slab a multiple of 4
   const unsigned blocks = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
   hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, s, wsB, wsC, gB, gC, n4, nslab);

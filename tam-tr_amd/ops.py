@@ -293,7 +293,55 @@ def selective_scan(u, delta, A, Bm, Cm, D, delta_bias):
     return _SelectiveScan.apply(u, delta, A, Bm, Cm, D, delta_bias, 0)
 
 
-def selective_scan_cross(u2, delta, A, Bm, Cm, D, delta_bias):
-    """Cross-scan layout (no 4x materialisation): u2 [B,2,Dk,L] = (row-major, column-major) flattenings; delta [B,4*Dk,L],
-    Bm, Cm [B,4,16,L] and the result are stored UN-reversed (directions 2, 3 share the order of 0, 1 and are walked backwards)."""
+def selective_scan_cross_delta(u2, delta, A, Bm, Cm, D, delta_bias):
+    """Cross-scan layout with a materialised delta (kept for testing the layout on its own)."""
     return _SelectiveScan.apply(u2, delta, A, Bm, Cm, D, delta_bias, 1)
+
+
+class _SelectiveScanDtProj(torch.autograd.Function):
+    """Scan with the dt projection fused in: delta = Wdt . dtr is formed inside the kernels (never materialised)."""
+
+    @staticmethod
+    def forward(ctx, u, dtr, Wdt, A, Bm, Cm, D, dbias, xmode):
+        require_gpu(u, dtr, Wdt, A, Bm, Cm, D, dbias)
+        Bn, K, R, L = dtr.shape
+        KD, N = A.shape
+        u, dtr, Wdt, A, Bm, Cm, D, dbias = (_c(t.float()) for t in (u, dtr, Wdt, A, Bm, Cm, D, dbias))
+        chunk = _lib.lib().tamtr_selective_scan_chunk()
+        nchunk = (L + chunk - 1) // chunk
+        y = torch.empty(Bn, KD, L, device=u.device, dtype=torch.float32)
+        hstate = torch.empty(Bn, KD, nchunk, N, device=u.device, dtype=torch.float32)
+        call('tamtr_selective_scan_dtproj_fwd', ptr(u), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(dbias), ptr(y),
+             ptr(hstate), Bn, K, KD // K, N, R, L, int(xmode), stream_ptr())
+        ctx.save_for_backward(u, dtr, Wdt, A, Bm, Cm, D, dbias, hstate)
+        ctx.xmode = int(xmode)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        u, dtr, Wdt, A, Bm, Cm, D, dbias, hstate = ctx.saved_tensors
+        Bn, K, R, L = dtr.shape
+        KD, N = A.shape
+        gy = _c(gy.float())
+        gu = torch.empty(Bn, KD, L, device=u.device, dtype=torch.float32)
+        gdelta = torch.empty(Bn, KD, L, device=u.device, dtype=torch.float32)  # workspace between the two backward kernels
+        gdtr = torch.empty_like(dtr)
+        gW, gA = torch.zeros_like(Wdt), torch.zeros_like(A)
+        gB, gC = torch.empty_like(Bm), torch.empty_like(Cm)
+        gD, gbias = torch.zeros_like(D), torch.zeros_like(dbias)
+        nslab = _lib.lib().tamtr_selective_scan_bwd_slabs(KD // K)
+        ws = torch.empty(2 * nslab * Bm.numel(), device=u.device, dtype=torch.float32)
+        call('tamtr_selective_scan_dtproj_bwd', ptr(gy), ptr(u), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(dbias),
+             ptr(hstate), ptr(gu), ptr(gdelta), ptr(gdtr), ptr(gW), ptr(gA), ptr(gB), ptr(gC), ptr(gD), ptr(gbias), ptr(ws), Bn, K,
+             KD // K, N, R, L, ctx.xmode, stream_ptr())
+        if ctx.xmode:
+            g4 = gu.view(Bn, 4, KD // 4, L)
+            gu = g4[:, :2] + g4[:, 2:]
+        return gu, gdtr, gW, gA, gB, gC, gD, gbias, None
+
+
+def selective_scan_cross(u2, dtr, Wdt, A, Bm, Cm, D, delta_bias):
+    """Cross-scan layout + fused dt projection: u2 [B,2,Dk,L] (row-major / column-major copies), dtr [B,4,R,L] low-rank dt
+    factors, Wdt [4*Dk, R]; Bm, Cm [B,4,16,L]; everything stored UN-reversed (directions 2, 3 walk the buffers backwards).
+    Returns y [B, 4*Dk, L] (un-reversed)."""
+    return _SelectiveScanDtProj.apply(u2, dtr, Wdt, A, Bm, Cm, D, delta_bias, 1)

@@ -11,7 +11,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 from . import ops
+
+_EINSUM_DT = os.environ.get('TAMTR_SS2D_EINSUM') == '1'
 
 
 class DropPath(nn.Module):
@@ -83,14 +87,18 @@ class SS2D(nn.Module):
         xd_b = torch.matmul(torch.cat([wx[1], wx[3]], 0), u2[:, 1])  # directions 1 and 3
         C = R + 2 * N
         x_dbl = torch.stack([xd_a[:, :C], xd_b[:, :C], xd_a[:, C:], xd_b[:, C:]], 1)  # [B,4,C,L]
-        dts, Bs, Cs = torch.split(x_dbl, [R, N, N], 2)
-        # (folding dt_proj into x_proj as one [D,D] GEMM per direction was tried: -30 ms of GPU time but +11 ms of wall, the
-        #  step is host-launch-bound; the real fix is computing delta inside the scan kernel - DESIGN.md "next")
-        dts = torch.einsum('bkrl,kdr->bkdl', dts, self.dt_projs_weight.float())
-        Bs, Cs = Bs.contiguous(), Cs.contiguous()
+        dtr, Bs, Cs = (t.contiguous() for t in torch.split(x_dbl, [R, N, N], 2))
+        # the dt projection (einsum "bkrl,kdr->bkdl", vmamba.py:972) happens INSIDE the scan kernels: the [B, 4*d_inner, L]
+        # delta tensor is never written, and its skinny K = R <= 32 GEMMs (forward + two backward: ~38 ms per step through
+        # rocBLAS at these shapes) disappear
         As = -torch.exp(self.A_logs.float())
-        ys = ops.selective_scan_cross(u2, dts.reshape(B, -1, L), As, Bs, Cs, self.Ds.float(),
-                                      self.dt_projs_bias.float().reshape(-1)).view(B, K, D, L)
+        if _EINSUM_DT:  # A/B switch (env TAMTR_SS2D_EINSUM=1): reference-shaped einsum + materialised delta
+            dts = torch.einsum('bkrl,kdr->bkdl', dtr, self.dt_projs_weight.float())
+            ys = ops.selective_scan_cross_delta(u2, dts.reshape(B, -1, L), As, Bs, Cs, self.Ds.float(),
+                                                self.dt_projs_bias.float().reshape(-1)).view(B, K, D, L)
+        else:
+            ys = ops.selective_scan_cross(u2, dtr, self.dt_projs_weight.float().reshape(K * D, R), As, Bs, Cs, self.Ds.float(),
+                                          self.dt_projs_bias.float().reshape(-1)).view(B, K, D, L)
         # cross-merge (csms6s.py:26-34) on un-reversed outputs: no flips left
         y = ys[:, 0] + ys[:, 2] + (ys[:, 1] + ys[:, 3]).view(B, D, W, H).transpose(2, 3).reshape(B, D, L)
         y = self.out_norm(y.transpose(1, 2)).view(B, H, W, -1)

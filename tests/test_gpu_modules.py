@@ -85,10 +85,39 @@ def test_selective_scan_cross_layout(pkg, Bn, Dk, H, W):
     (ref * cot).sum().backward()
     g = [dev(t).requires_grad_() for t in (xi, dl, A, Bm, Cm, D, bias)]
     u2 = torch.stack([g[0].flatten(2), g[0].transpose(2, 3).flatten(2)], 1)
-    out = pkg.ops.selective_scan_cross(u2, g[1], g[2], g[3], g[4], g[5], g[6])
+    out = pkg.ops.selective_scan_cross_delta(u2, g[1], g[2], g[3], g[4], g[5], g[6])
     (out * dev(cot)).sum().backward()
     assert_close(out, ref, 1e-3, 1e-4, 'y (cross layout)')
     for n, a, b in zip('xi delta A B C D bias'.split(), g, r):
+        assert_close(a.grad, b.grad, 2e-3, 2e-4 * max(float(b.grad.abs().max()), 1.0), 'grad ' + n)
+
+
+@pytest.mark.parametrize('Bn,Dk,H,W,R', [(2, 5, 4, 6, 8), (1, 40, 16, 16, 16), (1, 9, 8, 10, 32), (2, 3, 4, 4, 1)])
+def test_selective_scan_fused_dt_projection(pkg, Bn, Dk, H, W, R):
+    """Scan with the dt projection fused in (delta = Wdt . dtr formed in-kernel) vs oracle einsum + CrossScan + scan."""
+    L, K, N = H * W, 4, 16
+    xi, dtr = rnd((Bn, Dk, H, W), 1), rnd((Bn, K, R, L), 2)
+    Wdt = rnd((K, Dk, R), 9, R ** -0.5)
+    A = -torch.exp(rnd((K * Dk, N), 3, 0.5))
+    Bm, Cm = rnd((Bn, K, N, L), 4), rnd((Bn, K, N, L), 5)
+    D, bias = rnd((K * Dk,), 6), rnd((K * Dk,), 7) - 2.0
+    cot = rnd((Bn, K * Dk, L), 8)
+
+    def flip_rev(t, kd):
+        v = t.view(Bn, K, kd, L)
+        return torch.cat([v[:, :2], v[:, 2:].flip(-1)], 1).reshape(t.shape)
+
+    r = [t.clone().requires_grad_() for t in (xi, dtr, Wdt, A, Bm, Cm, D, bias)]
+    delta = torch.einsum('bkrl,kdr->bkdl', r[1], r[2]).reshape(Bn, K * Dk, L)  # vmamba.py:972
+    xs = O.cross_scan(r[0]).reshape(Bn, K * Dk, L)
+    ref = flip_rev(O.selective_scan(xs, flip_rev(delta, Dk), r[3], flip_rev(r[4], N), flip_rev(r[5], N), r[6], r[7]), Dk)
+    (ref * cot).sum().backward()
+    g = [dev(t).requires_grad_() for t in (xi, dtr, Wdt, A, Bm, Cm, D, bias)]
+    u2 = torch.stack([g[0].flatten(2), g[0].transpose(2, 3).flatten(2)], 1)
+    out = pkg.ops.selective_scan_cross(u2, g[1], g[2].reshape(K * Dk, R), g[3], g[4], g[5], g[6], g[7])
+    (out * dev(cot)).sum().backward()
+    assert_close(out, ref, 1e-3, 1e-4, 'y (fused dt)')
+    for n, a, b in zip('xi dtr Wdt A B C D bias'.split(), g, r):
         assert_close(a.grad, b.grad, 2e-3, 2e-4 * max(float(b.grad.abs().max()), 1.0), 'grad ' + n)
 
 

@@ -25,27 +25,29 @@ def timeit(fn, n=5, warm=2):
 
 
 def bench_scan():
-    for lvl, (d_inner, L) in enumerate([(256, 25600), (512, 6400), (1024, 1600)]):
+    for lvl, (d_inner, L, R) in enumerate([(256, 25600, 8), (512, 6400, 16), (1024, 1600, 32)]):
         B, K, N = 16, 4, 16
         g = torch.Generator(device='cuda').manual_seed(0)
-        u = torch.randn(B, K * d_inner, L, device='cuda', generator=g)
-        dl = torch.randn(B, K * d_inner, L, device='cuda', generator=g)
+        side = int(L ** 0.5)
+        u2 = torch.randn(B, 2, d_inner, L, device='cuda', generator=g)
+        dtr = torch.randn(B, K, R, L, device='cuda', generator=g)
+        Wdt = torch.randn(K * d_inner, R, device='cuda', generator=g) * R ** -0.5
         A = -torch.exp(torch.randn(K * d_inner, N, device='cuda', generator=g) * 0.3)
         Bm = torch.randn(B, K, N, L, device='cuda', generator=g)
         Cm = torch.randn(B, K, N, L, device='cuda', generator=g)
         D = torch.randn(K * d_inner, device='cuda', generator=g)
         bias = torch.randn(K * d_inner, device='cuda', generator=g) - 3
-        ins = [t.requires_grad_() for t in (u, dl, A, Bm, Cm, D, bias)]
-        y = ops.selective_scan(*ins)
+        ins = [t.requires_grad_() for t in (u2, dtr, Wdt, A, Bm, Cm, D, bias)]
+        y = ops.selective_scan_cross(*ins)
         gy = torch.randn_like(y)
-        f_avg, f_min = timeit(lambda: ops.selective_scan(*ins))
+        f_avg, f_min = timeit(lambda: ops.selective_scan_cross(*ins))
         def fb():
-            yy = ops.selective_scan(*ins)
+            yy = ops.selective_scan_cross(*ins)
             torch.autograd.grad(yy, ins, gy)
         fb_avg, fb_min = timeit(fb)
-        byt = u.numel() * 4
-        print(f'scan level {lvl} d_inner={d_inner} L={L}: fwd {f_avg:.2f} ms ({3 * byt / f_avg / 1e6:.0f} GB/s algorithmic), '
-              f'bwd {fb_avg - f_avg:.2f} ms ({5 * byt / (fb_avg - f_avg) / 1e6:.0f} GB/s)')
+        byt = y.numel() * 4
+        print(f'scan (cross layout, fused dt proj) level {lvl} d_inner={d_inner} L={L} R={R}: fwd {f_avg:.2f} ms '
+              f'({1.5 * byt / f_avg / 1e6:.0f} GB/s algorithmic: u2 + y), fwd+bwd {fb_avg:.2f} ms -> bwd {fb_avg - f_avg:.2f} ms')
 
 
 def bench_gemm():
