@@ -40,7 +40,9 @@ def synth_batch(B, S, seed, device):
     wh = 0.02 + 0.2 * torch.rand(B * n, 2, generator=g)
     bidx = torch.arange(B).repeat_interleave(n).float()
     b = {'img': img, 'txt_feats': txt, 'cls': cls, 'bboxes': torch.cat([xy, wh], 1), 'batch_idx': bidx}
-    return {k: v.to(device) for k, v in b.items()}
+    # image + text embeddings resident in HBM; the (tiny) label tensors stay on the host, where the reference's trainer leaves them
+    # (RTDETRTrainer.preprocess_batch), and are uploaded inside the step
+    return {k: v.to(device) if k in ('img', 'txt_feats') else v for k, v in b.items()}
 
 
 class KernelTimer:

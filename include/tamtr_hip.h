@@ -162,6 +162,21 @@ int tamtr_selective_scan_dtproj_bwd(const float* gy, const float* u, const float
                                     float* gu, float* gdelta_ws, float* gdtr, float* gWdt, float* gA, float* gB, float* gC, float* gD,
                                     float* gdbias, float* ws, int B, int K, int Dk, int N, int R, int L, int xmode, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * a-10 / next-4  Device-side Hungarian assignment.  Replaces `C.cpu()` + scipy.optimize.linear_sum_assignment per
+ *      image in HungarianMatcher.forward, ultralytics/models/utils/ops.py:98-119 (and its four host syncs per step).
+ *      Same solver as scipy's (shortest augmenting paths, float64 duals, same scan order and tie rule): the pairs
+ *      returned are scipy's, in scipy's order (ascending query index inside each image).
+ *      cost  f32 [bs, nq, G]         finite matching costs, G = sum(group_sizes); image b owns columns
+ *                                    [off_b, off_b + group_sizes[b])
+ *      group_sizes_host i32 [bs]     HOST array (boxes per image; bs <= 256)
+ *      batch_idx/query_idx/gt_idx i64 [sum_b min(nq, group_sizes[b])]   outputs: image, query and GLOBAL box index of
+ *                                    every matched pair (query_idx = gt_idx = -1 for an image whose costs are not finite)
+ *      TAMTR_EUNSUP when one image needs more than 64 KB of LDS (about nq + boxes > 3000).
+ */
+int tamtr_lsap_assign(const float* cost, const int32_t* group_sizes_host, int bs, int nq, int G, int64_t* batch_idx,
+                      int64_t* query_idx, int64_t* gt_idx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

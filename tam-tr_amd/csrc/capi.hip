@@ -1,5 +1,5 @@
-// capi.hip - ABI version of libtamtr_hip.so (the kernels live in gate/msdeform/contrastive/selfattn/selscan/gemm_bf16.hip).
+// capi.hip - ABI version of libtamtr_hip.so (the kernels live in gate/msdeform/contrastive/selfattn/selscan/gemm_bf16/lsap.hip).
 #include "common.h"
 
-extern "C" int tamtr_abi_version(void) { return 3; }
+extern "C" int tamtr_abi_version(void) { return 4; }
 

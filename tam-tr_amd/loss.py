@@ -2,15 +2,37 @@
 contrastive-denoising query groups and the 12-term RT-DETR loss.
 
   bbox_iou(RIOU)        ultralytics/utils/metrics.py:71-130
-  HungarianMatcher      ultralytics/models/utils/ops.py:12-119     (cost on device, ONE async D2H per layer, scipy LSA)
+  HungarianMatcher      ultralytics/models/utils/ops.py:12-119     (cost on device; assignment by the HIP solver
+                        ops.lsap_assign for GPU tensors - no host round trip; scipy, as the reference, for CPU tensors)
   get_cdn_group         ultralytics/models/utils/ops.py:152-291
   RTDETRDetectionLoss   ultralytics/models/utils/loss.py:14-442 (VFL + L1 + RIOU, aux + dn branches)
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .hostio import stager
+
+_SCIPY_MATCHER = os.environ.get('TAMTR_MATCHER') == 'scipy'  # A/B switch: the reference's host round trip on GPU runs too
+
+
+class Matches(list):
+    """list of per-image (query_idx, gt_idx) pairs as the reference returns them (models/utils/ops.py:117-119), plus
+    `.flat` = (batch_idx, query_idx, gt_idx) device tensors over all images, which is what the loss terms consume."""
+    flat = None
+
+
+def flat_matches(match, dev):
+    """One staged (non-synchronising) H2D of a host-side list of (query_idx, gt_idx) pairs -> (bi, si, gi) on `dev`."""
+    if getattr(match, 'flat', None) is not None:
+        return match.flat
+    bi = torch.cat([torch.full_like(s, i) for i, (s, _) in enumerate(match)])
+    idx = torch.stack([bi, torch.cat([s for s, _ in match]), torch.cat([g for _, g in match])]).long()
+    idx = idx.to(dev) if idx.is_cuda else stager().h2d(idx, dev)
+    return idx[0], idx[1], idx[2]
 
 
 def xywh2xyxy(b):
@@ -74,12 +96,22 @@ class HungarianMatcher(nn.Module):
         c_iou = 1.0 - bbox_iou(pb.unsqueeze(1), gt_bboxes.unsqueeze(0), xywh=True, RIOU=True).squeeze(-1)
         C = self.cost_gain['class'] * c_cls + self.cost_gain['bbox'] * c_l1 + self.cost_gain['giou'] * c_iou
         C = torch.where(torch.isfinite(C), C, torch.zeros_like(C)).view(bs, nq, -1)
-        C = C.cpu()  # the one device->host sync of this layer's loss
-        out, off = [], 0
-        for i, c in enumerate(C.split(list(gt_groups), -1)):
+        groups = [int(n) for n in gt_groups]
+        if C.is_cuda and not _SCIPY_MATCHER:
+            from . import ops
+            bi, si, gi = ops.lsap_assign(C, groups)  # HIP solver, scipy's pairs in scipy's order, nothing leaves the GPU
+            sizes = [min(nq, n) for n in groups]
+            out = Matches(zip(si.split(sizes), gi.split(sizes)))
+            out.flat = (bi, si, gi)
+            return out
+        dev, C = C.device, C.cpu()  # reference behaviour: device->host sync, scipy per image
+        out, off = Matches(), 0
+        for i, c in enumerate(C.split(groups, -1)):
             r, k = linear_sum_assignment(c[i].numpy())
             out.append((torch.as_tensor(r, dtype=torch.long), torch.as_tensor(k, dtype=torch.long) + off))
-            off += gt_groups[i]
+            off += groups[i]
+        if dev.type != 'cpu':
+            out.flat = tuple(t.to(dev) for t in flat_matches(out, 'cpu'))
         return out
 
 
@@ -96,9 +128,10 @@ def get_cdn_group(batch, num_classes, num_queries, class_embed, num_dn=100, cls_
     dev = class_embed.device
     ng = max(num_dn // mx, 1)
     bs = len(groups)
-    cls = batch['cls'].cpu().repeat(2 * ng)
-    box = batch['bboxes'].cpu().float().repeat(2 * ng, 1)
-    bidx = batch['batch_idx'].cpu().repeat(2 * ng).view(-1)
+    host = batch.get('host') or {k: batch[k].cpu() for k in ('cls', 'bboxes', 'batch_idx')}  # host copies (model.loss keeps them)
+    cls = host['cls'].repeat(2 * ng)
+    box = host['bboxes'].float().repeat(2 * ng, 1)
+    bidx = host['batch_idx'].repeat(2 * ng).view(-1)
     neg = torch.arange(total * ng, dtype=torch.long) + ng * total
     if cls_noise_ratio > 0:
         idx = torch.nonzero(torch.rand(cls.shape) < cls_noise_ratio * 0.5).squeeze(-1)
@@ -115,22 +148,37 @@ def get_cdn_group(batch, num_classes, num_queries, class_embed, num_dn=100, cls_
     within = torch.cat([torch.arange(n, dtype=torch.long) for n in groups])
     pos_idx = torch.stack([within + mx * i for i in range(ng)], 0)
     slot = torch.cat([within + mx * i for i in range(2 * ng)])
-    cls, box, bidx, slot = cls.to(dev), box.to(dev), bidx.to(dev), slot.to(dev)
+    put = stager().h2d  # pinned, non-synchronising uploads
+    cls, box, bidx, slot = put(cls, dev), put(box, dev), put(bidx, dev), put(slot, dev)
     emb = class_embed[cls]
     pad_c = torch.zeros(bs, n_dn, emb.shape[-1], device=dev, dtype=emb.dtype)
     pad_b = torch.zeros(bs, n_dn, 4, device=dev)
     pad_c[bidx, slot] = emb
     pad_b[bidx, slot] = box
-    size = n_dn + num_queries
-    mask = torch.zeros(size, size, dtype=torch.bool)
-    mask[n_dn:, :n_dn] = True
-    for i in range(ng):
-        lo, hi = mx * 2 * i, mx * 2 * (i + 1)
-        mask[lo:hi, hi:n_dn] = True
-        mask[lo:hi, :lo] = True
+    mask = _dn_attn_mask(n_dn, num_queries, mx, ng, str(dev))
     meta = {'dn_pos_idx': [p.reshape(-1) for p in pos_idx.split(list(groups), 1)], 'dn_num_group': ng,
             'dn_num_split': [n_dn, num_queries]}
-    return pad_c, pad_b, mask.to(dev), meta
+    return pad_c, pad_b, mask, meta
+
+
+_MASKS = {}
+
+
+def _dn_attn_mask(n_dn, num_queries, mx, ng, dev):
+    """Block mask of the denoising groups (ops.py:273-284); depends only on the four sizes, so it is built once per shape."""
+    key = (n_dn, num_queries, mx, ng, dev)
+    if key not in _MASKS:
+        size = n_dn + num_queries
+        mask = torch.zeros(size, size, dtype=torch.bool)
+        mask[n_dn:, :n_dn] = True
+        for i in range(ng):
+            lo, hi = mx * 2 * i, mx * 2 * (i + 1)
+            mask[lo:hi, hi:n_dn] = True
+            mask[lo:hi, :lo] = True
+        if len(_MASKS) > 64:
+            _MASKS.clear()
+        _MASKS[key] = mask.to(dev)
+    return _MASKS[key]
 
 
 def varifocal_loss(pred, gt_score, label, alpha=0.75, gamma=2.0):
@@ -158,9 +206,7 @@ class DETRLoss(nn.Module):
         dev = pb.device
         if match is None:
             match = self.matcher(pb, ps, gt_bboxes, gt_cls, gt_groups)
-        bi = torch.cat([torch.full_like(s, i) for i, (s, _) in enumerate(match)]).to(dev)
-        si = torch.cat([s for s, _ in match]).to(dev)
-        gi = torch.cat([g for _, g in match]).to(dev)
+        bi, si, gi = flat_matches(match, dev)
         bs, nq = pb.shape[:2]
         p_sel, g_sel = pb[bi, si].float(), gt_bboxes[gi]
         n = int(g_sel.shape[0])
@@ -185,6 +231,10 @@ class DETRLoss(nn.Module):
 
     def forward(self, pred_bboxes, pred_scores, batch, postfix='', match_indices=None):
         gt_cls, gt_bboxes, gt_groups = batch['cls'], batch['bboxes'], batch['gt_groups']
+        if match_indices is not None and getattr(match_indices, 'flat', None) is None:  # fixed (dn) pairs: upload once, not per layer
+            fixed = Matches(match_indices)
+            fixed.flat = flat_matches(match_indices, pred_bboxes.device)
+            match_indices = fixed
         out = {}
         c, b, g = self._layer(pred_bboxes[-1], pred_scores[-1], gt_bboxes, gt_cls, gt_groups, match_indices)
         out[f'loss_class{postfix}'], out[f'loss_bbox{postfix}'], out[f'loss_giou{postfix}'] = c, b, g

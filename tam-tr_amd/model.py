@@ -9,6 +9,7 @@ import torch.nn as nn
 
 from .backbone import CPAM, Concat, Conv, RepNCSPELAN4, SPPELAN
 from .head import ManbaWorldDecoder
+from .hostio import stager
 from .loss import RTDETRDetectionLoss
 from .modules import TIAGELAN
 
@@ -107,10 +108,17 @@ class RTDETRDetectionWorldModel(nn.Module):
         if not hasattr(self, 'criterion'):
             self.criterion = self.init_criterion()
         img = batch['img']
-        bidx = batch['batch_idx'].to(img.device, dtype=torch.long).view(-1)
-        counts = torch.bincount(bidx, minlength=len(img)).tolist()  # one host sync for the ragged group sizes
-        targets = {'cls': batch['cls'].to(img.device, dtype=torch.long).view(-1), 'bboxes': batch['bboxes'].to(img.device),
-                   'batch_idx': bidx, 'gt_groups': counts}
+        dev = img.device
+        # Labels arrive on the HOST in the reference's trainer (RTDETRTrainer.preprocess_batch regroups them on the CPU); keep
+        # the host copies for the ragged group sizes and the denoising RNG and upload through the pinned ring, so that nothing in
+        # the step waits for the GPU.  Device-resident labels are accepted too, at the cost of one synchronising read-back.
+        host = {'cls': batch['cls'].detach().cpu().long().view(-1), 'bboxes': batch['bboxes'].detach().cpu().float(),
+                'batch_idx': batch['batch_idx'].detach().cpu().long().view(-1)}
+        counts = torch.bincount(host['batch_idx'], minlength=len(img)).tolist()
+        st = stager()
+        st.next_step()
+        targets = {k: (batch[k].to(dev, host[k].dtype).view(host[k].shape) if batch[k].is_cuda else st.h2d(host[k], dev)) for k in host}
+        targets.update(gt_groups=counts, host=host)
         preds = self.predict(img, batch=targets, txt_feats=batch['txt_feats']) if preds is None else preds
         dec_bboxes, dec_scores, enc_bboxes, enc_scores, dn_meta = preds if self.training else preds[1]
         dn_bboxes = dn_scores = None

@@ -345,3 +345,24 @@ def selective_scan_cross(u2, dtr, Wdt, A, Bm, Cm, D, delta_bias):
     factors, Wdt [4*Dk, R]; Bm, Cm [B,4,16,L]; everything stored UN-reversed (directions 2, 3 walk the buffers backwards).
     Returns y [B, 4*Dk, L] (un-reversed)."""
     return _SelectiveScanDtProj.apply(u2, dtr, Wdt, A, Bm, Cm, D, delta_bias, 1)
+
+
+@torch.no_grad()
+def lsap_assign(cost, gt_groups):
+    """Device-side Hungarian assignment (models/utils/ops.py:98-119 without the host round trip).
+    cost f32 [bs, nq, G] on the GPU, gt_groups: python list of boxes per image (sum == G).
+    Returns int64 device tensors (batch_idx, query_idx, gt_idx) of length sum(min(nq, n_b)): scipy's pairs in scipy's
+    order, gt_idx already offset into the flattened box list.  No synchronisation."""
+    require_gpu(cost)
+    bs, nq, G = cost.shape
+    groups = [int(n) for n in gt_groups]
+    if len(groups) != bs or sum(groups) != G:
+        raise _lib.TamtrHipError(f'lsap_assign: group sizes {groups} do not tile cost {tuple(cost.shape)}')
+    m = sum(min(nq, n) for n in groups)
+    out = torch.empty(3, m, device=cost.device, dtype=torch.int64)
+    if m:
+        cost = _c(cost.float())
+        sizes = (ctypes.c_int32 * bs)(*groups)
+        call('tamtr_lsap_assign', ptr(cost), ctypes.cast(sizes, ctypes.c_void_p), bs, nq, G, ptr(out[0]), ptr(out[1]), ptr(out[2]),
+             stream_ptr())
+    return out[0], out[1], out[2]

@@ -19,11 +19,12 @@ def pkg():
         pytest.skip('no GPU')
     import tamtr_amd  # noqa: F401
     import tamtr_amd.head as head
+    import tamtr_amd.loss as loss
     import tamtr_amd.model as model
     import tamtr_amd.modules as modules
     import tamtr_amd.ops as ops
     import tamtr_amd.vss as vss
-    return type('P', (), dict(modules=modules, head=head, model=model, ops=ops, vss=vss))
+    return type('P', (), dict(modules=modules, head=head, model=model, ops=ops, vss=vss, loss=loss))
 
 
 def dev(t, dtype=None):
@@ -388,6 +389,56 @@ def test_full_model_vs_reference_fixture(pkg, golden):
         y, _ = model(batch['img'], txt_feats=batch['txt_feats'])
     for b in range(2):
         assert_rows_match(y[b], fx['y_eval'][b], 2e-3, f'eval predictions image {b}')
+
+
+def test_matcher_on_device_equals_reference_fixture(pkg, golden):
+    """HungarianMatcher with GPU tensors (HIP assignment, no host round trip) returns the reference's pairs."""
+    fx = golden('matcher')
+    t = _targets(fx)
+    idx = pkg.loss.HungarianMatcher(cost_gain={'class': 2, 'bbox': 5, 'giou': 2})(dev(T(fx['pred_bboxes'])), dev(T(fx['pred_scores'])),
+                                                                                  t['bboxes'], t['cls'], t['gt_groups'])
+    assert idx.flat is not None and all(v.is_cuda for v in idx.flat)
+    for i, (a, b) in enumerate(idx):
+        assert torch.equal(a.cpu(), T(fx[f'match{i}.src']).long()) and torch.equal(b.cpu(), T(fx[f'match{i}.dst']).long())
+
+
+def test_training_step_never_synchronises(pkg):
+    """With labels on the host (as the reference's trainer hands them) a training step must not block on the GPU: no
+    device->host read-back, no pageable upload.  torch's sync debug mode reports every such call."""
+    import warnings
+    torch.manual_seed(0)
+    model = pkg.model.RTDETRDetectionWorldModel(nc=10).cuda().train()
+    model.autocast_dtype = torch.bfloat16
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
+    B, S = 2, 128
+    g = torch.Generator().manual_seed(3)
+    batch = {'img': torch.rand(B, 3, S, S, generator=g).cuda(),
+             'txt_feats': torch.nn.functional.normalize(torch.randn(B, 10, 512, generator=g), dim=-1).cuda(),
+             'cls': torch.randint(0, 10, (7, 1), generator=g).float(),
+             'bboxes': torch.cat([0.2 + 0.6 * torch.rand(7, 2, generator=g), 0.02 + 0.2 * torch.rand(7, 2, generator=g)], 1),
+             'batch_idx': torch.tensor([0., 0, 0, 1, 1, 1, 1])}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, _ = model(batch)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], max_norm=0.1)
+        opt.step()
+        return loss
+
+    step()  # lazy initialisation (MIOpen kernel selection, pinned ring, caches) may synchronise once
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('warn')
+    try:
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter('always')
+            loss = step()
+            loss2 = step()
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    syncs = [str(w.message) for w in rec if 'synchroniz' in str(w.message).lower()]
+    assert not syncs, syncs
+    assert torch.isfinite(loss).item() and torch.isfinite(loss2).item()
 
 
 def test_full_model_real_vss_vs_oracle(pkg):

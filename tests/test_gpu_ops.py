@@ -150,3 +150,53 @@ def test_cpu_tensor_is_refused():
     from tamtr_amd import TamtrHipError
     with pytest.raises(TamtrHipError):
         ops.contrastive_logits(torch.zeros(1, 1, 64), torch.zeros(1, 1, 64), torch.zeros(()), torch.zeros(1))
+
+
+def _scipy_pairs(cost, groups):
+    """What HungarianMatcher does in the reference (models/utils/ops.py:98-119): scipy per image on its own column block."""
+    from scipy.optimize import linear_sum_assignment
+    bi, si, gi, off = [], [], [], 0
+    for b, n in enumerate(groups):
+        r, c = linear_sum_assignment(cost[b, :, off:off + n].numpy())
+        bi += [b] * len(r); si += r.tolist(); gi += (c + off).tolist()
+        off += n
+    return bi, si, gi
+
+
+@pytest.mark.parametrize('nq,groups,kind', [
+    (100, [8] * 16, 'float'),                       # the bench configuration
+    (100, [0, 3, 17, 1, 0, 42], 'float'),           # ragged, empty images
+    (100, [150, 100, 99, 101], 'float'),            # more boxes than queries: scipy does not transpose
+    (300, [500, 7], 'float'),                       # reference default nq with a crowded VisDrone-like image (unstaged costs)
+    (100, [8] * 4, 'ties'),                         # small-integer costs: many exact ties, tie rule must equal scipy's
+    (37, [5, 40, 37], 'const'),                     # constant matrix (non-finite costs are zeroed by the matcher)
+    (64, [64, 1], 'ties'),
+])
+def test_lsap_assign_equals_scipy(ops, nq, groups, kind):
+    g = torch.Generator().manual_seed(nq + len(groups))
+    G = sum(groups)
+    if kind == 'float':
+        cost = torch.randn(len(groups), nq, G, generator=g) * 3
+    elif kind == 'ties':
+        cost = torch.randint(0, 4, (len(groups), nq, G), generator=g).float()
+    else:
+        cost = torch.zeros(len(groups), nq, G)
+    bi, si, gi = ops.lsap_assign(cost.cuda(), groups)
+    rb, rs, rg = _scipy_pairs(cost, groups)
+    assert bi.tolist() == rb
+    if kind == 'float':
+        assert si.tolist() == rs and gi.tolist() == rg
+    else:  # same optimum, and (the solver restates scipy's scan order and tie rule) the very same pairs
+        tot = cost[bi.cpu(), si.cpu(), gi.cpu()].double().sum()
+        assert float(tot) == float(cost[rb, rs, rg].double().sum())
+        assert si.tolist() == rs and gi.tolist() == rg
+
+
+def test_lsap_assign_argument_checks(ops):
+    import tamtr_amd
+    with pytest.raises(tamtr_amd.TamtrHipError):
+        ops.lsap_assign(torch.zeros(2, 10, 5).cuda(), [2, 2])          # sizes do not tile the columns
+    with pytest.raises(tamtr_amd.TamtrHipError):
+        ops.lsap_assign(torch.zeros(2, 10, 5), [2, 3])                 # CPU tensor: no fallback
+    bi, si, gi = ops.lsap_assign(torch.zeros(3, 10, 0).cuda(), [0, 0, 0])
+    assert bi.numel() == si.numel() == gi.numel() == 0
