@@ -177,6 +177,26 @@ int tamtr_selective_scan_dtproj_bwd(const float* gy, const float* u, const float
 int tamtr_lsap_assign(const float* cost, const int32_t* group_sizes_host, int bs, int nq, int G, int64_t* batch_idx,
                       int64_t* query_idx, int64_t* gt_idx, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * next-3  CPAM gates.  Replaces CPAM.forward after its max-pool, ultralytics/nn/extra_modules/block.py:271-308:
+ *          c   = sigmoid(interpolate(p, scale_factor=2, mode='bilinear', align_corners=False)) * x,  p = MaxPool2d(3,2,1)(x)
+ *          out = cat_g( sigmoid(max over the channels of chunk g of c) * c_g ),  g = 0..7  (c.chunk(8, 1))
+ *      x, out (T) [B, C, H, W]     H, W even (odd maps make the reference fail too), C % 8 == 0
+ *      p      (T) [B, C, H/2, W/2] pooled map (the caller runs the max-pool and keeps its indices for the backward)
+ *      s2    f32 [B, 8, H, W]      saved sigmoid of the chunk max     } consumed by _bwd
+ *      arg   i32 [B, 8, H, W]      channel (inside the chunk) holding the max }
+ */
+int tamtr_cpam_fwd(const void* x, const void* p, void* out, float* s2, int32_t* arg, int B, int C, int H, int W, int dtype,
+                   void* stream);
+
+/*      Backward.  gout (T) [B,C,H,W] ->
+ *      dx_direct (T) [B,C,H,W]    dL/dx through the product sigmoid(up(p)) * x
+ *      dp        (T) [B,C,H/2,W/2] dL/dp (caller scatters it through the max-pool indices and adds it to dx_direct)
+ *      du_ws     (T) [B,C,H,W]    workspace (dL/d upsampled map) between the two kernels
+ */
+int tamtr_cpam_bwd(const void* gout, const void* x, const void* p, const float* s2, const int32_t* arg, void* dx_direct,
+                   void* du_ws, void* dp, int B, int C, int H, int W, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

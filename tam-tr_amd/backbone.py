@@ -1,7 +1,7 @@
 """GELAN backbone / neck blocks that surround the hot path ("rest PyTorch-ROCm", BASELINE configs[1]).
 
-These are stock PyTorch modules (MIOpen convolutions) - they are NOT part of the hand-written HIP path; they exist so
-that the TAMTR graph can be assembled and its checkpoints (state_dict keys) stay interchangeable with the reference:
+These are stock PyTorch modules (MIOpen convolutions) - they are NOT part of the hand-written HIP path (except CPAM, whose
+gates run in the fused kernels of csrc/cpam.hip); they exist so that the TAMTR graph can be assembled and its checkpoints (state_dict keys) stay interchangeable with the reference:
   Conv            ultralytics/nn/modules/conv.py:23-40
   RepConvN ... RepNCSPELAN4, SPPELAN, CPAM   ultralytics/nn/extra_modules/block.py:26-163,255-308
 """
@@ -112,10 +112,8 @@ class CPAM(nn.Module):
         super().__init__()
 
     def forward(self, x):
-        c = torch.sigmoid(F.interpolate(F.max_pool2d(x, 3, 2, 1), scale_factor=2, mode='bilinear', align_corners=False)) * x
-        B, C, H, W = c.shape
-        g = c.reshape(B, 8, C // 8, H, W)
-        return (torch.sigmoid(g.amax(2, keepdim=True)) * g).reshape(B, C, H, W)
+        from . import ops
+        return ops.cpam(x)  # fused HIP kernels; no torch fallback
 
 
 class Concat(nn.Module):

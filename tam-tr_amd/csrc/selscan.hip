@@ -13,8 +13,8 @@
 // looped; the y dot product stays inside the lane.  Chunk-boundary states are written out for the backward pass, which
 // walks the chunks in reverse, recomputes h inside the chunk and runs the mirrored (suffix) scan for dL/dh.
 // B/C (and dB/dC) are shared by the Dk rows of a (b, k) group: a workgroup holds rows of ONE group and stages the chunk's
-// B/C tiles once in LDS.  In the backward every wave walks BWD_RPW rows per chunk and sums their dB/dC contributions in
-// REGISTERS; the waves then fold their register tiles into one LDS tile in turns, and the workgroup plain-stores it to
+// B/C tiles once in LDS.  In the backward every wave walks BWD_RPW rows per chunk (per group of STG states) and sums their
+// dB/dC contributions in REGISTERS; the waves then fold their register tiles into one LDS tile in turns, and the workgroup plain-stores it to
 // its slab of a workspace that a second kernel sums.  What was measured on the way (MI355X, level 0 = 16x1024 rows x
 // 25600 steps): float atomics straight into gB/gC ran at the contended-atomic rate (79 ms); an LDS tile fed by
 // ds_add_f32 from 8 waves was no better (81 ms, 64 of them in the LDS atomics); shuffles through ds_bpermute made both
@@ -31,6 +31,18 @@ constexpr int BWD_WAVES = 4;   // waves per workgroup, backward
 constexpr int BWD_RPW = 8;     // rows handled one after the other by each wave per chunk
 constexpr int BWD_ROWS = BWD_WAVES * BWD_RPW;  // rows of one (b,k) group per workgroup = one dB/dC slab
 constexpr float LOG2E = 1.4426950408889634f;
+// Backward kernel: states per group (STG; register tile of dB/dC = 2 x STG x ITEMS).  Measured on MI355X with
+// tools/bench_kernels.py scan at the three MEH levels (backward ms at level 0 / 1 / 2 = dt rank 8 / 16 / 32):
+//   STG 4, 2 waves/SIMD (207 VGPR)      18.8 / 10.5 / 7.3        STG 8 (256 VGPR + 256 B scratch)   23.1 / 12.0 / 7.6
+//   STG 2 (149 VGPR)                    26.4 / 14.5 / 10.0       STG 16, 1 wave/SIMD (501 VGPR+AGPR, 636 v_accvgpr moves)  - / - / 8.7
+// (STG 16 is the single-group kernel of the first version: 39.5 ms per training step over the three levels, now 36.6.)
+// Small groups repeat the row's delta projection (R FMAs x 4 per group); large ones spill the tile to AGPRs / scratch.
+#ifndef SCAN_BWD_STG_SMALLR
+#define SCAN_BWD_STG_SMALLR 4
+#endif
+#ifndef SCAN_BWD_STG_BIGR
+#define SCAN_BWD_STG_BIGR 4
+#endif
 
 // softplus with torch's threshold (20); log(1+e^x) through the hardware exp2/log2 (abs err ~1e-7, the e^x branch keeps
 // the relative accuracy for very negative x where 1 + e^x rounds to 1)
@@ -273,8 +285,8 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
 }
 
 // Backward: BWD_WAVES waves x BWD_RPW rows each = BWD_ROWS rows of one (b, k) group per workgroup.
-template <bool VEC>
-__global__ __launch_bounds__(BWD_WAVES* WAVE) void selscan_bwd_kernel(
+template <bool VEC, int STG>
+__global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_bwd_kernel(
     const float* __restrict__ gy, const float* __restrict__ u, const float* __restrict__ delta, const float* __restrict__ Am,
     const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ Dv, const float* __restrict__ dbias,
     const float* __restrict__ hstate, float* __restrict__ gu, float* __restrict__ gdelta, float* __restrict__ gA,
@@ -318,142 +330,163 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE) void selscan_bwd_kernel(
     if (dtr) stage_dtr<BWD_WAVES * WAVE>(Rp, R, c * CHUNK, L, s_dtr, VEC, rev);
     __syncthreads();
     const int t = c * CHUNK + lane * ITEMS;
-    float accB[NS][ITEMS], accC[NS][ITEMS];  // this wave's rows' dB/dC for the chunk, summed in registers
+    // The 16 states are walked in groups of STG: the dB/dC register tile is [STG][ITEMS] x 2 instead of [16][ITEMS] x 2 and
+    // only STG states are in flight, which is what lets two waves share a SIMD (<= 256 VGPR, no AGPR shuttling, no scratch).
+    // The per-row d(delta)/du partial sums travel between groups through the gu / gdelta output buffers (same lane, same
+    // address: program order is enough); the row's own inputs (u, gy, delta) are simply re-read / re-projected per group.
+#pragma unroll 1
+    for (int sg = 0; sg < NS / STG; ++sg) {
+      const int n0 = sg * STG;
+      const bool first = sg == 0, last = sg == NS / STG - 1;
+      float accB[STG][ITEMS], accC[STG][ITEMS];  // this wave's rows' dB/dC for the chunk and state group, summed in registers
 #pragma unroll
-    for (int n = 0; n < NS; ++n)
+      for (int j = 0; j < STG; ++j)
 #pragma unroll
-      for (int i = 0; i < ITEMS; ++i) { accB[n][i] = 0.f; accC[n][i] = 0.f; }
+        for (int i = 0; i < ITEMS; ++i) { accB[j][i] = 0.f; accC[j][i] = 0.f; }
 
 #pragma unroll 1
-    for (int r = 0; r < BWD_RPW; ++r) {  // a real loop: the state loop inside is fully unrolled (register tiles accB/accC)
-      const int d = d0 + r;
-      if (d < Dk) {  // wave-uniform
-        const int kd = k * Dk + d;
-        const size_t row = (size_t)(bk / K) * K * Dk + kd;
-        const float Dd = Dv[kd], bias = dbias[kd];
-        const float* An = s_A[wave][r];
-        float* carry = s_carry[wave][r];
-        float uu[ITEMS], dl[ITEMS], dt[ITEMS], g[ITEMS], ddt[ITEMS], du[ITEMS], dtu[ITEMS];
-        float dD = 0.f, dbs = 0.f;
-        const float* up = xmode ? u + (((size_t)(bk / K) * 2 + (k & 1)) * Dk + d) * L : u + row * L;
-        load4<VEC>(up, t, L, uu, 0.f, rev);
-        const float* Wr = s_W + (wave * BWD_RPW + r) * RMAX;
-        if (dtr) {
-          dl[0] = dl[1] = dl[2] = dl[3] = 0.f;
-          for (int q = 0; q < R; ++q) {
-            const float w = Wr[q];
-            const float4 f = *reinterpret_cast<const float4*>(&s_dtr[q][lane * ITEMS]);
-            dl[0] = fmaf(w, f.x, dl[0]); dl[1] = fmaf(w, f.y, dl[1]); dl[2] = fmaf(w, f.z, dl[2]); dl[3] = fmaf(w, f.w, dl[3]);
+      for (int r = 0; r < BWD_RPW; ++r) {
+        const int d = d0 + r;
+        if (d < Dk) {  // wave-uniform
+          const int kd = k * Dk + d;
+          const size_t row = (size_t)(bk / K) * K * Dk + kd;
+          const float Dd = Dv[kd], bias = dbias[kd];
+          const float* An = s_A[wave][r];
+          float* carry = s_carry[wave][r];
+          float uu[ITEMS], dl[ITEMS], dt[ITEMS], g[ITEMS], ddt[ITEMS], du[ITEMS], dtu[ITEMS];
+          const float* up = xmode ? u + (((size_t)(bk / K) * 2 + (k & 1)) * Dk + d) * L : u + row * L;
+          load4<VEC>(up, t, L, uu, 0.f, rev);
+          const float* Wr = s_W + (wave * BWD_RPW + r) * RMAX;
+          if (dtr) {
+            dl[0] = dl[1] = dl[2] = dl[3] = 0.f;
+            for (int q = 0; q < R; ++q) {
+              const float w = Wr[q];
+              const float4 f = *reinterpret_cast<const float4*>(&s_dtr[q][lane * ITEMS]);
+              dl[0] = fmaf(w, f.x, dl[0]); dl[1] = fmaf(w, f.y, dl[1]); dl[2] = fmaf(w, f.z, dl[2]); dl[3] = fmaf(w, f.w, dl[3]);
+            }
+          } else {
+            load4<VEC>(delta + row * L, t, L, dl, 0.f, rev);
           }
-        } else {
-          load4<VEC>(delta + row * L, t, L, dl, 0.f, rev);
-        }
-        load4<VEC>(gy + row * L, t, L, g, 0.f, rev);
+          load4<VEC>(gy + row * L, t, L, g, 0.f, rev);
+          if (first) {
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-          dt[i] = (t + i < L) ? softplus_f(dl[i] + bias) : 0.f;
-          dtu[i] = dt[i] * uu[i];
-          ddt[i] = 0.f;
-          du[i] = Dd * g[i];
-          dD = fmaf(g[i], uu[i], dD);
-        }
-        const float* hs = hstate + (row * nchunk + (c > 0 ? c - 1 : 0)) * NS;
-#pragma unroll
-        for (int n = 0; n < NS; ++n) {
-          const float4 b4 = *reinterpret_cast<const float4*>(&sB[n][lane * ITEMS]);
-          const float4 c4 = *reinterpret_cast<const float4*>(&sC[n][lane * ITEMS]);
-          const float bb[ITEMS] = {b4.x, b4.y, b4.z, b4.w}, cc[ITEMS] = {c4.x, c4.y, c4.z, c4.w};
-          float a[ITEMS], hh[ITEMS], bu[ITEMS], cg[ITEMS];
-          const float An_n = An[n];
-          const float A2 = An_n * LOG2E;
-          // ---- recompute h inside the chunk (same arithmetic as the forward)
-          float A = 1.f, Bv = 0.f;
+            for (int i = 0; i < ITEMS; ++i) { ddt[i] = 0.f; du[i] = Dd * g[i]; }
+          } else {  // partial sums left by the previous state group
+            load4<VEC>(gu + row * L, t, L, du, 0.f, rev);
+            load4<VEC>(gdelta + row * L, t, L, ddt, 0.f, rev);
+          }
 #pragma unroll
           for (int i = 0; i < ITEMS; ++i) {
-            a[i] = __builtin_amdgcn_exp2f(dt[i] * A2);
-            bu[i] = dtu[i] * bb[i];
-            cg[i] = cc[i] * g[i];
-            Bv = fmaf(a[i], Bv, bu[i]);
-            A *= a[i];
+            dt[i] = (t + i < L) ? softplus_f(dl[i] + bias) : 0.f;
+            dtu[i] = dt[i] * uu[i];
           }
-          wave_scan_prefix(A, Bv);
-          const float EA = prev_lane(1.f, A), EB = prev_lane(0.f, Bv);
-          const float h0 = (c == 0) ? 0.f : hs[n];
-          const float hin = fmaf(EA, h0, EB);  // h_{t-1} of this lane's first step
-          float hp = hin;
+          const float* hs = hstate + (row * nchunk + (c > 0 ? c - 1 : 0)) * NS + n0;
 #pragma unroll
-          for (int i = 0; i < ITEMS; ++i) { hp = fmaf(a[i], hp, bu[i]); hh[i] = hp; }
-          // ---- dL/dh suffix scan:  gh_i = cc_i*g_i + a_{i+1} * gh_{i+1}
-          // a of the next lane's first step; the chunk's last step takes `carry` (= a*gh of the next chunk) with factor 1
-          float al[ITEMS];
+          for (int j = 0; j < STG; ++j) {
+            const int n = n0 + j;
+            const float4 b4 = *reinterpret_cast<const float4*>(&sB[n][lane * ITEMS]);
+            const float4 c4 = *reinterpret_cast<const float4*>(&sC[n][lane * ITEMS]);
+            const float bb[ITEMS] = {b4.x, b4.y, b4.z, b4.w}, cc[ITEMS] = {c4.x, c4.y, c4.z, c4.w};
+            float a[ITEMS], hh[ITEMS], bu[ITEMS], cg[ITEMS];
+            const float An_n = An[n];
+            const float A2 = An_n * LOG2E;
+            // ---- recompute h inside the chunk (same arithmetic as the forward)
+            float A = 1.f, Bv = 0.f;
 #pragma unroll
-          for (int i = 0; i < ITEMS - 1; ++i) al[i] = a[i + 1];
-          al[ITEMS - 1] = next_lane(1.f, a[0]);
-          float SA = 1.f, SB = 0.f;
+            for (int i = 0; i < ITEMS; ++i) {
+              a[i] = __builtin_amdgcn_exp2f(dt[i] * A2);
+              bu[i] = dtu[i] * bb[i];
+              cg[i] = cc[i] * g[i];
+              Bv = fmaf(a[i], Bv, bu[i]);
+              A *= a[i];
+            }
+            wave_scan_prefix(A, Bv);
+            const float EA = prev_lane(1.f, A), EB = prev_lane(0.f, Bv);
+            const float h0 = (c == 0) ? 0.f : hs[j];
+            const float hin = fmaf(EA, h0, EB);  // h_{t-1} of this lane's first step
+            float hp = hin;
 #pragma unroll
-          for (int i = ITEMS - 1; i >= 0; --i) { SB = fmaf(al[i], SB, cg[i]); SA *= al[i]; }
-          wave_scan_suffix(SA, SB, addr1, addr2);
-          const float XA = next_lane(1.f, SA), XB = next_lane(0.f, SB);
-          float gh = fmaf(XA, carry[n], XB);  // gh of the step right after this lane's last one (already times its a)
-          float dA_n = 0.f;
+            for (int i = 0; i < ITEMS; ++i) { hp = fmaf(a[i], hp, bu[i]); hh[i] = hp; }
+            // ---- dL/dh suffix scan:  gh_i = cc_i*g_i + a_{i+1} * gh_{i+1}
+            // a of the next lane's first step; the chunk's last step takes `carry` (= a*gh of the next chunk) with factor 1
+            float al[ITEMS];
 #pragma unroll
-          for (int i = ITEMS - 1; i >= 0; --i) {
-            gh = fmaf(al[i], gh, cg[i]);  // dL/dh_t
-            const float hprev = (i == 0) ? hin : hh[i - 1];
-            const float da = gh * hprev * a[i];  // dL/d(dt*A) through a = exp(dt*A)
-            dA_n = fmaf(da, dt[i], dA_n);
-            ddt[i] = fmaf(da, An_n, ddt[i]);
-            ddt[i] = fmaf(gh * uu[i], bb[i], ddt[i]);
-            du[i] = fmaf(gh * dt[i], bb[i], du[i]);
-            accB[n][i] = fmaf(gh, dtu[i], accB[n][i]);
-            accC[n][i] = fmaf(g[i], hh[i], accC[n][i]);
+            for (int i = 0; i < ITEMS - 1; ++i) al[i] = a[i + 1];
+            al[ITEMS - 1] = next_lane(1.f, a[0]);
+            float SA = 1.f, SB = 0.f;
+#pragma unroll
+            for (int i = ITEMS - 1; i >= 0; --i) { SB = fmaf(al[i], SB, cg[i]); SA *= al[i]; }
+            wave_scan_suffix(SA, SB, addr1, addr2);
+            const float XA = next_lane(1.f, SA), XB = next_lane(0.f, SB);
+            float gh = fmaf(XA, carry[n], XB);  // gh of the step right after this lane's last one (already times its a)
+            float dA_n = 0.f;
+#pragma unroll
+            for (int i = ITEMS - 1; i >= 0; --i) {
+              gh = fmaf(al[i], gh, cg[i]);  // dL/dh_t
+              const float hprev = (i == 0) ? hin : hh[i - 1];
+              const float da = gh * hprev * a[i];  // dL/d(dt*A) through a = exp(dt*A)
+              dA_n = fmaf(da, dt[i], dA_n);
+              ddt[i] = fmaf(da, An_n, ddt[i]);
+              ddt[i] = fmaf(gh * uu[i], bb[i], ddt[i]);
+              du[i] = fmaf(gh * dt[i], bb[i], du[i]);
+              accB[j][i] = fmaf(gh, dtu[i], accB[j][i]);
+              accC[j][i] = fmaf(g[i], hh[i], accC[j][i]);
+            }
+            if (lane == 0) carry[n] = a[0] * gh;  // a_t * gh_t of this chunk's first step, for the previous chunk
+            dA_n = wave_sum_dpp(dA_n);
+            if (lane == WAVE - 1) s_dA[wave][r][n] += dA_n;
           }
-          if (lane == 0) carry[n] = a[0] * gh;  // a_t * gh_t of this chunk's first step, for the previous chunk
-          dA_n = wave_sum_dpp(dA_n);
-          if (lane == WAVE - 1) s_dA[wave][r][n] += dA_n;
-        }
-        float gd[ITEMS];
+          if (!last) {
+            store4<VEC>(gu + row * L, t, L, du, rev);
+            store4<VEC>(gdelta + row * L, t, L, ddt, rev);
+          } else {
+            float gd[ITEMS];
+            float dD = 0.f, dbs = 0.f;
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-          gd[i] = (t + i < L) ? ddt[i] * sigmoid_f(dl[i] + bias) : 0.f;
-          dbs += gd[i];
-        }
-        dD = wave_sum_dpp(dD);
-        dbs = wave_sum_dpp(dbs);
-        if (lane == WAVE - 1) { s_dD[wave][r] += dD; s_db[wave][r] += dbs; }
-        if (dtr) {  // gWdt[kd, q] += sum_t gdelta_t * dtr[q, t]
-          float* gWr = s_gW + (wave * BWD_RPW + r) * RMAX;
-          for (int q = 0; q < R; ++q) {
-            const float4 f = *reinterpret_cast<const float4*>(&s_dtr[q][lane * ITEMS]);
-            const float p = wave_sum_dpp(fmaf(gd[0], f.x, fmaf(gd[1], f.y, fmaf(gd[2], f.z, gd[3] * f.w))));
-            if (lane == WAVE - 1) gWr[q] += p;
+            for (int i = 0; i < ITEMS; ++i) {
+              gd[i] = (t + i < L) ? ddt[i] * sigmoid_f(dl[i] + bias) : 0.f;
+              dbs += gd[i];
+              dD = fmaf(g[i], uu[i], dD);
+            }
+            dD = wave_sum_dpp(dD);
+            dbs = wave_sum_dpp(dbs);
+            if (lane == WAVE - 1) { s_dD[wave][r] += dD; s_db[wave][r] += dbs; }
+            if (dtr) {  // gWdt[kd, q] += sum_t gdelta_t * dtr[q, t]
+              float* gWr = s_gW + (wave * BWD_RPW + r) * RMAX;
+              for (int q = 0; q < R; ++q) {
+                const float4 f = *reinterpret_cast<const float4*>(&s_dtr[q][lane * ITEMS]);
+                const float p = wave_sum_dpp(fmaf(gd[0], f.x, fmaf(gd[1], f.y, fmaf(gd[2], f.z, gd[3] * f.w))));
+                if (lane == WAVE - 1) gWr[q] += p;
+              }
+            }
+            store4<VEC>(gu + row * L, t, L, du, rev);  // gu is always [B, K*Dk, L]; the host folds direction pairs in xmode
+            store4<VEC>(gdelta + row * L, t, L, gd, rev);
           }
         }
-        store4<VEC>(gu + row * L, t, L, du, rev);  // gu is always [B, K*Dk, L]; the host folds direction pairs in xmode
-        store4<VEC>(gdelta + row * L, t, L, gd, rev);
       }
-    }
-    // ---- fold the BWD_WAVES register tiles into one LDS tile, one wave at a time (plain LDS traffic, no atomics)
-    __syncthreads();  // the tile aliases the B/C tiles: every wave must be past its last read of them
-#pragma unroll 1
-    for (int w = 0; w < BWD_WAVES; ++w) {
-      if (wave == w) {
-#pragma unroll
-        for (int n = 0; n < NS; ++n) {
-          float4* pb = reinterpret_cast<float4*>(&s_dB[n][lane * ITEMS]);
-          float4* pc = reinterpret_cast<float4*>(&s_dC[n][lane * ITEMS]);
-          float4 vb = make_float4(accB[n][0], accB[n][1], accB[n][2], accB[n][3]);
-          float4 vc = make_float4(accC[n][0], accC[n][1], accC[n][2], accC[n][3]);
-          if (w > 0) {
-            const float4 ob = *pb, oc = *pc;
-            vb.x += ob.x; vb.y += ob.y; vb.z += ob.z; vb.w += ob.w;
-            vc.x += oc.x; vc.y += oc.y; vc.z += oc.z; vc.w += oc.w;
-          }
-          *pb = vb;
-          *pc = vc;
-        }
-      }
+      // ---- fold the BWD_WAVES register tiles of this state group into the LDS tile, one wave at a time (plain LDS traffic, no
+      // atomics).  The tile aliases the B/C tiles: rows [n0, n0 + STG) of both are dead once every wave is past this group.
       __syncthreads();
+#pragma unroll 1
+      for (int w = 0; w < BWD_WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+          for (int j = 0; j < STG; ++j) {
+            float4* pb = reinterpret_cast<float4*>(&s_dB[n0 + j][lane * ITEMS]);
+            float4* pc = reinterpret_cast<float4*>(&s_dC[n0 + j][lane * ITEMS]);
+            float4 vb = make_float4(accB[j][0], accB[j][1], accB[j][2], accB[j][3]);
+            float4 vc = make_float4(accC[j][0], accC[j][1], accC[j][2], accC[j][3]);
+            if (w > 0) {
+              const float4 ob = *pb, oc = *pc;
+              vb.x += ob.x; vb.y += ob.y; vb.z += ob.z; vb.w += ob.w;
+              vc.x += oc.x; vc.y += oc.y; vc.z += oc.z; vc.w += oc.w;
+            }
+            *pb = vb;
+            *pc = vc;
+          }
+        }
+        __syncthreads();
+      }
     }
     // ---- plain, coalesced stores of this workgroup's partial dB/dC tile into its slab
     if (VEC) {
@@ -634,12 +667,16 @@ static int scan_bwd_launch(const float* gy, const float* u, const float* delta, 
   dim3 grid(nslab, B * K);
   hipStream_t s = (hipStream_t)stream;
   const size_t dyn = dtr ? ((size_t)R * CHUNK + 2 * BWD_ROWS * RMAX) * sizeof(float) : 0;
-  if (L % 4 == 0)
-    hipLaunchKernelGGL(selscan_bwd_kernel<true>, grid, dim3(BWD_WAVES * WAVE), dyn, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu,
-                       gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab, xmode, dtr, Wdt, gWdt, R);
-  else
-    hipLaunchKernelGGL(selscan_bwd_kernel<false>, grid, dim3(BWD_WAVES * WAVE), dyn, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu,
-                       gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab, xmode, dtr, Wdt, gWdt, R);
+#define LAUNCH_BWD(VEC, STG)                                                                                                   \
+  hipLaunchKernelGGL((selscan_bwd_kernel<VEC, STG>), grid, dim3(BWD_WAVES * WAVE), dyn, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, \
+                     gu, gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab, xmode, dtr, Wdt, gWdt, R)
+  const bool big_r = dtr && R > 16;
+  if (L % 4 == 0) {
+    if (big_r) LAUNCH_BWD(true, SCAN_BWD_STG_BIGR); else LAUNCH_BWD(true, SCAN_BWD_STG_SMALLR);
+  } else {
+    if (big_r) LAUNCH_BWD(false, SCAN_BWD_STG_BIGR); else LAUNCH_BWD(false, SCAN_BWD_STG_SMALLR);
+  }
+#undef LAUNCH_BWD
   if (dtr && L % 4) {
     hipLaunchKernelGGL(dtproj_gdtr_scalar_kernel, dim3((L + 255) / 256, B * K), dim3(256), 0, s, gdelta, Wdt, gdtr, K, Dk, R, L);
   } else if (dtr) {  // gdtr = Wdt^T gdelta (position space, un-reversed)

@@ -366,3 +366,35 @@ def lsap_assign(cost, gt_groups):
         call('tamtr_lsap_assign', ptr(cost), ctypes.cast(sizes, ctypes.c_void_p), bs, nq, G, ptr(out[0]), ptr(out[1]), ptr(out[2]),
              stream_ptr())
     return out[0], out[1], out[2]
+
+
+class _CPAM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        require_gpu(x)
+        x = _c(x)
+        B, C, H, W = x.shape
+        p, idx = torch.nn.functional.max_pool2d(x, 3, 2, 1, return_indices=True)  # ChannelAttentionModule.Maxpool (block.py:274)
+        out = torch.empty_like(x)
+        s2 = torch.empty(B, 8, H, W, device=x.device, dtype=torch.float32)
+        arg = torch.empty(B, 8, H, W, device=x.device, dtype=torch.int32)
+        call('tamtr_cpam_fwd', ptr(x), ptr(p), ptr(out), ptr(s2), ptr(arg), B, C, H, W, dtype_code(x), stream_ptr())
+        ctx.save_for_backward(x, p, idx, s2, arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, p, idx, s2, arg = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gout = _c(gout.to(x.dtype))
+        dxd, du, dp = torch.empty_like(x), torch.empty_like(x), torch.empty_like(p)
+        call('tamtr_cpam_bwd', ptr(gout), ptr(x), ptr(p), ptr(s2), ptr(arg), ptr(dxd), ptr(du), ptr(dp), B, C, H, W, dtype_code(x),
+             stream_ptr())
+        dx = torch.ops.aten.max_pool2d_with_indices_backward(dp, x, [3, 3], [2, 2], [1, 1], [1, 1], False, idx)
+        return dx.add_(dxd)
+
+
+def cpam(x):
+    """CPAM (extra_modules/block.py:271-308): x [B,C,H,W] fp32/bf16 -> channel gate sigmoid(up2(maxpool3s2(x))) * x followed by
+    the per-chunk (8 chunks) spatial gate sigmoid(max over the chunk's channels).  One fused kernel after the pool."""
+    return _CPAM.apply(x)

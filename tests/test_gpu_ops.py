@@ -200,3 +200,50 @@ def test_lsap_assign_argument_checks(ops):
         ops.lsap_assign(torch.zeros(2, 10, 5), [2, 3])                 # CPU tensor: no fallback
     bi, si, gi = ops.lsap_assign(torch.zeros(3, 10, 0).cuda(), [0, 0, 0])
     assert bi.numel() == si.numel() == gi.numel() == 0
+
+
+@pytest.mark.parametrize('B,C,H,W', [(2, 64, 12, 16), (1, 128, 6, 6), (2, 16, 2, 2), (1, 256, 10, 4), (1, 8, 14, 30)])
+def test_cpam_vs_oracle(ops, B, C, H, W):
+    """Fused CPAM gates vs the oracle's restatement of extra_modules/block.py:271-308 (forward and dx), fp32."""
+    x = rnd((B, C, H, W), 5) * 2
+    cot = rnd((B, C, H, W), 6)
+    xr = x.clone().requires_grad_()
+    ref = O.cpam(xr)
+    (ref * cot).sum().backward()
+    xd = dev(x).requires_grad_()
+    out = ops.cpam(xd)
+    (out * dev(cot)).sum().backward()
+    assert_close(out, ref, 1e-5, 1e-6, 'cpam out')
+    assert_close(xd.grad, xr.grad, 1e-4, 1e-5, 'cpam dx')
+
+
+def test_cpam_bf16_and_argument_checks(ops):
+    import tamtr_amd
+    x = rnd((2, 128, 16, 16), 7)
+    cot = rnd((2, 128, 16, 16), 8)
+    xr = x.bfloat16().float().requires_grad_()
+    ref = O.cpam(xr)
+    (ref * cot.bfloat16().float()).sum().backward()
+    xd = dev(x, torch.bfloat16).requires_grad_()
+    out = ops.cpam(xd)
+    (out * dev(cot, torch.bfloat16)).sum().backward()
+    assert out.dtype == torch.bfloat16
+    # bf16 storage of out / p / du (8 mantissa bits), fp32 arithmetic inside
+    assert_close(out.float(), ref, 1e-2, 1e-2, 'cpam bf16 out')
+    assert_close(xd.grad.float(), xr.grad, 3e-2, 3e-2, 'cpam bf16 dx')
+    with pytest.raises(tamtr_amd.TamtrHipError):
+        ops.cpam(torch.zeros(1, 16, 5, 4).cuda())      # odd height: the reference fails on it too
+    with pytest.raises(tamtr_amd.TamtrHipError):
+        ops.cpam(torch.zeros(1, 12, 4, 4).cuda())      # channels not divisible into 8 chunks
+    with pytest.raises(tamtr_amd.TamtrHipError):
+        ops.cpam(torch.zeros(1, 16, 4, 4))             # CPU tensor
+
+
+def test_cpam_full_size_properties(ops):
+    """BASELINE-size site (bs 16, 128 x 160 x 160, bf16): output bounded by |x| (two sigmoid gates), equals the fp32 kernel."""
+    g = torch.Generator(device='cuda').manual_seed(0)
+    x = torch.randn(16, 128, 160, 160, device='cuda', generator=g)
+    o32 = ops.cpam(x)
+    o16 = ops.cpam(x.bfloat16())
+    assert bool((o32.abs() <= x.abs() + 1e-6).all())
+    assert float((o16.float() - o32).abs().max()) < 0.05
