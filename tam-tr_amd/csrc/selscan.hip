@@ -37,11 +37,8 @@ constexpr float LOG2E = 1.4426950408889634f;
 //   STG 2 (149 VGPR)                    26.4 / 14.5 / 10.0       STG 16, 1 wave/SIMD (501 VGPR+AGPR, 636 v_accvgpr moves)  - / - / 8.7
 // (STG 16 is the single-group kernel of the first version: 39.5 ms per training step over the three levels, now 36.6.)
 // Small groups repeat the row's delta projection (R FMAs x 4 per group); large ones spill the tile to AGPRs / scratch.
-#ifndef SCAN_BWD_STG_SMALLR
-#define SCAN_BWD_STG_SMALLR 4
-#endif
-#ifndef SCAN_BWD_STG_BIGR
-#define SCAN_BWD_STG_BIGR 4
+#ifndef SCAN_BWD_STG
+#define SCAN_BWD_STG 4
 #endif
 
 // softplus with torch's threshold (20); log(1+e^x) through the hardware exp2/log2 (abs err ~1e-7, the e^x branch keeps
@@ -116,6 +113,9 @@ __device__ __forceinline__ float next_lane(float old, float v) { return dpp<0x13
 // previous row" DPP mode).  addr1/addr2: byte addresses of those lanes, or -1 when the row does not exist.
 __device__ __forceinline__ void wave_scan_suffix(float& A, float& Bv, int addr1, int addr2) {
   SCAN_STEP(0x101, 0xf) SCAN_STEP(0x102, 0xf) SCAN_STEP(0x104, 0xf) SCAN_STEP(0x108, 0xf)
+#ifdef SCAN_ABL_NO_BPERMUTE
+  return;
+#endif
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int ad = s ? addr2 : addr1;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
     const float* __restrict__ hstate, float* __restrict__ gu, float* __restrict__ gdelta, float* __restrict__ gA,
     float* __restrict__ wsB, float* __restrict__ wsC, float* __restrict__ gD, float* __restrict__ gdbias, int K, int Dk, int L,
     int nchunk, size_t slab_elems, int xmode, const float* __restrict__ dtr, const float* __restrict__ Wdt, float* __restrict__ gWdt,
-    int R) {
+    int R, int h0_staged) {
   __shared__ float sB[NS][CHUNK];
   __shared__ float sC[NS][CHUNK];
   // the dB/dC fold tile aliases the B/C tiles: they are dead once the chunk's rows are done (keeps LDS at 2 workgroups per CU)
@@ -304,6 +304,9 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
   float(*s_dtr)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(s_dyn);
   float* s_W = s_dyn + (size_t)R * CHUNK;
   float* s_gW = s_W + BWD_ROWS * RMAX;
+  // states entering the chunk, [BWD_ROWS][NS] (wave-private rows; fetched while the tiles are staged).  Only when the
+  // launcher found room for it next to the rank-R tiles: 2 workgroups per CU matter more (rank 32 runs without it)
+  float* s_h0 = h0_staged ? s_dyn + (dtr ? (size_t)R * CHUNK + 2 * BWD_ROWS * RMAX : 0) : nullptr;
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
   const int bk = blockIdx.y, k = bk % K;
   const float* Bp = Bm + (size_t)bk * NS * L;
@@ -326,6 +329,16 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
 
   for (int c = nchunk - 1; c >= 0; --c) {
     __syncthreads();  // previous chunk's tiles fully consumed / flushed
+    // chunk-entry states of this wave's rows: 16 consecutive floats per row, requested now and consumed after the staging
+    // barrier (read per state as wave-uniform scalars they cost ~8 % of the kernel in s_waitcnt on HBM-missing s_loads)
+    if (h0_staged) {
+#pragma unroll
+      for (int rr = lane >> 4; rr < BWD_RPW; rr += WAVE / NS) {
+        const int d = min(d0 + rr, Dk - 1);
+        const size_t row = (size_t)(bk / K) * K * Dk + (size_t)k * Dk + d;
+        s_h0[((wave * BWD_RPW) + rr) * NS + (lane & (NS - 1))] = c > 0 ? hstate[(row * nchunk + (c - 1)) * NS + (lane & (NS - 1))] : 0.f;
+      }
+    }
     stage_bc<BWD_WAVES * WAVE>(Bp, Cp, c * CHUNK, L, sB, sC, VEC, rev);
     if (dtr) stage_dtr<BWD_WAVES * WAVE>(Rp, R, c * CHUNK, L, s_dtr, VEC, rev);
     __syncthreads();
@@ -380,7 +393,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
             dt[i] = (t + i < L) ? softplus_f(dl[i] + bias) : 0.f;
             dtu[i] = dt[i] * uu[i];
           }
-          const float* hs = hstate + (row * nchunk + (c > 0 ? c - 1 : 0)) * NS + n0;
+          const float* hs = h0_staged ? s_h0 + (wave * BWD_RPW + r) * NS + n0 : hstate + (row * nchunk + (c > 0 ? c - 1 : 0)) * NS + n0;
 #pragma unroll
           for (int j = 0; j < STG; ++j) {
             const int n = n0 + j;
@@ -394,7 +407,11 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
             float A = 1.f, Bv = 0.f;
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
+#ifndef SCAN_ABL_NO_EXP
               a[i] = __builtin_amdgcn_exp2f(dt[i] * A2);
+#else
+              a[i] = fmaf(dt[i], A2, 1.f);
+#endif
               bu[i] = dtu[i] * bb[i];
               cg[i] = cc[i] * g[i];
               Bv = fmaf(a[i], Bv, bu[i]);
@@ -433,8 +450,12 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
               accC[j][i] = fmaf(g[i], hh[i], accC[j][i]);
             }
             if (lane == 0) carry[n] = a[0] * gh;  // a_t * gh_t of this chunk's first step, for the previous chunk
+#ifndef SCAN_ABL_NO_DA
             dA_n = wave_sum_dpp(dA_n);
             if (lane == WAVE - 1) s_dA[wave][r][n] += dA_n;
+#else
+            if (dA_n == 123.456f) s_dA[wave][r][n] += dA_n;
+#endif
           }
           if (!last) {
             store4<VEC>(gu + row * L, t, L, du, rev);
@@ -451,6 +472,9 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
             dD = wave_sum_dpp(dD);
             dbs = wave_sum_dpp(dbs);
             if (lane == WAVE - 1) { s_dD[wave][r] += dD; s_db[wave][r] += dbs; }
+#ifdef SCAN_ABL_NO_GW
+            if (false)
+#endif
             if (dtr) {  // gWdt[kd, q] += sum_t gdelta_t * dtr[q, t]
               float* gWr = s_gW + (wave * BWD_RPW + r) * RMAX;
               for (int q = 0; q < R; ++q) {
@@ -464,6 +488,10 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
           }
         }
       }
+#ifdef SCAN_ABL_NO_FOLD
+      if (accB[0][0] == 123.456f || accC[STG - 1][ITEMS - 1] == 123.456f) s_dD[wave][0] += accB[1][1] + accC[2][2];
+      continue;
+#endif
       // ---- fold the BWD_WAVES register tiles of this state group into the LDS tile, one wave at a time (plain LDS traffic, no
       // atomics).  The tile aliases the B/C tiles: rows [n0, n0 + STG) of both are dead once every wave is past this group.
       __syncthreads();
@@ -666,16 +694,16 @@ static int scan_bwd_launch(const float* gy, const float* u, const float* delta, 
   float* wsC = ws + (size_t)nslab * slab;
   dim3 grid(nslab, B * K);
   hipStream_t s = (hipStream_t)stream;
-  const size_t dyn = dtr ? ((size_t)R * CHUNK + 2 * BWD_ROWS * RMAX) * sizeof(float) : 0;
-#define LAUNCH_BWD(VEC, STG)                                                                                                   \
-  hipLaunchKernelGGL((selscan_bwd_kernel<VEC, STG>), grid, dim3(BWD_WAVES * WAVE), dyn, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, \
-                     gu, gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab, xmode, dtr, Wdt, gWdt, R)
-  const bool big_r = dtr && R > 16;
-  if (L % 4 == 0) {
-    if (big_r) LAUNCH_BWD(true, SCAN_BWD_STG_BIGR); else LAUNCH_BWD(true, SCAN_BWD_STG_SMALLR);
-  } else {
-    if (big_r) LAUNCH_BWD(false, SCAN_BWD_STG_BIGR); else LAUNCH_BWD(false, SCAN_BWD_STG_SMALLR);
-  }
+  size_t dyn = dtr ? ((size_t)R * CHUNK + 2 * BWD_ROWS * RMAX) * sizeof(float) : 0;
+  // static LDS of the kernel: B/C tiles + per-row state (A, carry, dA, dD, db); two workgroups per CU need <= 80 KB each
+  const size_t stat = (size_t)(2 * NS * CHUNK + 3 * BWD_ROWS * NS + 2 * BWD_ROWS) * sizeof(float);
+  const size_t h0_bytes = (size_t)BWD_ROWS * NS * sizeof(float);
+  const int h0_staged = stat + dyn + h0_bytes <= 80 * 1024;
+  if (h0_staged) dyn += h0_bytes;
+#define LAUNCH_BWD(VEC)                                                                                                              \
+  hipLaunchKernelGGL((selscan_bwd_kernel<VEC, SCAN_BWD_STG>), grid, dim3(BWD_WAVES * WAVE), dyn, s, gy, u, delta, A, Bm, Cm, D, dbias, \
+                     hstate, gu, gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab, xmode, dtr, Wdt, gWdt, R, h0_staged)
+  if (L % 4 == 0) LAUNCH_BWD(true); else LAUNCH_BWD(false);
 #undef LAUNCH_BWD
   if (dtr && L % 4) {
     hipLaunchKernelGGL(dtproj_gdtr_scalar_kernel, dim3((L + 255) / 256, B * K), dim3(256), 0, s, gdelta, Wdt, gdtr, K, Dk, R, L);

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from .backbone import batchnorm
+from . import ops
 from .loss import get_cdn_group
 from .modules import ContrastiveHeadMLP, DeformableTransformerDecoderLayer, MLP, TextDeformableTransformerDecoder
 from .vss import VSSBlock
@@ -88,7 +89,10 @@ class ManbaWorldDecoder(nn.Module):
     def _get_decoder_input(self, feats, shapes, dn_embed=None, dn_bbox=None, text=None):
         bs = feats.shape[0]
         anchors, valid = self._generate_anchors(shapes, dtype=torch.float32, device=feats.device)
-        memory = self.enc_output(valid.to(feats.dtype) * feats)
+        x = valid.to(feats.dtype) * feats
+        lin, norm = self.enc_output[0], self.enc_output[1]
+        # same [B*L, 512] x [512, 512] contraction as the value projection: bf16 activations take the MFMA kernel
+        memory = norm(ops.linear_bf16(x, lin.weight, lin.bias) if x.dtype == torch.bfloat16 else lin(x))
         scores = self.enc_score_head(memory)
         top = torch.topk(scores.max(-1).values, self.num_queries, dim=1).indices
         bi = torch.arange(bs, device=feats.device).unsqueeze(-1)

@@ -149,8 +149,8 @@ def contrastive_logits(x, w, logit_scale, bias):
 
 # ------------------------------------------------------------------------------------------------ a-5 value projection
 class _LinearBF16(torch.autograd.Function):
-    """Y = X W^T + b on the hand-written MFMA kernel (bf16 in/out, fp32 accumulate).  Backward = two plain library
-    GEMMs (dX = dY W, dW = dY^T X: rocBLAS/hipBLASLt through torch), which is what the tier rules reserve libraries for."""
+    """Y = X W^T + b on the hand-written MFMA kernel (bf16 in/out, fp32 accumulate).  Backward: dX = dY W on the same kernel
+    (against W^T); dW = dY^T X (a reduction over the M = B*L rows) is a plain library GEMM through torch."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -180,7 +180,15 @@ class _LinearBF16(torch.autograd.Function):
         x2, w16 = ctx.saved_tensors
         xshape, w_dt, b_dt = ctx.cfg
         g2 = _c(gy.reshape(-1, gy.shape[-1]).to(torch.bfloat16))
-        gx = (g2 @ w16).view(xshape) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            N, K = w16.shape
+            if K % 128 == 0 and N % 64 == 0:  # dX = dY W is the same "NT" GEMM against W^T (a 0.5 MB transpose): same MFMA kernel
+                gx = torch.empty(g2.shape[0], K, device=g2.device, dtype=torch.bfloat16)
+                call('tamtr_linear_bf16', ptr(g2), ptr(_c(w16.t())), None, ptr(gx), g2.shape[0], K, N, stream_ptr())
+                gx = gx.view(xshape)
+            else:
+                gx = (g2 @ w16).view(xshape)
         gw = (g2.t() @ x2).to(w_dt) if ctx.needs_input_grad[1] else None
         gb = g2.float().sum(0).to(b_dt) if (b_dt is not None and ctx.needs_input_grad[2]) else None
         return gx, gw, gb

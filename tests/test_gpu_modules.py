@@ -166,9 +166,11 @@ def test_linear_bf16_kernel(pkg, M, N, K):
     y = pkg.ops.linear_bf16(xd, wd, bd)
     assert y.dtype == torch.bfloat16 and y.shape == (M, N)
     assert_close(y.float(), ref, 2 ** -8, 1e-3, 'linear_bf16')
-    y.float().sum().backward()
-    assert_close(bd.grad, torch.full((N,), float(M)), 1e-6, 1e-6, 'bias grad')
-    assert_close(xd.grad.float(), w.float().sum(0).expand(M, K), 2e-2, 2e-2, 'x grad')
+    cot = rnd((M, N), 4).bfloat16()
+    (y.float() * dev(cot).float()).sum().backward()
+    assert_close(bd.grad, cot.float().sum(0), 1e-5, 1e-4, 'bias grad')
+    assert_close(xd.grad.float(), cot.float() @ w.float(), 2e-2, 2e-2, 'x grad')  # dX = dY W (MFMA kernel against W^T when K % 128 == 0)
+    assert_close(wd.grad, cot.float().t() @ x.float(), 2e-2, 2e-2 * M ** 0.5, 'w grad')
     # asymmetric-operand check of the fragment layout: X = I picks out W^T exactly
     eye = torch.eye(K).bfloat16()
     yi = pkg.ops.linear_bf16(dev(eye), dev(w).float(), None)
