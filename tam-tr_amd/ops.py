@@ -148,9 +148,70 @@ def contrastive_logits(x, w, logit_scale, bias):
 
 
 # ------------------------------------------------------------------------------------------------ a-5 value projection
+def _split_count(M, min_rows=2048, max_split=64):
+    S = 1
+    while S < max_split and M % (2 * S) == 0 and M // (2 * S) >= min_rows:
+        S *= 2
+    return S
+
+
+_BMM_F32_OUT = None  # does this torch build take bmm(..., out_dtype=float32) on the GPU?
+
+
+def dw_splitk(g2, x2):
+    """dW [N, K] = g2^T x2 for very tall operands (M = B*L rows >> N, K), fp32 result.
+    A single M-reduction GEMM of this shape has only (N/64)*(K/128) = 8..32 output tiles: hipBLASLt ran it on that many
+    workgroups (945 us for M = 537 600, N = K = 512: 0.3 PF/s).  Sliced into S row blocks it is ONE batched GEMM with S x
+    the tiles, and the S partial products are summed in fp32."""
+    M, N = g2.shape
+    K = x2.shape[1]
+    S = _split_count(M)
+    if S == 1:
+        return (g2.t() @ x2).float()
+    a, b = g2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, K)
+    global _BMM_F32_OUT
+    if _BMM_F32_OUT is not False:
+        try:
+            out = torch.bmm(a, b, out_dtype=torch.float32)
+            _BMM_F32_OUT = True
+            return out.sum(0)
+        except (NotImplementedError, RuntimeError, TypeError):
+            if _BMM_F32_OUT:
+                raise
+            _BMM_F32_OUT = False
+    return torch.bmm(a, b).float().sum(0)
+
+
+class _LinearSplitK(torch.autograd.Function):
+    """y = x W^T + b through the library GEMM (forward and dX); dW through dw_splitk.  For the tall-skinny linears of the
+    VSS blocks (in_proj / out_proj / fc1 / fc2: M = B*H*W rows, 128..2048 features)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        w16 = weight.to(x.dtype)
+        ctx.save_for_backward(x, w16)
+        ctx.cfg = (weight.dtype, None if bias is None else bias.dtype)
+        return torch.nn.functional.linear(x, w16, None if bias is None else bias.to(x.dtype))
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w16 = ctx.saved_tensors
+        w_dt, b_dt = ctx.cfg
+        g2 = _c(gy.reshape(-1, gy.shape[-1]).to(x.dtype))
+        x2 = _c(x.reshape(-1, x.shape[-1]))
+        gx = (g2 @ w16).view(x.shape) if ctx.needs_input_grad[0] else None
+        gw = dw_splitk(g2, x2).to(w_dt) if ctx.needs_input_grad[1] else None
+        gb = g2.float().sum(0).to(b_dt) if (b_dt is not None and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb
+
+
+def linear_splitk(x, weight, bias=None):
+    return _LinearSplitK.apply(x, weight, bias)
+
+
 class _LinearBF16(torch.autograd.Function):
     """Y = X W^T + b on the hand-written MFMA kernel (bf16 in/out, fp32 accumulate).  Backward: dX = dY W on the same kernel
-    (against W^T); dW = dY^T X (a reduction over the M = B*L rows) is a plain library GEMM through torch."""
+    (against W^T); dW = dY^T X (a reduction over the M = B*L rows) is a batched library GEMM over row slices (dw_splitk)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -189,7 +250,7 @@ class _LinearBF16(torch.autograd.Function):
                 gx = gx.view(xshape)
             else:
                 gx = (g2 @ w16).view(xshape)
-        gw = (g2.t() @ x2).to(w_dt) if ctx.needs_input_grad[1] else None
+        gw = dw_splitk(g2, x2).to(w_dt) if ctx.needs_input_grad[1] else None
         gb = g2.float().sum(0).to(b_dt) if (b_dt is not None and ctx.needs_input_grad[2]) else None
         return gx, gw, gb
 

@@ -18,6 +18,16 @@ from . import ops
 _EINSUM_DT = os.environ.get('TAMTR_SS2D_EINSUM') == '1'
 
 
+class TallLinear(nn.Linear):
+    """nn.Linear (same parameters / state_dict keys) whose weight gradient on the GPU in bf16 is the split-K batched GEMM of
+    ops.dw_splitk: the plain dW GEMM of a [B*H*W, C] activation runs on a handful of workgroups."""
+
+    def forward(self, x):
+        if x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)):
+            return ops.linear_splitk(x.to(torch.bfloat16), self.weight, self.bias)
+        return F.linear(x, self.weight, self.bias)
+
+
 class DropPath(nn.Module):
     """Stochastic depth per sample (timm semantics: keep w.p. 1-p, rescale by 1/(1-p)); identity in eval or p=0."""
 
@@ -56,11 +66,11 @@ class SS2D(nn.Module):
         K = 4
         self.d_inner, self.dt_rank, self.d_state = d_inner, R, d_state
         self.out_norm = nn.LayerNorm(d_inner)
-        self.in_proj = nn.Linear(d_model, 2 * d_inner, bias=bias)
+        self.in_proj = TallLinear(d_model, 2 * d_inner, bias=bias)
         self.conv2d = nn.Conv2d(d_inner, d_inner, d_conv, padding=(d_conv - 1) // 2, groups=d_inner, bias=conv_bias)
         self.x_proj_weight = nn.Parameter(torch.stack([nn.Linear(d_inner, R + 2 * d_state, bias=False).weight.detach()
                                                        for _ in range(K)], 0))
-        self.out_proj = nn.Linear(d_inner, d_model, bias=bias)
+        self.out_proj = TallLinear(d_inner, d_model, bias=bias)
         # dt projection init (vmamba.py:152-176): weight U(-R^-0.5, R^-0.5), bias = softplus^-1(dt), dt log-uniform
         std = R ** -0.5 * dt_scale
         self.dt_projs_weight = nn.Parameter(torch.empty(K, d_inner, R).uniform_(-std, std))
@@ -108,8 +118,8 @@ class SS2D(nn.Module):
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None):
         super().__init__()
-        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
-        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.fc1 = TallLinear(in_features, hidden_features or in_features)
+        self.fc2 = TallLinear(hidden_features or in_features, out_features or in_features)
 
     def forward(self, x):
         return self.fc2(F.gelu(self.fc1(x)))

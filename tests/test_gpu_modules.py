@@ -177,6 +177,24 @@ def test_linear_bf16_kernel(pkg, M, N, K):
     assert torch.equal(yi.cpu(), w.t().contiguous())
 
 
+@pytest.mark.parametrize('M,N,K', [(16 * 1600, 256, 128), (8192, 10, 512), (3000, 64, 64)])
+def test_tall_linear_weight_gradient(pkg, M, N, K):
+    """TallLinear (VSS in_proj / out_proj / fc1 / fc2): split-K batched dW equals the plain reduction (fp32 reference of the
+    same bf16 operands); forward and dX are the library GEMM."""
+    lin = pkg.vss.TallLinear(K, N).cuda()
+    x = dev(rnd((M, K), 1), torch.bfloat16).requires_grad_()
+    cot = dev(rnd((M, N), 2), torch.bfloat16)
+    y = lin(x)
+    assert y.dtype == torch.bfloat16
+    (y.float() * cot.float()).sum().backward()
+    xr, wr, br = x.detach().float().cpu(), lin.weight.detach().float().cpu().bfloat16().float(), lin.bias.detach().float().cpu().bfloat16().float()
+    assert_close(y.float(), xr @ wr.t() + br, 2 ** -7, 2e-2, 'tall linear fwd')
+    assert_close(lin.weight.grad, cot.float().cpu().t() @ xr, 1e-2, 1e-2 * M ** 0.5, 'tall linear dW')
+    assert_close(lin.bias.grad, cot.float().cpu().sum(0), 1e-3, 1e-2, 'tall linear db')
+    assert_close(x.grad.float(), cot.float().cpu() @ wr, 2e-2, 2e-2, 'tall linear dX')
+    assert pkg.ops._split_count(16 * 33600) == 64 and pkg.ops._split_count(3000) == 1
+
+
 def test_linear_bf16_full_size(pkg):
     """BASELINE shape M = 16 * 33600, N = K = 512: checksum-of-rows property against an fp32 GEMV (size independent)."""
     M, N, K = 16 * 33600, 512, 512
