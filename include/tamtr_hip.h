@@ -142,6 +142,9 @@ int tamtr_selective_scan_fwd(const float* u, const float* delta, const float* A,
  *      gu[:, k] + gu[:, k+2] to get the gradient of u[:, k]); gB, gC f32 [B,K,N,L] (plain stores); gA f32 [KD,N], gD,
  *      gdbias f32 [KD] (ACCUMULATED over the batch: caller zeroes).  ws: caller workspace of
  *      2 * tamtr_selective_scan_bwd_slabs(Dk) * B*K*N*L floats (per-workgroup partial dB/dC slabs, summed by a second kernel).
+ *      xmode = 3 (backward only): as xmode = 1 and gy is ALSO in pair layout [B, 2, Dk, L] - the gradient of the
+ *      cross-merged map (CrossMerge, csms6s.py:26-34) in its row-major and column-major flattening; direction k reads
+ *      gy[:, k & 1], so the four per-direction gradient planes are never materialised.
  */
 int tamtr_selective_scan_bwd_slabs(int Dk);
 int tamtr_selective_scan_bwd(const float* gy, const float* u, const float* delta, const float* A, const float* Bm,

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
           } else {
             load4<VEC>(delta + row * L, t, L, dl, 0.f, rev);
           }
-          load4<VEC>(gy + row * L, t, L, g, 0.f, rev);
+          load4<VEC>((xmode & 2) ? gy + (((size_t)(bk / K) * 2 + (k & 1)) * Dk + d) * L : gy + row * L, t, L, g, 0.f, rev);
           if (first) {
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) { ddt[i] = 0.f; du[i] = Dd * g[i]; }
@@ -628,6 +628,7 @@ static int scan_fwd_launch(const float* u, const float* delta, const float* dtr,
   if (!u || (!delta && !dtr) || (dtr && !Wdt) || !A || !Bm || !Cm || !D || !dbias || !y || !hstate || B <= 0 || K <= 0 || Dk <= 0 ||
       L <= 0)
     return TAMTR_EINVAL;
+  if (xmode != 0 && xmode != 1) return TAMTR_EINVAL;
   if (N != NS || (long long)B * K > 65535 || (xmode && K != 4) || (dtr && (R < 1 || R > RMAX))) return TAMTR_EUNSUP;
   const int nchunk = (L + CHUNK - 1) / CHUNK;
   dim3 grid((Dk + FWD_ROWS - 1) / FWD_ROWS, B * K);
@@ -686,6 +687,7 @@ static int scan_bwd_launch(const float* gy, const float* u, const float* delta, 
   if (!gy || !u || (!delta && !dtr) || !A || !Bm || !Cm || !D || !dbias || !hstate || !gu || !gdelta || !gA || !gB || !gC || !gD ||
       !gdbias || !ws || B <= 0 || K <= 0 || Dk <= 0 || L <= 0)
     return TAMTR_EINVAL;
+  if (xmode != 0 && xmode != 1 && xmode != 3) return TAMTR_EINVAL;
   if (N != NS || (long long)B * K > 65535 || (xmode && K != 4) || (dtr && (R < 1 || R > RMAX))) return TAMTR_EUNSUP;
   const int nchunk = (L + CHUNK - 1) / CHUNK;
   const int nslab = (Dk + BWD_ROWS - 1) / BWD_ROWS;

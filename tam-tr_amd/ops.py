@@ -409,6 +409,59 @@ class _SelectiveScanDtProj(torch.autograd.Function):
         return gu, gdtr, gW, gA, gB, gC, gD, gbias, None
 
 
+class _SelectiveScanCrossMerged(torch.autograd.Function):
+    """Cross-scan + fused dt projection + CrossMerge (csms6s.py:4-46) as one autograd node: forward returns the merged map
+    [B, Dk, H*W]; backward hands the scan kernel the merged gradient in its two flattenings instead of four planes (the
+    slice/add autograd graph of the merge cost 5.4 ms per level-0 block: 1.7 GB zero fills, copies and adds)."""
+
+    @staticmethod
+    def forward(ctx, u2, dtr, Wdt, A, Bm, Cm, D, dbias, H, W):
+        require_gpu(u2, dtr, Wdt, A, Bm, Cm, D, dbias)
+        u2, dtr, Wdt, A, Bm, Cm, D, dbias = (_c(t.float()) for t in (u2, dtr, Wdt, A, Bm, Cm, D, dbias))
+        Bn, _, Dk, L = u2.shape
+        K, R, N = 4, dtr.shape[2], A.shape[1]
+        chunk = _lib.lib().tamtr_selective_scan_chunk()
+        nchunk = (L + chunk - 1) // chunk
+        y = torch.empty(Bn, K, Dk, L, device=u2.device, dtype=torch.float32)
+        hstate = torch.empty(Bn, K * Dk, nchunk, N, device=u2.device, dtype=torch.float32)
+        call('tamtr_selective_scan_dtproj_fwd', ptr(u2), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(dbias), ptr(y),
+             ptr(hstate), Bn, K, Dk, N, R, L, 1, stream_ptr())
+        ctx.save_for_backward(u2, dtr, Wdt, A, Bm, Cm, D, dbias, hstate)
+        ctx.hw = (H, W)
+        ym = y[:, 0] + y[:, 2]
+        ym += (y[:, 1] + y[:, 3]).view(Bn, Dk, W, H).transpose(2, 3).reshape(Bn, Dk, L)
+        return ym
+
+    @staticmethod
+    def backward(ctx, gm):
+        u2, dtr, Wdt, A, Bm, Cm, D, dbias, hstate = ctx.saved_tensors
+        H, W = ctx.hw
+        Bn, K, R, L = dtr.shape
+        Dk, N = u2.shape[2], A.shape[1]
+        KD = K * Dk
+        g2 = torch.empty(Bn, 2, Dk, L, device=u2.device, dtype=torch.float32)
+        g2[:, 0] = gm
+        g2[:, 1].view(Bn, Dk, W, H).copy_(gm.view(Bn, Dk, H, W).transpose(2, 3))
+        gu = torch.empty(Bn, KD, L, device=u2.device, dtype=torch.float32)
+        gdelta = torch.empty(Bn, KD, L, device=u2.device, dtype=torch.float32)
+        gdtr = torch.empty_like(dtr)
+        gW, gA = torch.zeros_like(Wdt), torch.zeros_like(A)
+        gB, gC = torch.empty_like(Bm), torch.empty_like(Cm)
+        gD, gbias = torch.zeros_like(D), torch.zeros_like(dbias)
+        nslab = _lib.lib().tamtr_selective_scan_bwd_slabs(Dk)
+        ws = torch.empty(2 * nslab * Bm.numel(), device=u2.device, dtype=torch.float32)
+        call('tamtr_selective_scan_dtproj_bwd', ptr(g2), ptr(u2), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(dbias),
+             ptr(hstate), ptr(gu), ptr(gdelta), ptr(gdtr), ptr(gW), ptr(gA), ptr(gB), ptr(gC), ptr(gD), ptr(gbias), ptr(ws), Bn, K,
+             Dk, N, R, L, 3, stream_ptr())
+        g4 = gu.view(Bn, 4, Dk, L)
+        return g4[:, :2] + g4[:, 2:], gdtr, gW, gA, gB, gC, gD, gbias, None, None
+
+
+def selective_scan_cross_merged(u2, dtr, Wdt, A, Bm, Cm, D, delta_bias, H, W):
+    """selective_scan_cross followed by the cross-merge: returns [B, Dk, H*W] in row-major pixel order."""
+    return _SelectiveScanCrossMerged.apply(u2, dtr, Wdt, A, Bm, Cm, D, delta_bias, H, W)
+
+
 def selective_scan_cross(u2, dtr, Wdt, A, Bm, Cm, D, delta_bias):
     """Cross-scan layout + fused dt projection: u2 [B,2,Dk,L] (row-major / column-major copies), dtr [B,4,R,L] low-rank dt
     factors, Wdt [4*Dk, R]; Bm, Cm [B,4,16,L]; everything stored UN-reversed (directions 2, 3 walk the buffers backwards).

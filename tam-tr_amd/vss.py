@@ -106,11 +106,11 @@ class SS2D(nn.Module):
             dts = torch.einsum('bkrl,kdr->bkdl', dtr, self.dt_projs_weight.float())
             ys = ops.selective_scan_cross_delta(u2, dts.reshape(B, -1, L), As, Bs, Cs, self.Ds.float(),
                                                 self.dt_projs_bias.float().reshape(-1)).view(B, K, D, L)
-        else:
-            ys = ops.selective_scan_cross(u2, dtr, self.dt_projs_weight.float().reshape(K * D, R), As, Bs, Cs, self.Ds.float(),
-                                          self.dt_projs_bias.float().reshape(-1)).view(B, K, D, L)
-        # cross-merge (csms6s.py:26-34) on un-reversed outputs: no flips left
-        y = ys[:, 0] + ys[:, 2] + (ys[:, 1] + ys[:, 3]).view(B, D, W, H).transpose(2, 3).reshape(B, D, L)
+            # cross-merge (csms6s.py:26-34) on un-reversed outputs: no flips left
+            y = ys[:, 0] + ys[:, 2] + (ys[:, 1] + ys[:, 3]).view(B, D, W, H).transpose(2, 3).reshape(B, D, L)
+        else:  # scan + cross-merge as one autograd node (the merged gradient feeds the scan backward directly)
+            y = ops.selective_scan_cross_merged(u2, dtr, self.dt_projs_weight.float().reshape(K * D, R), As, Bs, Cs, self.Ds.float(),
+                                                self.dt_projs_bias.float().reshape(-1), H, W)
         y = self.out_norm(y.transpose(1, 2)).view(B, H, W, -1)
         return self.out_proj((y * z).to(x.dtype))
 

@@ -122,6 +122,27 @@ def test_selective_scan_fused_dt_projection(pkg, Bn, Dk, H, W, R):
         assert_close(a.grad, b.grad, 2e-3, 2e-4 * max(float(b.grad.abs().max()), 1.0), 'grad ' + n)
 
 
+@pytest.mark.parametrize('Bn,Dk,H,W,R', [(2, 5, 4, 6, 8), (1, 33, 12, 8, 16)])
+def test_selective_scan_cross_merged(pkg, Bn, Dk, H, W, R):
+    """Scan + CrossMerge as one autograd node (merged gradient read by the scan backward in pair layout) == the per-direction
+    outputs merged with torch ops (csms6s.py:26-34), forward and every gradient."""
+    L, K, N = H * W, 4, 16
+    mk = lambda shape, seed, scale=1.0: dev(rnd(shape, seed, scale))
+    base = [mk((Bn, 2, Dk, L), 1), mk((Bn, K, R, L), 2), mk((K * Dk, R), 3, R ** -0.5), -torch.exp(mk((K * Dk, N), 4, 0.3)),
+            mk((Bn, K, N, L), 5), mk((Bn, K, N, L), 6), mk((K * Dk,), 7), mk((K * Dk,), 8) - 1.0]
+    cot = mk((Bn, Dk, L), 9)
+    a = [t.clone().requires_grad_() for t in base]
+    ys = pkg.ops.selective_scan_cross(*a).view(Bn, K, Dk, L)
+    ref = ys[:, 0] + ys[:, 2] + (ys[:, 1] + ys[:, 3]).view(Bn, Dk, W, H).transpose(2, 3).reshape(Bn, Dk, L)
+    (ref * cot).sum().backward()
+    b = [t.clone().requires_grad_() for t in base]
+    out = pkg.ops.selective_scan_cross_merged(*b, H, W)
+    (out * cot).sum().backward()
+    assert_close(out, ref, 1e-6, 1e-6, 'merged scan out')
+    for name, ta, tb in zip('u2 dtr Wdt A B C D bias'.split(), a, b):
+        assert_close(tb.grad, ta.grad, 1e-5, 1e-5 * max(1.0, float(ta.grad.abs().max())), 'merged scan grad ' + name)
+
+
 def _attn_ref(q, k, v, nh, mask):
     B, Q, C = q.shape
     dh = C // nh
