@@ -13,7 +13,7 @@ from .backbone import batchnorm
 from . import ops
 from .loss import get_cdn_group
 from .modules import ContrastiveHeadMLP, DeformableTransformerDecoderLayer, MLP, TextDeformableTransformerDecoder
-from .vss import VSSBlock
+from .vss import TallLinear, VSSBlock
 
 
 class ManbaWorldDecoder(nn.Module):
@@ -39,7 +39,7 @@ class ManbaWorldDecoder(nn.Module):
             self.tgt_embed = nn.Embedding(nq, hd)
         self.query_pos_head = MLP(4, 2 * hd, hd, num_layers=2)
         self.enc_output = nn.Sequential(nn.Linear(hd, hd), nn.LayerNorm(hd))
-        self.enc_score_head = nn.Linear(hd, nc)
+        self.enc_score_head = TallLinear(hd, nc)  # nn.Linear whose weight gradient over the B*L = 537 600 tokens is a split-K GEMM
         self.enc_bbox_head = MLP(hd, hd, 4, num_layers=3)
         self.dec_score_head = nn.ModuleList(ContrastiveHeadMLP() for _ in range(ndl))
         self.dec_bbox_head = nn.ModuleList(MLP(hd, hd, 4, num_layers=3) for _ in range(ndl))

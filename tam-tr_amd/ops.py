@@ -409,6 +409,86 @@ class _SelectiveScanDtProj(torch.autograd.Function):
         return gu, gdtr, gW, gA, gB, gC, gD, gbias, None
 
 
+class _CrossScanInput(torch.autograd.Function):
+    """u2 [B, 2, D, H*W] fp32 = SiLU(xc) in its row-major and column-major flattening (what CrossScan, csms6s.py:4-14, needs
+    in the pair layout of the scan kernels) as one autograd node: three kernels forward, three backward, instead of the
+    silu / float / stack / transpose chain and its slice-and-add autograd graph."""
+
+    @staticmethod
+    def forward(ctx, xc):
+        B, D, H, W = xc.shape
+        a = torch.nn.functional.silu(xc)  # in xc's dtype, as the reference's act (vmamba.py:951)
+        u2 = torch.empty(B, 2, D, H * W, device=xc.device, dtype=torch.float32)
+        u2[:, 0].view(B, D, H, W).copy_(a)
+        u2[:, 1].view(B, D, W, H).copy_(a.transpose(2, 3))
+        ctx.save_for_backward(xc)
+        return u2
+
+    @staticmethod
+    def backward(ctx, g2):
+        (xc,) = ctx.saved_tensors
+        B, D, H, W = xc.shape
+        ga = g2[:, 0].view(B, D, H, W) + g2[:, 1].view(B, D, W, H).transpose(2, 3)
+        return torch.ops.aten.silu_backward(ga.to(xc.dtype), xc)
+
+
+def cross_scan_input(xc):
+    return _CrossScanInput.apply(xc)
+
+
+def _split_len(L, min_len=1024, max_split=16):
+    S = 1
+    while S < max_split and L % (2 * S) == 0 and L // (2 * S) >= min_len:
+        S *= 2
+    return S
+
+
+class _XProjCross(torch.autograd.Function):
+    """x_proj of SS2D (vmamba.py:962-970) on the pair layout: wx [4, C, D] (C = R + 2N), u2 [B, 2, D, L] ->
+    dtr [B,4,R,L], Bs [B,4,N,L], Cs [B,4,N,L] (fp32, contiguous, un-reversed).  Directions k and k+2 share a base copy, so it
+    is two [2C, D] x [D, L] products; their weight gradient (a reduction over L per image) runs as a batched GEMM over L
+    slices, and the output assembly has an explicit backward (one concatenation per copy instead of ~30 slice kernels)."""
+
+    @staticmethod
+    def forward(ctx, wx, u2, R, N):
+        cdt = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else torch.float32
+        C = R + 2 * N
+        ub = u2.to(cdt)
+        wa, wb = torch.cat([wx[0], wx[2]], 0).to(cdt), torch.cat([wx[1], wx[3]], 0).to(cdt)
+        with torch.autocast('cuda', enabled=False):
+            xa, xb = torch.matmul(wa, ub[:, 0]), torch.matmul(wb, ub[:, 1])  # [B, 2C, L]
+        parts = []
+        for lo, n in ((0, R), (R, N), (R + N, N)):
+            parts.append(torch.stack([xa[:, lo:lo + n], xb[:, lo:lo + n], xa[:, C + lo:C + lo + n], xb[:, C + lo:C + lo + n]], 1).float())
+        ctx.save_for_backward(ub, wa, wb)
+        ctx.cfg = (R, N, wx.dtype, u2.dtype)
+        return tuple(parts)
+
+    @staticmethod
+    def backward(ctx, gdtr, gBs, gCs):
+        ub, wa, wb = ctx.saved_tensors
+        R, N, w_dt, u_dt = ctx.cfg
+        cdt = ub.dtype
+        Bn, _, D, L = ub.shape
+        C = R + 2 * N
+        S = _split_len(L)
+        gws, gus = [], []
+        with torch.autocast('cuda', enabled=False):
+            for i, w in ((0, wa), (1, wb)):
+                gx = torch.cat([gdtr[:, i], gBs[:, i], gCs[:, i], gdtr[:, i + 2], gBs[:, i + 2], gCs[:, i + 2]], 1).to(cdt)  # [B, 2C, L]
+                gus.append(torch.matmul(w.t(), gx))
+                ga = gx.view(Bn, 2 * C, S, L // S).transpose(1, 2).reshape(Bn * S, 2 * C, L // S)
+                ua = ub[:, i].reshape(Bn, D, S, L // S).transpose(1, 2).reshape(Bn * S, D, L // S)
+                gws.append(torch.bmm(ga, ua.transpose(1, 2)).float().sum(0))  # [2C, D]
+        gwx = torch.stack([gws[0][:C], gws[1][:C], gws[0][C:], gws[1][C:]], 0).to(w_dt)
+        gu2 = torch.stack(gus, 1).to(u_dt)
+        return gwx, gu2, None, None
+
+
+def x_proj_cross(wx, u2, R, N):
+    return _XProjCross.apply(wx, u2, R, N)
+
+
 class _SelectiveScanCrossMerged(torch.autograd.Function):
     """Cross-scan + fused dt projection + CrossMerge (csms6s.py:4-46) as one autograd node: forward returns the merged map
     [B, Dk, H*W]; backward hands the scan kernel the merged gradient in its two flattenings instead of four planes (the

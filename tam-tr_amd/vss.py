@@ -86,18 +86,23 @@ class SS2D(nn.Module):
         xz = self.in_proj(x)
         xi, z = xz.chunk(2, -1)
         z = F.silu(z)
-        xi = F.silu(self.conv2d(xi.permute(0, 3, 1, 2).contiguous())).float()  # [B,D,H,W]; the scan runs in fp32 (vmamba.py:980)
+        xc = self.conv2d(xi.permute(0, 3, 1, 2).contiguous())  # [B,D,H,W]
         K, R, N, L, D = 4, self.dt_rank, self.d_state, H * W, self.d_inner
         # Cross-scan WITHOUT materialising the four sequences (csms6s.py:4-14): directions 0/2 walk the row-major flattening
         # forwards/backwards, 1/3 the column-major one; the kernel reads the two stored copies and reverses on the fly, and all
-        # per-direction operands are kept in the un-reversed order of their base copy.
-        u2 = torch.stack([xi.flatten(2), xi.transpose(2, 3).flatten(2)], 1)  # [B,2,D,L]
-        wx = self.x_proj_weight.float()  # [4, R+2N, D]
-        xd_a = torch.matmul(torch.cat([wx[0], wx[2]], 0), u2[:, 0])  # [B, 2C, L]: directions 0 and 2 (same base order)
-        xd_b = torch.matmul(torch.cat([wx[1], wx[3]], 0), u2[:, 1])  # directions 1 and 3
-        C = R + 2 * N
-        x_dbl = torch.stack([xd_a[:, :C], xd_b[:, :C], xd_a[:, C:], xd_b[:, C:]], 1)  # [B,4,C,L]
-        dtr, Bs, Cs = (t.contiguous() for t in torch.split(x_dbl, [R, N, N], 2))
+        # per-direction operands are kept in the un-reversed order of their base copy.  The scan runs in fp32 (vmamba.py:980).
+        if _EINSUM_DT:
+            xi = F.silu(xc).float()
+            u2 = torch.stack([xi.flatten(2), xi.transpose(2, 3).flatten(2)], 1)  # [B,2,D,L]
+            wx = self.x_proj_weight.float()  # [4, R+2N, D]
+            xd_a = torch.matmul(torch.cat([wx[0], wx[2]], 0), u2[:, 0])  # [B, 2C, L]: directions 0 and 2 (same base order)
+            xd_b = torch.matmul(torch.cat([wx[1], wx[3]], 0), u2[:, 1])  # directions 1 and 3
+            C = R + 2 * N
+            x_dbl = torch.stack([xd_a[:, :C], xd_b[:, :C], xd_a[:, C:], xd_b[:, C:]], 1)  # [B,4,C,L]
+            dtr, Bs, Cs = (t.contiguous() for t in torch.split(x_dbl, [R, N, N], 2))
+        else:
+            u2 = ops.cross_scan_input(xc)                                   # SiLU + both flattenings, [B,2,D,L] fp32
+            dtr, Bs, Cs = ops.x_proj_cross(self.x_proj_weight, u2, R, N)    # [B,4,R|N|N,L]
         # the dt projection (einsum "bkrl,kdr->bkdl", vmamba.py:972) happens INSIDE the scan kernels: the [B, 4*d_inner, L]
         # delta tensor is never written, and its skinny K = R <= 32 GEMMs (forward + two backward: ~38 ms per step through
         # rocBLAS at these shapes) disappear
