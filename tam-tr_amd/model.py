@@ -63,6 +63,38 @@ def build_graph(spec, ch=3, nc=10):
     return nn.Sequential(*layers), sorted(set(save))
 
 
+class _CastGroup(torch.autograd.Function):
+    """fp32 master conv weights of one graph layer -> bf16 compute copies in ONE multi-tensor kernel, and their gradients back
+    to fp32 in one.  autocast casts every weight (and every weight gradient) with its own ~13 us kernel: 400 + 340 launches
+    and ~10 ms of GPU time per step on this graph.  One group per top-level layer, so weight gradients still become
+    available layer by layer during the backward (the DP reducer overlaps its all-reduce with what is left)."""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        outs = [torch.empty_like(w, dtype=torch.bfloat16) for w in ws]
+        torch._foreach_copy_(outs, list(ws))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [i for i, g in enumerate(gs) if g is not None]  # e.g. the gate's proj_conv: evaluated, never used (SURVEY D2)
+        outs = [torch.empty_like(gs[i], dtype=torch.float32) for i in live]
+        if live:
+            torch._foreach_copy_(outs, [gs[i] for i in live])
+        res = [None] * len(gs)
+        for i, o in zip(live, outs):
+            res[i] = o
+        return tuple(res)
+
+
+def _conv_weight_names(m):
+    names = getattr(m, '_tamtr_conv_names', None)
+    if names is None:
+        names = [f'{n}.weight' if n else 'weight' for n, sub in m.named_modules() if isinstance(sub, nn.Conv2d)]
+        m._tamtr_conv_names = names
+    return names
+
+
 class RTDETRDetectionWorldModel(nn.Module):
     """forward(dict) -> (loss, loss_items)   [training batch: img, txt_feats, cls, bboxes, batch_idx]
        forward(tensor) -> predictions        [uses self.txt_feats set in advance]"""
@@ -97,10 +129,17 @@ class RTDETRDetectionWorldModel(nn.Module):
         head = self.model[-1]
         with torch.autocast('cuda', dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None):
             y = []
+            grouped_cast = self.autocast_dtype == torch.bfloat16 and x.is_cuda and torch.is_grad_enabled()
             for m in self.model[:-1]:
                 if m.f != -1:
                     x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
-                x = m(x, txt) if isinstance(m, TIAGELAN) else m(x)
+                args = (x, txt) if isinstance(m, TIAGELAN) else (x,)
+                names = _conv_weight_names(m) if grouped_cast else ()
+                if names:  # this layer's conv weights as bf16 copies from one kernel (see _CastGroup); same values autocast would use
+                    w16 = _CastGroup.apply(*[m.get_parameter(n) for n in names])
+                    x = torch.func.functional_call(m, dict(zip(names, w16)), args)
+                else:
+                    x = m(*args)
                 y.append(x if m.i in self.save else None)
             return head([y[j] for j in head.f], txt.clone(), batch)
 

@@ -451,7 +451,7 @@ class _XProjCross(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, wx, u2, R, N):
-        cdt = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else torch.float32
+        cdt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else torch.float32
         C = R + 2 * N
         ub = u2.to(cdt)
         wa, wb = torch.cat([wx[0], wx[2]], 0).to(cdt), torch.cat([wx[1], wx[3]], 0).to(cdt)

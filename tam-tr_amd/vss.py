@@ -23,7 +23,7 @@ class TallLinear(nn.Linear):
     ops.dw_splitk: the plain dW GEMM of a [B*H*W, C] activation runs on a handful of workgroups."""
 
     def forward(self, x):
-        if x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)):
+        if x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16)):
             return ops.linear_splitk(x.to(torch.bfloat16), self.weight, self.bias)
         return F.linear(x, self.weight, self.bias)
 
