@@ -200,6 +200,27 @@ int tamtr_cpam_fwd(const void* x, const void* p, void* out, float* s2, int32_t* 
 int tamtr_cpam_bwd(const void* gout, const void* x, const void* p, const float* s2, const int32_t* arg, void* dx_direct,
                    void* du_ws, void* dp, int B, int C, int H, int W, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * a-9  SS2D front end: depthwise 3x3 conv + bias + SiLU + cross-scan layout.  Replaces `x = self.act(self.conv2d(x))`
+ *      (ultralytics/nn/extra_modules/VManba/vmamba.py:949-952, on the NCHW permutation of the in_proj output) together with
+ *      CrossScan (VManba/csms6s.py:4-14) in the pair layout of tamtr_selective_scan_* (xmode = 1).
+ *      x      (T) channels-last map: pixel (b, h, w) starts at x + ((b*H + h)*W + w) * x_pixel_stride, D channels are read
+ *                 (the in_proj output [B, H, W, 2*d_inner] is passed as it lies, x_pixel_stride = 2*d_inner)
+ *      weight f32 [D, 9] (= conv2d.weight [D, 1, 3, 3]), bias f32 [D] or NULL
+ *      u2     f32 [B, 2, D, H*W]: plane 0 = SiLU(conv) flattened row-major (h*W + w), plane 1 column-major (w*H + h)
+ *      D % 32 == 0; x_pixel_stride a multiple of 16 bytes.
+ */
+int tamtr_dwconv_silu_cross_fwd(const void* x, long long x_pixel_stride, const float* weight, const float* bias, float* u2, int B,
+                                int D, int H, int W, int dtype, void* stream);
+/*      Backward.  g2 f32 [B, 2, D, H*W] (gradient of u2) ->
+ *      gx (T) channels-last, pixel stride gx_pixel_stride (D channels written per pixel),
+ *      ws f32 [B, tamtr_dwconv_tiles(H, W), D, 10]: per-tile partial sums of d(weight) (9 taps) and d(bias) (caller sums
+ *      over the first two axes; no atomics).
+ */
+int tamtr_dwconv_tiles(int H, int W);
+int tamtr_dwconv_silu_cross_bwd(const float* g2, const void* x, long long x_pixel_stride, const float* weight, const float* bias,
+                                void* gx, long long gx_pixel_stride, float* ws, int B, int D, int H, int W, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,11 +6,11 @@ imported from this package.)
 """
 import ctypes
 import os
-from ctypes import c_float, c_int, c_void_p
+from ctypes import c_float, c_int, c_longlong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TAMTR_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libtamtr_hip.so')  # env override: kernel A/B experiments
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 F32, BF16 = 0, 1
 _ERR = {-1: 'TAMTR_EINVAL (bad argument)', -2: 'TAMTR_EUNSUP (shape/dtype outside what the kernels are built for)',
@@ -21,7 +21,7 @@ class TamtrHipError(RuntimeError):
     pass
 
 
-_P, _I, _F = c_void_p, c_int, c_float
+_P, _I, _F, _LL = c_void_p, c_int, c_float, c_longlong
 _SIGS = {
     'tamtr_abi_version': [],
     'tamtr_maxsigmoid_gate_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
@@ -42,6 +42,9 @@ _SIGS = {
     'tamtr_lsap_assign': [_P, _P, _I, _I, _I, _P, _P, _P, _P],
     'tamtr_cpam_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'tamtr_cpam_bwd': [_P] * 8 + [_I, _I, _I, _I, _I, _P],
+    'tamtr_dwconv_silu_cross_fwd': [_P, _LL, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'tamtr_dwconv_tiles': [_I, _I],
+    'tamtr_dwconv_silu_cross_bwd': [_P, _P, _LL, _P, _P, _P, _LL, _P, _I, _I, _I, _I, _I, _P],
 }
 EXPORTS = tuple(_SIGS)
 _lib = None

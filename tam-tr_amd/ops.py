@@ -436,6 +436,43 @@ def cross_scan_input(xc):
     return _CrossScanInput.apply(xc)
 
 
+class _DWConvSiluCross(torch.autograd.Function):
+    """SS2D front end on the in_proj output as it lies: xz [B, H, W, 2*D] (xi = the first D channels of every pixel) ->
+    u2 [B, 2, D, H*W] fp32 = SiLU(dwconv3x3(xi) + bias) in both flattenings (csrc/dwconv.hip)."""
+
+    @staticmethod
+    def forward(ctx, xz, weight, bias, D):
+        require_gpu(xz, weight)
+        xz = _c(xz)
+        B, H, W, C2 = xz.shape
+        w = _c(weight.float().reshape(D, 9))
+        bvec = _c(bias.float()) if bias is not None else None
+        u2 = torch.empty(B, 2, D, H * W, device=xz.device, dtype=torch.float32)
+        call('tamtr_dwconv_silu_cross_fwd', ptr(xz), C2, ptr(w), ptr(bvec), ptr(u2), B, D, H, W, dtype_code(xz), stream_ptr())
+        ctx.save_for_backward(xz, w, bvec if bvec is not None else w.new_empty(0))
+        ctx.cfg = (D, weight.shape, weight.dtype, None if bias is None else bias.dtype)
+        return u2
+
+    @staticmethod
+    def backward(ctx, g2):
+        xz, w, bvec = ctx.saved_tensors
+        D, w_shape, w_dt, b_dt = ctx.cfg
+        B, H, W, C2 = xz.shape
+        tiles = _lib.lib().tamtr_dwconv_tiles(H, W)
+        gxz = torch.zeros_like(xz)  # the second half (z) gets its gradient from the gate path; autograd adds the two
+        ws = torch.empty(B, tiles, D, 10, device=xz.device, dtype=torch.float32)
+        call('tamtr_dwconv_silu_cross_bwd', ptr(_c(g2.float())), ptr(xz), C2, ptr(w), ptr(bvec if b_dt is not None else None), ptr(gxz), C2,
+             ptr(ws), B, D, H, W, dtype_code(xz), stream_ptr())
+        gwb = ws.sum((0, 1))
+        gw = gwb[:, :9].reshape(w_shape).to(w_dt)
+        gb = gwb[:, 9].to(b_dt) if b_dt is not None else None
+        return gxz, gw, gb, None
+
+
+def dwconv_silu_cross(xz, weight, bias, D):
+    return _DWConvSiluCross.apply(xz, weight, bias, D)
+
+
 def _split_len(L, min_len=1024, max_split=16):
     S = 1
     while S < max_split and L % (2 * S) == 0 and L // (2 * S) >= min_len:

@@ -86,8 +86,9 @@ class SS2D(nn.Module):
         xz = self.in_proj(x)
         xi, z = xz.chunk(2, -1)
         z = F.silu(z)
-        xc = self.conv2d(xi.permute(0, 3, 1, 2).contiguous())  # [B,D,H,W]
         K, R, N, L, D = 4, self.dt_rank, self.d_state, H * W, self.d_inner
+        fused_front = not _EINSUM_DT and D % 32 == 0 and self.conv2d.kernel_size == (3, 3)
+        xc = None if fused_front else self.conv2d(xi.permute(0, 3, 1, 2).contiguous())  # [B,D,H,W]
         # Cross-scan WITHOUT materialising the four sequences (csms6s.py:4-14): directions 0/2 walk the row-major flattening
         # forwards/backwards, 1/3 the column-major one; the kernel reads the two stored copies and reverses on the fly, and all
         # per-direction operands are kept in the un-reversed order of their base copy.  The scan runs in fp32 (vmamba.py:980).
@@ -101,7 +102,10 @@ class SS2D(nn.Module):
             x_dbl = torch.stack([xd_a[:, :C], xd_b[:, :C], xd_a[:, C:], xd_b[:, C:]], 1)  # [B,4,C,L]
             dtr, Bs, Cs = (t.contiguous() for t in torch.split(x_dbl, [R, N, N], 2))
         else:
-            u2 = ops.cross_scan_input(xc)                                   # SiLU + both flattenings, [B,2,D,L] fp32
+            if fused_front:  # depthwise conv + SiLU + both flattenings in one kernel, read from the channels-last in_proj output
+                u2 = ops.dwconv_silu_cross(xz, self.conv2d.weight, self.conv2d.bias, D)
+            else:
+                u2 = ops.cross_scan_input(xc)                               # SiLU + both flattenings, [B,2,D,L] fp32
             dtr, Bs, Cs = ops.x_proj_cross(self.x_proj_weight, u2, R, N)    # [B,4,R|N|N,L]
         # the dt projection (einsum "bkrl,kdr->bkdl", vmamba.py:972) happens INSIDE the scan kernels: the [B, 4*d_inner, L]
         # delta tensor is never written, and its skinny K = R <= 32 GEMMs (forward + two backward: ~38 ms per step through

@@ -247,3 +247,34 @@ def test_cpam_full_size_properties(ops):
     o16 = ops.cpam(x.bfloat16())
     assert bool((o32.abs() <= x.abs() + 1e-6).all())
     assert float((o16.float() - o32).abs().max()) < 0.05
+
+
+@pytest.mark.parametrize('B,D,H,W,dt', [(2, 32, 16, 16, torch.float32), (1, 64, 13, 21, torch.float32), (2, 32, 40, 40, torch.float32),
+                                        (1, 96, 8, 5, torch.bfloat16)])
+def test_dwconv_silu_cross(ops, B, D, H, W, dt):
+    """SS2D front end (vmamba.py:949-952 + CrossScan csms6s.py:4-14): fused kernel vs conv2d + SiLU + the two flattenings in
+    torch on the CPU, forward and all three gradients; xi is the first half of the channels-last in_proj output."""
+    import torch.nn.functional as F
+    xz = rnd((B, H, W, 2 * D), 1).to(dt).float()
+    w, bias = rnd((D, 1, 3, 3), 2, 0.4), rnd((D,), 3, 0.2)
+    cot = rnd((B, 2, D, H * W), 4)
+    xr, wr, br = xz.clone().requires_grad_(), w.clone().requires_grad_(), bias.clone().requires_grad_()
+    a = F.silu(F.conv2d(xr[..., :D].permute(0, 3, 1, 2), wr, br, padding=1, groups=D))
+    ref = torch.stack([a.flatten(2), a.transpose(2, 3).flatten(2)], 1)
+    (ref * cot).sum().backward()
+    xd, wd, bd = dev(xz, dt).requires_grad_(), dev(w).requires_grad_(), dev(bias).requires_grad_()
+    out = ops.dwconv_silu_cross(xd, wd, bd, D)
+    (out * dev(cot)).sum().backward()
+    tol = 1e-5 if dt == torch.float32 else 1e-2
+    assert_close(out, ref, tol, tol, 'dwconv out')
+    assert_close(xd.grad.float(), xr.grad, 10 * tol, 10 * tol, 'dwconv dx')   # second half of the channels stays zero
+    assert_close(wd.grad, wr.grad, 10 * tol, 10 * tol * (B * H * W) ** 0.5, 'dwconv dw')
+    assert_close(bd.grad, br.grad, 10 * tol, 10 * tol * (B * H * W) ** 0.5, 'dwconv db')
+
+
+def test_dwconv_argument_checks(ops):
+    import tamtr_amd
+    with pytest.raises(tamtr_amd.TamtrHipError):
+        ops.dwconv_silu_cross(torch.zeros(1, 4, 4, 48).cuda(), torch.zeros(24, 1, 3, 3).cuda(), None, 24)   # D % 32 != 0
+    with pytest.raises(tamtr_amd.TamtrHipError):
+        ops.dwconv_silu_cross(torch.zeros(1, 4, 4, 64), torch.zeros(32, 1, 3, 3), None, 32)                # CPU tensors
