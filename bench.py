@@ -72,6 +72,20 @@ class KernelTimer:
         return {'launches': len(ms), 'avg_ms': avg, 'min_ms': ms[0], 'tflops': ev[0][2] / (avg * 1e-3) / 1e12}
 
 
+def gemm_traffic(args):
+    """HBM bytes per launch of the roofline kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+    WRITE_SIZE in separate runs of tools/gemm_only.py, corrected as the MI355X guide prescribes).  Counters cannot be collected
+    from inside this process; null when the committed measurement is not for this shape."""
+    path = os.path.join(ROOT, 'profiles', 'r01_gemm_pmc.json')
+    try:
+        d = json.load(open(path))
+        if d.get('M') == args.batch * 33600 and args.dtype == 'bf16':
+            return d['hbm_bytes_per_launch']
+    except Exception:
+        pass
+    return None
+
+
 def host_cores():
     """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota (the GPU boxes give a 1-GPU job a
     share of a large host) and by 32."""
@@ -204,10 +218,10 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'TAM-TR (TAMTR.yaml graph, 42.1M params) train step fwd+loss+bwd+AdamW, {args.imgsz}x{args.imgsz}, '
                                    f'bs {args.batch}/GPU, 10 text prompts, 8 GT/img, full BTA-PAN+MEH HIP path',
-                       'global_batch': world * args.batch, 'parallelism': f'dp{world}', 'final_loss': float(loss)},
+                       'global_batch': world * args.batch, 'parallelism': f'dp{world}', 'final_loss': float(loss.detach())},
             'roofline': None if ks is None else {
-                'bound': 'mfma', 'kernel': 'linear_bf16_kernel (MEH value_proj, M=%d N=K=512)' % (args.batch * 33600),
-                'achieved': ks['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': ks['tflops'] / peak, 'traffic': None,
+                'bound': 'mfma', 'kernel': 'linear_bf16_n512_k64_kernel (MEH value_proj x3 + enc_output, M=%d N=K=512)' % (args.batch * 33600),
+                'achieved': ks['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': ks['tflops'] / peak, 'traffic': gemm_traffic(args),
                 'avg_ms': ks['avg_ms'], 'launches': ks['launches']},
         }
         if not args.no_cpu_baseline and world == 1:

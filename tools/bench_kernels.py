@@ -117,8 +117,48 @@ def bench_attn():
         print(f'self-attn {str(dt)[6:]}: fwd {a * 1e3:.0f} us, fwd+bwd {ab * 1e3:.0f} us ({4 * B * nh * Q * Q * dh / a / 1e9:.1f} TFLOP/s fwd)')
 
 
+def bench_cpam():
+    for (C, H) in [(512, 40), (256, 80), (128, 160)]:
+        for dt in (torch.float32, torch.bfloat16):
+            x = torch.randn(16, C, H, H, device='cuda').to(dt).requires_grad_()
+            p, idx = torch.nn.functional.max_pool2d(x.detach(), 3, 2, 1, return_indices=True)
+            out, s2 = torch.empty_like(x), torch.empty(16, 8, H, H, device='cuda')
+            arg = torch.empty(16, 8, H, H, device='cuda', dtype=torch.int32)
+            code = 0 if dt == torch.float32 else 1
+            from tamtr_amd._lib import call, ptr, stream_ptr
+            k, _ = timeit(lambda: call('tamtr_cpam_fwd', ptr(x.detach()), ptr(p), ptr(out), ptr(s2), ptr(arg), 16, C, H, H, code, stream_ptr()), n=10)
+            a, _ = timeit(lambda: ops.cpam(x), n=10)
+            go = torch.randn_like(x)
+            ab, _ = timeit(lambda: torch.autograd.grad(ops.cpam(x), [x], go), n=10)
+            byt = (2 * x.numel() + p.numel()) * x.element_size()
+            print(f'cpam C={C} {H}x{H} {str(dt)[6:]}: gate kernel {k * 1e3:.0f} us = {byt / k / 1e6:.0f} GB/s (x + p + out); '
+                  f'op with max-pool {a * 1e3:.0f} us, fwd+bwd {ab * 1e3:.0f} us')
+
+
+def bench_dwconv():
+    for (D, H) in [(256, 160), (512, 80), (1024, 40)]:
+        xz = torch.randn(16, H, H, 2 * D, device='cuda').bfloat16().requires_grad_()
+        w = (torch.randn(D, 1, 3, 3, device='cuda') * 0.3).requires_grad_()
+        b = torch.zeros(D, device='cuda').requires_grad_()
+        a, _ = timeit(lambda: ops.dwconv_silu_cross(xz, w, b, D), n=10)
+        u2 = ops.dwconv_silu_cross(xz, w, b, D)
+        go = torch.randn_like(u2)
+        ab, _ = timeit(lambda: torch.autograd.grad(ops.dwconv_silu_cross(xz, w, b, D), [xz, w, b], go), n=10)
+        byt = 16 * H * H * D * (2 + 8)
+        print(f'dwconv+silu+cross d_inner={D} {H}x{H} bf16 in: fwd {a * 1e3:.0f} us = {byt / a / 1e6:.0f} GB/s (xi + two fp32 planes), '
+              f'fwd+bwd {ab * 1e3:.0f} us')
+
+
+def bench_lsap():
+    g = torch.Generator(device='cuda').manual_seed(0)
+    for nq, groups in [(100, [8] * 16), (300, [120] * 16)]:
+        cost = torch.randn(len(groups), nq, sum(groups), device='cuda', generator=g)
+        a, mn = timeit(lambda: ops.lsap_assign(cost, groups), n=20)
+        print(f'lsap nq={nq} boxes/img={groups[0]} x {len(groups)} images: {a * 1e3:.0f} us avg, {mn * 1e3:.0f} us min (one launch, no host round trip)')
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['all']
-    for name in ('scan', 'gemm', 'gate', 'msda', 'attn'):
+    for name in ('scan', 'gemm', 'gate', 'msda', 'attn', 'cpam', 'dwconv', 'lsap'):
         if name in which or 'all' in which:
             globals()['bench_' + name]()
