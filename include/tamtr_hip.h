@@ -221,6 +221,30 @@ int tamtr_dwconv_tiles(int H, int W);
 int tamtr_dwconv_silu_cross_bwd(const float* g2, const void* x, long long x_pixel_stride, const float* weight, const float* bias,
                                 void* gx, long long gx_pixel_stride, float* ws, int B, int D, int H, int W, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * a-9  SS2D back end.  tamtr_cross_merge_* replace CrossMerge (VManba/csms6s.py:26-34) and the transposition to channels-last:
+ *          ymT[b, h*W+w, d] = y4[b,0,d,h*W+w] + y4[b,2,d,h*W+w] + y4[b,1,d,w*H+h] + y4[b,3,d,w*H+h]
+ *      y4 f32 [B, 4, D, H*W] (scan outputs, un-reversed, as tamtr_selective_scan_* with xmode = 1 write them), ymT f32 [B, H*W, D];
+ *      backward: gymT f32 [B, H*W, D] -> g2 f32 [B, 2, D, H*W], the gradient in pair layout that the scan backward reads with
+ *      xmode = 3.  D % 32 == 0.
+ */
+int tamtr_cross_merge_fwd(const float* y4, float* ymT, int B, int D, int H, int W, void* stream);
+int tamtr_cross_merge_bwd(const float* gymT, float* g2, int B, int D, int H, int W, void* stream);
+
+/*      tamtr_ln_gate_* replace `y = self.out_norm(y); y = y * self.act(z)` (VManba/vmamba.py:1005-1008,1029-1036):
+ *          out[t, :] = LayerNorm(x[t, :]; gamma, beta, eps) * SiLU(z[t, :]),  z[t, d] = xz[t * xz_token_stride + D + d]
+ *      x f32 [ntok, D]; xz (T) the channels-last in_proj output (z = second half of each token's 2*D row); out (T) [ntok, D];
+ *      stats f32 [ntok, 2] (mean, 1/std) saved for the backward.  D in {64, 128, 256, 512, 1024}.
+ *      Backward: gout (T) [ntok, D] -> gx f32 [ntok, D]; d(z) written into gxz (T) at the same offsets as z in xz (the
+ *      caller zero-fills the x half); partials f32 [tamtr_ln_gate_blocks(ntok), 2, D]: per-workgroup sums of d(gamma), d(beta).
+ */
+int tamtr_ln_gate_blocks(long long ntok);
+int tamtr_ln_gate_fwd(const float* x, const void* xz, long long xz_token_stride, const float* gamma, const float* beta, void* out,
+                      float* stats, long long ntok, int D, float eps, int dtype, void* stream);
+int tamtr_ln_gate_bwd(const void* gout, const float* x, const void* xz, long long xz_token_stride, const float* gamma,
+                      const float* beta, const float* stats, float* gx, void* gxz, float* partials, long long ntok, int D, int dtype,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,272 @@
+// ss2d_out.hip - SS2D back end: CrossMerge into token-major layout, and out_norm (LayerNorm) x SiLU(z) gate, gfx950.
+//
+// Reference: CrossMerge (ultralytics/nn/extra_modules/VManba/csms6s.py:26-34) on the four scan outputs, then
+// `y = out_norm(y); y = y * act(z); out_proj(y)` (VManba/vmamba.py:1005-1008,1029-1036).  Through PyTorch the scan outputs
+// [B, 4, D, L] became [B, L, D] in seven strided passes (two adds, a transposing add, a transposing copy for LayerNorm, LayerNorm,
+// the gate, a cast), and the backward undid them with as many again plus LayerNorm's two backward kernels.  Here:
+//   cross_merge_fwd : y4 [B,4,D,L] -> ymT [B,L,D]   (16x16 pixel x 32 channel tiles through LDS; both flattenings are read
+//                     along their own contiguous axis, the token-major result is written in 128-B channel runs)
+//   cross_merge_bwd : d(ymT) -> the gradient in the scan's pair layout [B,2,D,L] (what tamtr_selective_scan_*_bwd reads, xmode 3)
+//   ln_gate_fwd/bwd : one wave per token: LayerNorm over D in registers, SiLU(z) read from the channels-last in_proj output where
+//                     it lies (second half of each pixel's 2*D row), bf16/fp32 output; backward also yields d(z) in place,
+//                     per-workgroup partial d(gamma) / d(beta) (no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int TS = 16, CB = 32, MT_THREADS = 256, PITCH = TS + 1;
+
+__global__ __launch_bounds__(MT_THREADS) void cross_merge_fwd_kernel(const float* __restrict__ y4, float* __restrict__ ymT, int D, int H,
+                                                                      int W, int tiles_w) {
+  __shared__ float s[CB][TS][PITCH];
+  const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
+  const int d0 = blockIdx.y * CB, b = blockIdx.z, h0 = th * TS, w0 = tw * TS;
+  const size_t L = (size_t)H * W;
+  const float* yb = y4 + (size_t)b * 4 * D * L;
+  {  // directions 0 and 2: row-major flattening, lanes along x
+    const int ty = threadIdx.x / TS, tx = threadIdx.x % TS, h = h0 + ty, w = w0 + tx;
+    const bool ok = h < H && w < W;
+    const size_t p = (size_t)h * W + w;
+    for (int c = 0; c < CB; ++c)
+      s[c][ty][tx] = ok ? yb[(size_t)(d0 + c) * L + p] + yb[((size_t)2 * D + d0 + c) * L + p] : 0.f;
+  }
+  __syncthreads();
+  {  // directions 1 and 3: column-major flattening, lanes along y
+    const int ty = threadIdx.x % TS, tx = threadIdx.x / TS, h = h0 + ty, w = w0 + tx;
+    if (h < H && w < W) {
+      const size_t p = (size_t)w * H + h;
+      for (int c = 0; c < CB; ++c)
+        s[c][ty][tx] += yb[((size_t)D + d0 + c) * L + p] + yb[((size_t)3 * D + d0 + c) * L + p];
+    }
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < TS * TS * (CB / 4); it += MT_THREADS) {
+    const int pix = it / (CB / 4), g = it - pix * (CB / 4), py = pix / TS, px = pix - py * TS;
+    const int h = h0 + py, w = w0 + px;
+    if (h < H && w < W)
+      *reinterpret_cast<float4*>(ymT + ((size_t)b * L + (size_t)h * W + w) * D + d0 + g * 4) =
+          make_float4(s[g * 4][py][px], s[g * 4 + 1][py][px], s[g * 4 + 2][py][px], s[g * 4 + 3][py][px]);
+  }
+}
+
+__global__ __launch_bounds__(MT_THREADS) void cross_merge_bwd_kernel(const float* __restrict__ gT, float* __restrict__ g2, int D, int H,
+                                                                      int W, int tiles_w) {
+  __shared__ float s[CB][TS][PITCH];
+  const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
+  const int d0 = blockIdx.y * CB, b = blockIdx.z, h0 = th * TS, w0 = tw * TS;
+  const size_t L = (size_t)H * W;
+  for (int it = threadIdx.x; it < TS * TS * (CB / 4); it += MT_THREADS) {
+    const int pix = it / (CB / 4), g = it - pix * (CB / 4), py = pix / TS, px = pix - py * TS;
+    const int h = h0 + py, w = w0 + px;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (h < H && w < W) v = *reinterpret_cast<const float4*>(gT + ((size_t)b * L + (size_t)h * W + w) * D + d0 + g * 4);
+    s[g * 4][py][px] = v.x; s[g * 4 + 1][py][px] = v.y; s[g * 4 + 2][py][px] = v.z; s[g * 4 + 3][py][px] = v.w;
+  }
+  __syncthreads();
+  float* gb = g2 + (size_t)b * 2 * D * L;
+  {
+    const int ty = threadIdx.x / TS, tx = threadIdx.x % TS, h = h0 + ty, w = w0 + tx;
+    if (h < H && w < W)
+      for (int c = 0; c < CB; ++c) gb[(size_t)(d0 + c) * L + (size_t)h * W + w] = s[c][ty][tx];
+  }
+  {
+    const int ty = threadIdx.x % TS, tx = threadIdx.x / TS, h = h0 + ty, w = w0 + tx;
+    if (h < H && w < W)
+      for (int c = 0; c < CB; ++c) gb[((size_t)D + d0 + c) * L + (size_t)w * H + h] = s[c][ty][tx];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int LG_WAVES = 4;       // tokens in flight per workgroup (one wave each)
+constexpr int LG_TOK_BWD = 16;    // tokens walked by each wave of the backward kernel (d(gamma)/d(beta) accumulate in registers)
+
+template <typename T>
+__device__ __forceinline__ void ld4t(const T* p, float (&o)[4]) { Elt<T>::ld4(p, o); }
+
+__device__ __forceinline__ float wsum(float v) { return group_sum<WAVE>(v); }
+
+template <typename T, int D>
+__global__ __launch_bounds__(LG_WAVES* WAVE) void ln_gate_fwd_kernel(const float* __restrict__ x, const T* __restrict__ xz, size_t zs,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                      T* __restrict__ out, float* __restrict__ stats, size_t ntok,
+                                                                      float eps) {
+  constexpr int NJ = (D + 255) / 256;  // float4 pieces per lane; lanes beyond D / 4 idle when D < 256
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+  const bool act = lane * 4 < D;
+  const size_t tok = (size_t)blockIdx.x * LG_WAVES + wave;
+  if (tok >= ntok) return;
+  float v[NJ][4];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
+    if (act) Elt<float>::ld4(x + tok * D + j * 256 + lane * 4, v[j]);
+    sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+  }
+  const float mean = wsum(sum) * (1.f / D);
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float c = act ? v[j][i] - mean : 0.f; sq = fmaf(c, c, sq); }
+  const float rstd = rsqrtf(wsum(sq) * (1.f / D) + eps);
+  if (lane == 0) { stats[2 * tok] = mean; stats[2 * tok + 1] = rstd; }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int d = j * 256 + lane * 4;
+    if (!act) continue;
+    float z[4], g[4], be[4], o[4];
+    ld4t<T>(xz + tok * zs + D + d, z);
+    Elt<float>::ld4(gamma + d, g);
+    Elt<float>::ld4(beta + d, be);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float y = fmaf((v[j][i] - mean) * rstd, g[i], be[i]);
+      o[i] = y * (z[i] / (1.f + __expf(-z[i])));
+    }
+    Elt<T>::st4(out + tok * D + d, o);
+  }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(LG_WAVES* WAVE) void ln_gate_bwd_kernel(const T* __restrict__ gout, const float* __restrict__ x,
+                                                                      const T* __restrict__ xz, size_t zs, const float* __restrict__ gamma,
+                                                                      const float* __restrict__ beta, const float* __restrict__ stats,
+                                                                      float* __restrict__ gx, T* __restrict__ gxz, float* __restrict__ part,
+                                                                      size_t ntok) {
+  constexpr int NJ = (D + 255) / 256;
+  __shared__ float s_red[LG_WAVES][2][NJ * 256];
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+  const bool act = lane * 4 < D;
+  float dgam[NJ][4], dbet[NJ][4], gm[NJ][4], bt[NJ][4];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dgam[j][i] = 0.f; dbet[j][i] = 0.f; gm[j][i] = 0.f; bt[j][i] = 0.f; }
+    if (act) {
+      Elt<float>::ld4(gamma + j * 256 + lane * 4, gm[j]);
+      Elt<float>::ld4(beta + j * 256 + lane * 4, bt[j]);
+    }
+  }
+  const size_t tok0 = ((size_t)blockIdx.x * LG_WAVES + wave) * LG_TOK_BWD;
+  for (int t = 0; t < LG_TOK_BWD; ++t) {
+    const size_t tok = tok0 + t;
+    if (tok >= ntok) break;  // wave-uniform
+    const float mean = stats[2 * tok], rstd = stats[2 * tok + 1];
+    float xh[NJ][4], gxh[NJ][4];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int d = j * 256 + lane * 4;
+      float xv[4] = {mean, mean, mean, mean}, z[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f}, gz[4];
+      if (act) {
+        Elt<float>::ld4(x + tok * D + d, xv);
+        ld4t<T>(xz + tok * zs + D + d, z);
+        ld4t<T>(gout + tok * D + d, g);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xh[j][i] = (xv[i] - mean) * rstd;
+        const float y = fmaf(xh[j][i], gm[j][i], bt[j][i]);
+        const float sg = 1.f / (1.f + __expf(-z[i]));
+        const float gy = g[i] * (z[i] * sg);                      // through the gate
+        gz[i] = g[i] * y * (sg * (1.f + z[i] * (1.f - sg)));      // d SiLU(z)
+        dgam[j][i] = fmaf(gy, xh[j][i], dgam[j][i]);
+        dbet[j][i] += gy;
+        gxh[j][i] = gy * gm[j][i];
+        c1 += gxh[j][i];
+        c2 = fmaf(gxh[j][i], xh[j][i], c2);
+      }
+      if (act) Elt<T>::st4(gxz + tok * zs + D + d, gz);
+    }
+    c1 = wsum(c1) * (1.f / D);
+    c2 = wsum(c2) * (1.f / D);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = rstd * (gxh[j][i] - c1 - xh[j][i] * c2);
+      if (act) Elt<float>::st4(gx + tok * D + j * 256 + lane * 4, o);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s_red[wave][0][j * 256 + lane * 4 + i] = dgam[j][i]; s_red[wave][1][j * 256 + lane * 4 + i] = dbet[j][i]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += LG_WAVES * WAVE) {
+    const int which = i / D, d = i - which * D;  // (lanes with lane * 4 >= D wrote zeros beyond D: never read)
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < LG_WAVES; ++w) a += s_red[w][which][d];
+    part[((size_t)blockIdx.x * 2 + which) * D + d] = a;
+  }
+}
+
+}  // namespace
+
+extern "C" int tamtr_cross_merge_fwd(const float* y4, float* ymT, int B, int D, int H, int W, void* stream) {
+  if (!y4 || !ymT || B <= 0 || D <= 0 || H <= 0 || W <= 0) return TAMTR_EINVAL;
+  if (D % CB || B > 65535 || D / CB > 65535) return TAMTR_EUNSUP;
+  const int tiles_w = (W + TS - 1) / TS, tiles_h = (H + TS - 1) / TS;
+  hipLaunchKernelGGL(cross_merge_fwd_kernel, dim3(tiles_w * tiles_h, D / CB, B), dim3(MT_THREADS), 0, (hipStream_t)stream, y4, ymT, D, H,
+                     W, tiles_w);
+  return tamtr_launch_status();
+}
+
+extern "C" int tamtr_cross_merge_bwd(const float* gymT, float* g2, int B, int D, int H, int W, void* stream) {
+  if (!gymT || !g2 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return TAMTR_EINVAL;
+  if (D % CB || B > 65535 || D / CB > 65535) return TAMTR_EUNSUP;
+  const int tiles_w = (W + TS - 1) / TS, tiles_h = (H + TS - 1) / TS;
+  hipLaunchKernelGGL(cross_merge_bwd_kernel, dim3(tiles_w * tiles_h, D / CB, B), dim3(MT_THREADS), 0, (hipStream_t)stream, gymT, g2, D, H,
+                     W, tiles_w);
+  return tamtr_launch_status();
+}
+
+static int ln_gate_check(const void* a, const void* b, const void* c, long long ntok, int D, long long zs, int dtype) {
+  if (!a || !b || !c || ntok <= 0 || D <= 0 || zs < 2LL * D) return TAMTR_EINVAL;
+  if (dtype != TAMTR_F32 && dtype != TAMTR_BF16) return TAMTR_EINVAL;
+  if ((D != 64 && D != 128 && D != 256 && D != 512 && D != 1024) || zs % 4) return TAMTR_EUNSUP;
+  return TAMTR_OK;
+}
+
+extern "C" int tamtr_ln_gate_blocks(long long ntok) { return (int)((ntok + LG_WAVES * LG_TOK_BWD - 1) / (LG_WAVES * LG_TOK_BWD)); }
+
+#define LG_DISPATCH(KERNEL, T, ...)                                                                      \
+  switch (D) {                                                                                           \
+    case 64: hipLaunchKernelGGL((KERNEL<T, 64>), grid, dim3(LG_WAVES * WAVE), 0, s, __VA_ARGS__); break;   \
+    case 128: hipLaunchKernelGGL((KERNEL<T, 128>), grid, dim3(LG_WAVES * WAVE), 0, s, __VA_ARGS__); break; \
+    case 256: hipLaunchKernelGGL((KERNEL<T, 256>), grid, dim3(LG_WAVES * WAVE), 0, s, __VA_ARGS__); break; \
+    case 512: hipLaunchKernelGGL((KERNEL<T, 512>), grid, dim3(LG_WAVES * WAVE), 0, s, __VA_ARGS__); break; \
+    default: hipLaunchKernelGGL((KERNEL<T, 1024>), grid, dim3(LG_WAVES * WAVE), 0, s, __VA_ARGS__); break; \
+  }
+
+extern "C" int tamtr_ln_gate_fwd(const float* x, const void* xz, long long xz_token_stride, const float* gamma, const float* beta,
+                                 void* out, float* stats, long long ntok, int D, float eps, int dtype, void* stream) {
+  const int rc = ln_gate_check(x, xz, out, ntok, D, xz_token_stride, dtype);
+  if (rc) return rc;
+  if (!gamma || !beta || !stats) return TAMTR_EINVAL;
+  const dim3 grid((unsigned)((ntok + LG_WAVES - 1) / LG_WAVES));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t zs = (size_t)xz_token_stride, nt = (size_t)ntok;
+  if (dtype == TAMTR_F32) { LG_DISPATCH(ln_gate_fwd_kernel, float, x, (const float*)xz, zs, gamma, beta, (float*)out, stats, nt, eps) }
+  else { LG_DISPATCH(ln_gate_fwd_kernel, bf16_t, x, (const bf16_t*)xz, zs, gamma, beta, (bf16_t*)out, stats, nt, eps) }
+  return tamtr_launch_status();
+}
+
+extern "C" int tamtr_ln_gate_bwd(const void* gout, const float* x, const void* xz, long long xz_token_stride, const float* gamma,
+                                 const float* beta, const float* stats, float* gx, void* gxz, float* partials, long long ntok, int D,
+                                 int dtype, void* stream) {
+  const int rc = ln_gate_check(gout, x, xz, ntok, D, xz_token_stride, dtype);
+  if (rc) return rc;
+  if (!gamma || !beta || !stats || !gx || !gxz || !partials) return TAMTR_EINVAL;
+  const dim3 grid((unsigned)tamtr_ln_gate_blocks(ntok));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t zs = (size_t)xz_token_stride, nt = (size_t)ntok;
+  if (dtype == TAMTR_F32) {
+    LG_DISPATCH(ln_gate_bwd_kernel, float, (const float*)gout, x, (const float*)xz, zs, gamma, beta, stats, gx, (float*)gxz, partials, nt)
+  } else {
+    LG_DISPATCH(ln_gate_bwd_kernel, bf16_t, (const bf16_t*)gout, x, (const bf16_t*)xz, zs, gamma, beta, stats, gx, (bf16_t*)gxz, partials, nt)
+  }
+  return tamtr_launch_status();
+}

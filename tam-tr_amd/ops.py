@@ -532,7 +532,7 @@ class _SelectiveScanCrossMerged(torch.autograd.Function):
     slice/add autograd graph of the merge cost 5.4 ms per level-0 block: 1.7 GB zero fills, copies and adds)."""
 
     @staticmethod
-    def forward(ctx, u2, dtr, Wdt, A, Bm, Cm, D, dbias, H, W):
+    def forward(ctx, u2, dtr, Wdt, A, Bm, Cm, D, dbias, H, W, token_major=False):
         require_gpu(u2, dtr, Wdt, A, Bm, Cm, D, dbias)
         u2, dtr, Wdt, A, Bm, Cm, D, dbias = (_c(t.float()) for t in (u2, dtr, Wdt, A, Bm, Cm, D, dbias))
         Bn, _, Dk, L = u2.shape
@@ -544,7 +544,11 @@ class _SelectiveScanCrossMerged(torch.autograd.Function):
         call('tamtr_selective_scan_dtproj_fwd', ptr(u2), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(dbias), ptr(y),
              ptr(hstate), Bn, K, Dk, N, R, L, 1, stream_ptr())
         ctx.save_for_backward(u2, dtr, Wdt, A, Bm, Cm, D, dbias, hstate)
-        ctx.hw = (H, W)
+        ctx.hw = (H, W, token_major)
+        if token_major:  # CrossMerge straight into [B, L, Dk] (what out_norm / out_proj consume): one tiled-transpose kernel
+            ymT = torch.empty(Bn, L, Dk, device=u2.device, dtype=torch.float32)
+            call('tamtr_cross_merge_fwd', ptr(y), ptr(ymT), Bn, Dk, H, W, stream_ptr())
+            return ymT
         ym = y[:, 0] + y[:, 2]
         ym += (y[:, 1] + y[:, 3]).view(Bn, Dk, W, H).transpose(2, 3).reshape(Bn, Dk, L)
         return ym
@@ -552,13 +556,16 @@ class _SelectiveScanCrossMerged(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gm):
         u2, dtr, Wdt, A, Bm, Cm, D, dbias, hstate = ctx.saved_tensors
-        H, W = ctx.hw
+        H, W, token_major = ctx.hw
         Bn, K, R, L = dtr.shape
         Dk, N = u2.shape[2], A.shape[1]
         KD = K * Dk
         g2 = torch.empty(Bn, 2, Dk, L, device=u2.device, dtype=torch.float32)
-        g2[:, 0] = gm
-        g2[:, 1].view(Bn, Dk, W, H).copy_(gm.view(Bn, Dk, H, W).transpose(2, 3))
+        if token_major:
+            call('tamtr_cross_merge_bwd', ptr(_c(gm.float())), ptr(g2), Bn, Dk, H, W, stream_ptr())
+        else:
+            g2[:, 0] = gm
+            g2[:, 1].view(Bn, Dk, W, H).copy_(gm.view(Bn, Dk, H, W).transpose(2, 3))
         gu = torch.empty(Bn, KD, L, device=u2.device, dtype=torch.float32)
         gdelta = torch.empty(Bn, KD, L, device=u2.device, dtype=torch.float32)
         gdtr = torch.empty_like(dtr)
@@ -571,12 +578,52 @@ class _SelectiveScanCrossMerged(torch.autograd.Function):
              ptr(hstate), ptr(gu), ptr(gdelta), ptr(gdtr), ptr(gW), ptr(gA), ptr(gB), ptr(gC), ptr(gD), ptr(gbias), ptr(ws), Bn, K,
              Dk, N, R, L, 3, stream_ptr())
         g4 = gu.view(Bn, 4, Dk, L)
-        return g4[:, :2] + g4[:, 2:], gdtr, gW, gA, gB, gC, gD, gbias, None, None
+        return g4[:, :2] + g4[:, 2:], gdtr, gW, gA, gB, gC, gD, gbias, None, None, None
 
 
-def selective_scan_cross_merged(u2, dtr, Wdt, A, Bm, Cm, D, delta_bias, H, W):
-    """selective_scan_cross followed by the cross-merge: returns [B, Dk, H*W] in row-major pixel order."""
-    return _SelectiveScanCrossMerged.apply(u2, dtr, Wdt, A, Bm, Cm, D, delta_bias, H, W)
+def selective_scan_cross_merged(u2, dtr, Wdt, A, Bm, Cm, D, delta_bias, H, W, token_major=False):
+    """selective_scan_cross followed by the cross-merge: returns [B, Dk, H*W] in row-major pixel order, or with
+    token_major=True [B, H*W, Dk] (needs Dk % 32 == 0)."""
+    return _SelectiveScanCrossMerged.apply(u2, dtr, Wdt, A, Bm, Cm, D, delta_bias, H, W, token_major)
+
+
+class _LNGate(torch.autograd.Function):
+    """out = LayerNorm(x; gamma, beta) * SiLU(z) with z = the second half of the channels-last in_proj output xz [B,H,W,2D]
+    (vmamba.py:1005-1008,1029-1036) - csrc/ss2d_out.hip.  x fp32 [B, L, D] -> out [B, L, D] in xz's dtype."""
+
+    @staticmethod
+    def forward(ctx, x, xz, gamma, beta, eps):
+        require_gpu(x, xz, gamma, beta)
+        x, xz = _c(x.float()), _c(xz)
+        D = x.shape[-1]
+        ntok = x.numel() // D
+        g32, b32 = _c(gamma.float()), _c(beta.float())
+        out = torch.empty(x.shape, device=x.device, dtype=xz.dtype)
+        stats = torch.empty(ntok, 2, device=x.device, dtype=torch.float32)
+        call('tamtr_ln_gate_fwd', ptr(x), ptr(xz), xz.shape[-1], ptr(g32), ptr(b32), ptr(out), ptr(stats), ntok, D, float(eps),
+             dtype_code(xz), stream_ptr())
+        ctx.save_for_backward(x, xz, g32, b32, stats)
+        ctx.cfg = (gamma.dtype, beta.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, xz, g32, b32, stats = ctx.saved_tensors
+        D = x.shape[-1]
+        ntok = x.numel() // D
+        gout = _c(gout.to(xz.dtype))
+        gx = torch.empty_like(x)
+        gxz = torch.zeros_like(xz)  # the xi half gets its gradient from the conv path; autograd adds the two
+        nblk = _lib.lib().tamtr_ln_gate_blocks(ntok)
+        part = torch.empty(nblk, 2, D, device=x.device, dtype=torch.float32)
+        call('tamtr_ln_gate_bwd', ptr(gout), ptr(x), ptr(xz), xz.shape[-1], ptr(g32), ptr(b32), ptr(stats), ptr(gx), ptr(gxz), ptr(part),
+             ntok, D, dtype_code(xz), stream_ptr())
+        gsum = part.sum(0)
+        return gx, gxz, gsum[0].to(ctx.cfg[0]), gsum[1].to(ctx.cfg[1]), None
+
+
+def ln_gate(x, xz, gamma, beta, eps=1e-5):
+    return _LNGate.apply(x, xz, gamma, beta, eps)
 
 
 def selective_scan_cross(u2, dtr, Wdt, A, Bm, Cm, D, delta_bias):

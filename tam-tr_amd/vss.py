@@ -85,7 +85,6 @@ class SS2D(nn.Module):
         B, H, W, _ = x.shape
         xz = self.in_proj(x)
         xi, z = xz.chunk(2, -1)
-        z = F.silu(z)
         K, R, N, L, D = 4, self.dt_rank, self.d_state, H * W, self.d_inner
         fused_front = not _EINSUM_DT and D % 32 == 0 and self.conv2d.kernel_size == (3, 3)
         xc = None if fused_front else self.conv2d(xi.permute(0, 3, 1, 2).contiguous())  # [B,D,H,W]
@@ -118,10 +117,14 @@ class SS2D(nn.Module):
             # cross-merge (csms6s.py:26-34) on un-reversed outputs: no flips left
             y = ys[:, 0] + ys[:, 2] + (ys[:, 1] + ys[:, 3]).view(B, D, W, H).transpose(2, 3).reshape(B, D, L)
         else:  # scan + cross-merge as one autograd node (the merged gradient feeds the scan backward directly)
+            fused_back = D in (64, 128, 256, 512, 1024)
             y = ops.selective_scan_cross_merged(u2, dtr, self.dt_projs_weight.float().reshape(K * D, R), As, Bs, Cs, self.Ds.float(),
-                                                self.dt_projs_bias.float().reshape(-1), H, W)
+                                                self.dt_projs_bias.float().reshape(-1), H, W, token_major=fused_back)
+            if fused_back:  # y is [B, L, D]: out_norm + SiLU(z) gate in one kernel, z read from xz where it lies
+                g = ops.ln_gate(y, xz, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps)
+                return self.out_proj(g.view(B, H, W, D))
         y = self.out_norm(y.transpose(1, 2)).view(B, H, W, -1)
-        return self.out_proj((y * z).to(x.dtype))
+        return self.out_proj((y * F.silu(z)).to(x.dtype))
 
 
 class Mlp(nn.Module):

@@ -278,3 +278,46 @@ def test_dwconv_argument_checks(ops):
         ops.dwconv_silu_cross(torch.zeros(1, 4, 4, 48).cuda(), torch.zeros(24, 1, 3, 3).cuda(), None, 24)   # D % 32 != 0
     with pytest.raises(tamtr_amd.TamtrHipError):
         ops.dwconv_silu_cross(torch.zeros(1, 4, 4, 64), torch.zeros(32, 1, 3, 3), None, 32)                # CPU tensors
+
+
+@pytest.mark.parametrize('D,dt', [(64, torch.float32), (256, torch.float32), (1024, torch.float32), (128, torch.bfloat16), (512, torch.bfloat16)])
+def test_ln_gate(ops, D, dt):
+    """out_norm + SiLU(z) gate (vmamba.py:1005-1008,1029-1036) in one kernel vs LayerNorm * silu in torch on the CPU: forward and the
+    gradients of x, z (inside xz), gamma, beta."""
+    import torch.nn.functional as F
+    B, H, W = 2, 5, 7
+    x = rnd((B, H * W, D), 1) * 1.5 + 0.3
+    xz = rnd((B, H, W, 2 * D), 2).to(dt).float()
+    gamma, beta = 1 + 0.2 * rnd((D,), 3), 0.1 * rnd((D,), 4)
+    cot = rnd((B, H * W, D), 5).to(dt).float()
+    xr, zr, gr, br = x.clone().requires_grad_(), xz.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    ref = F.layer_norm(xr, (D,), gr, br, 1e-5) * F.silu(zr[..., D:]).reshape(B, H * W, D)
+    (ref * cot).sum().backward()
+    xd, zd, gd, bd = dev(x).requires_grad_(), dev(xz, dt).requires_grad_(), dev(gamma).requires_grad_(), dev(beta).requires_grad_()
+    out = ops.ln_gate(xd, zd, gd, bd, 1e-5)
+    assert out.dtype == dt and out.shape == (B, H * W, D)
+    (out.float() * dev(cot)).sum().backward()
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    assert_close(out.float(), ref, tol, tol, 'ln_gate out')
+    assert_close(xd.grad, xr.grad, 5 * tol, 5 * tol, 'ln_gate dx')
+    assert_close(zd.grad.float(), zr.grad, 5 * tol, 5 * tol, 'ln_gate dxz')   # first half (xi) stays zero
+    assert_close(gd.grad, gr.grad, 5 * tol, 5 * tol * (B * H * W) ** 0.5, 'ln_gate dgamma')
+    assert_close(bd.grad, br.grad, 5 * tol, 5 * tol * (B * H * W) ** 0.5, 'ln_gate dbeta')
+
+
+@pytest.mark.parametrize('B,D,H,W', [(2, 32, 16, 16), (1, 64, 13, 21), (1, 32, 40, 8)])
+def test_cross_merge_kernels(ops, B, D, H, W):
+    """CrossMerge (csms6s.py:26-34) into token-major layout and its transpose: pure data movement + adds, exact."""
+    from tamtr_amd._lib import call, ptr, stream_ptr
+    L = H * W
+    y4 = dev(rnd((B, 4, D, L), 1))
+    ymT = torch.empty(B, L, D, device='cuda')
+    call('tamtr_cross_merge_fwd', ptr(y4), ptr(ymT), B, D, H, W, stream_ptr())
+    ref = y4[:, 0] + y4[:, 2] + (y4[:, 1] + y4[:, 3]).view(B, D, W, H).transpose(2, 3).reshape(B, D, L)
+    assert_close(ymT, ref.transpose(1, 2), 1e-6, 1e-6, 'cross merge fwd')
+    g = dev(rnd((B, L, D), 2))
+    g2 = torch.empty(B, 2, D, L, device='cuda')
+    call('tamtr_cross_merge_bwd', ptr(g), ptr(g2), B, D, H, W, stream_ptr())
+    gm = g.transpose(1, 2)
+    assert torch.equal(g2[:, 0], gm.contiguous())
+    assert torch.equal(g2[:, 1], gm.reshape(B, D, H, W).transpose(2, 3).reshape(B, D, L))
