@@ -245,6 +245,15 @@ int tamtr_ln_gate_bwd(const void* gout, const float* x, const void* xz, long lon
                       const float* beta, const float* stats, float* gx, void* gxz, float* partials, long long ntok, int D, int dtype,
                       void* stream);
 
+/*      tamtr_layernorm_* : LayerNorm over the channel axis of a token-major map, VSSBlock.norm / norm2
+ *      (VManba/vmamba.py:1190,1222,1239-1254).  x, out, gout, gx (T) [ntok, D]; gamma, beta f32 [D]; stats f32 [ntok, 2];
+ *      partials f32 [tamtr_ln_gate_blocks(ntok), 2, D] (per-workgroup d(gamma), d(beta) sums).  D in {32,...,1024} powers of two.
+ */
+int tamtr_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* out, float* stats, long long ntok, int D,
+                        float eps, int dtype, void* stream);
+int tamtr_layernorm_bwd(const void* gout, const void* x, const float* gamma, const float* stats, void* gx, float* partials,
+                        long long ntok, int D, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -203,6 +203,110 @@ __global__ __launch_bounds__(LG_WAVES* WAVE) void ln_gate_bwd_kernel(const T* __
   }
 }
 
+// plain LayerNorm over the channel axis of a token-major map (VSSBlock.norm / norm2, vmamba.py:1190,1222): same wave-per-token
+// scheme; reads and writes the activation dtype directly (autocast otherwise wraps the fp32 LayerNorm kernel in two casts)
+template <typename T, int D>
+__global__ __launch_bounds__(LG_WAVES* WAVE) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, T* __restrict__ out,
+                                                                 float* __restrict__ stats, size_t ntok, float eps) {
+  constexpr int NJ = (D + 255) / 256;
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+  const bool act = lane * 4 < D;
+  const size_t tok = (size_t)blockIdx.x * LG_WAVES + wave;
+  if (tok >= ntok) return;
+  float v[NJ][4];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
+    if (act) ld4t<T>(x + tok * D + j * 256 + lane * 4, v[j]);
+    sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+  }
+  const float mean = wsum(sum) * (1.f / D);
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float c = act ? v[j][i] - mean : 0.f; sq = fmaf(c, c, sq); }
+  const float rstd = rsqrtf(wsum(sq) * (1.f / D) + eps);
+  if (lane == 0) { stats[2 * tok] = mean; stats[2 * tok + 1] = rstd; }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int d = j * 256 + lane * 4;
+    if (!act) continue;
+    float g[4], be[4], o[4];
+    Elt<float>::ld4(gamma + d, g);
+    Elt<float>::ld4(beta + d, be);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = fmaf((v[j][i] - mean) * rstd, g[i], be[i]);
+    Elt<T>::st4(out + tok * D + d, o);
+  }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(LG_WAVES* WAVE) void ln_bwd_kernel(const T* __restrict__ gout, const T* __restrict__ x,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                                 T* __restrict__ gx, float* __restrict__ part, size_t ntok) {
+  constexpr int NJ = (D + 255) / 256;
+  __shared__ float s_red[LG_WAVES][2][NJ * 256];
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+  const bool act = lane * 4 < D;
+  float dgam[NJ][4], dbet[NJ][4], gm[NJ][4];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dgam[j][i] = 0.f; dbet[j][i] = 0.f; gm[j][i] = 0.f; }
+    if (act) Elt<float>::ld4(gamma + j * 256 + lane * 4, gm[j]);
+  }
+  const size_t tok0 = ((size_t)blockIdx.x * LG_WAVES + wave) * LG_TOK_BWD;
+  for (int t = 0; t < LG_TOK_BWD; ++t) {
+    const size_t tok = tok0 + t;
+    if (tok >= ntok) break;  // wave-uniform
+    const float mean = stats[2 * tok], rstd = stats[2 * tok + 1];
+    float xh[NJ][4], gxh[NJ][4];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int d = j * 256 + lane * 4;
+      float xv[4] = {mean, mean, mean, mean}, g[4] = {0.f, 0.f, 0.f, 0.f};
+      if (act) {
+        ld4t<T>(x + tok * D + d, xv);
+        ld4t<T>(gout + tok * D + d, g);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xh[j][i] = (xv[i] - mean) * rstd;
+        dgam[j][i] = fmaf(g[i], xh[j][i], dgam[j][i]);
+        dbet[j][i] += g[i];
+        gxh[j][i] = g[i] * gm[j][i];
+        c1 += gxh[j][i];
+        c2 = fmaf(gxh[j][i], xh[j][i], c2);
+      }
+    }
+    c1 = wsum(c1) * (1.f / D);
+    c2 = wsum(c2) * (1.f / D);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = rstd * (gxh[j][i] - c1 - xh[j][i] * c2);
+      if (act) Elt<T>::st4(gx + tok * D + j * 256 + lane * 4, o);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s_red[wave][0][j * 256 + lane * 4 + i] = dgam[j][i]; s_red[wave][1][j * 256 + lane * 4 + i] = dbet[j][i]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += LG_WAVES * WAVE) {
+    const int which = i / D, d = i - which * D;
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < LG_WAVES; ++w) a += s_red[w][which][d];
+    part[((size_t)blockIdx.x * 2 + which) * D + d] = a;
+  }
+}
+
 }  // namespace
 
 extern "C" int tamtr_cross_merge_fwd(const float* y4, float* ymT, int B, int D, int H, int W, void* stream) {
@@ -268,5 +372,48 @@ extern "C" int tamtr_ln_gate_bwd(const void* gout, const float* x, const void* x
   } else {
     LG_DISPATCH(ln_gate_bwd_kernel, bf16_t, (const bf16_t*)gout, x, (const bf16_t*)xz, zs, gamma, beta, stats, gx, (bf16_t*)gxz, partials, nt)
   }
+  return tamtr_launch_status();
+}
+
+#define LN_DISPATCH(KERNEL, T, ...)                                                                      \
+  switch (D) {                                                                                           \
+    case 32: hipLaunchKernelGGL((KERNEL<T, 32>), grid, dim3(LG_WAVES * WAVE), 0, s, __VA_ARGS__); break;   \
+    case 64: hipLaunchKernelGGL((KERNEL<T, 64>), grid, dim3(LG_WAVES * WAVE), 0, s, __VA_ARGS__); break;   \
+    case 128: hipLaunchKernelGGL((KERNEL<T, 128>), grid, dim3(LG_WAVES * WAVE), 0, s, __VA_ARGS__); break; \
+    case 256: hipLaunchKernelGGL((KERNEL<T, 256>), grid, dim3(LG_WAVES * WAVE), 0, s, __VA_ARGS__); break; \
+    case 512: hipLaunchKernelGGL((KERNEL<T, 512>), grid, dim3(LG_WAVES * WAVE), 0, s, __VA_ARGS__); break; \
+    default: hipLaunchKernelGGL((KERNEL<T, 1024>), grid, dim3(LG_WAVES * WAVE), 0, s, __VA_ARGS__); break; \
+  }
+
+static int ln_check(const void* a, const void* b, const void* c, long long ntok, int D, int dtype) {
+  if (!a || !b || !c || ntok <= 0 || D <= 0) return TAMTR_EINVAL;
+  if (dtype != TAMTR_F32 && dtype != TAMTR_BF16) return TAMTR_EINVAL;
+  if (D != 32 && D != 64 && D != 128 && D != 256 && D != 512 && D != 1024) return TAMTR_EUNSUP;
+  return TAMTR_OK;
+}
+
+extern "C" int tamtr_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* out, float* stats, long long ntok, int D,
+                                   float eps, int dtype, void* stream) {
+  const int rc = ln_check(x, gamma, out, ntok, D, dtype);
+  if (rc) return rc;
+  if (!beta || !stats) return TAMTR_EINVAL;
+  const dim3 grid((unsigned)((ntok + LG_WAVES - 1) / LG_WAVES));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t nt = (size_t)ntok;
+  if (dtype == TAMTR_F32) { LN_DISPATCH(ln_fwd_kernel, float, (const float*)x, gamma, beta, (float*)out, stats, nt, eps) }
+  else { LN_DISPATCH(ln_fwd_kernel, bf16_t, (const bf16_t*)x, gamma, beta, (bf16_t*)out, stats, nt, eps) }
+  return tamtr_launch_status();
+}
+
+extern "C" int tamtr_layernorm_bwd(const void* gout, const void* x, const float* gamma, const float* stats, void* gx, float* partials,
+                                   long long ntok, int D, int dtype, void* stream) {
+  const int rc = ln_check(gout, x, gamma, ntok, D, dtype);
+  if (rc) return rc;
+  if (!stats || !gx || !partials) return TAMTR_EINVAL;
+  const dim3 grid((unsigned)tamtr_ln_gate_blocks(ntok));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t nt = (size_t)ntok;
+  if (dtype == TAMTR_F32) { LN_DISPATCH(ln_bwd_kernel, float, (const float*)gout, (const float*)x, gamma, stats, (float*)gx, partials, nt) }
+  else { LN_DISPATCH(ln_bwd_kernel, bf16_t, (const bf16_t*)gout, (const bf16_t*)x, gamma, stats, (bf16_t*)gx, partials, nt) }
   return tamtr_launch_status();
 }

@@ -684,3 +684,37 @@ def cpam(x):
     """CPAM (extra_modules/block.py:271-308): x [B,C,H,W] fp32/bf16 -> channel gate sigmoid(up2(maxpool3s2(x))) * x followed by
     the per-chunk (8 chunks) spatial gate sigmoid(max over the chunk's channels).  One fused kernel after the pool."""
     return _CPAM.apply(x)
+
+
+class _LayerNorm(torch.autograd.Function):
+    """LayerNorm over the last axis in the activation's own dtype (VSSBlock.norm / norm2) - csrc/ss2d_out.hip."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        require_gpu(x, gamma, beta)
+        x = _c(x)
+        D = x.shape[-1]
+        ntok = x.numel() // D
+        g32, b32 = _c(gamma.float()), _c(beta.float())
+        out = torch.empty_like(x)
+        stats = torch.empty(ntok, 2, device=x.device, dtype=torch.float32)
+        call('tamtr_layernorm_fwd', ptr(x), ptr(g32), ptr(b32), ptr(out), ptr(stats), ntok, D, float(eps), dtype_code(x), stream_ptr())
+        ctx.save_for_backward(x, g32, stats)
+        ctx.cfg = (gamma.dtype, beta.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, g32, stats = ctx.saved_tensors
+        D = x.shape[-1]
+        ntok = x.numel() // D
+        gout = _c(gout.to(x.dtype))
+        gx = torch.empty_like(x)
+        part = torch.empty(_lib.lib().tamtr_ln_gate_blocks(ntok), 2, D, device=x.device, dtype=torch.float32)
+        call('tamtr_layernorm_bwd', ptr(gout), ptr(x), ptr(g32), ptr(stats), ptr(gx), ptr(part), ntok, D, dtype_code(x), stream_ptr())
+        gsum = part.sum(0)
+        return gx, gsum[0].to(ctx.cfg[0]), gsum[1].to(ctx.cfg[1]), None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return _LayerNorm.apply(x, gamma, beta, eps)

@@ -150,6 +150,12 @@ class VSSBlock(nn.Module):
         self.norm2 = nn.LayerNorm(hidden_dim)
         self.mlp = Mlp(hidden_dim, int(hidden_dim * mlp_ratio))
 
+    @staticmethod
+    def _ln(norm, x):
+        if x.is_cuda and x.shape[-1] in (32, 64, 128, 256, 512, 1024) and x.dtype in (torch.float32, torch.bfloat16):
+            return ops.layer_norm(x, norm.weight, norm.bias, norm.eps)  # activation dtype in and out (no autocast casts around it)
+        return norm(x)
+
     def forward(self, x):
-        x = x + self.drop_path(self.op(self.norm(x)))
-        return x + self.drop_path(self.mlp(self.norm2(x)))
+        x = x + self.drop_path(self.op(self._ln(self.norm, x)))
+        return x + self.drop_path(self.mlp(self._ln(self.norm2, x)))

@@ -321,3 +321,25 @@ def test_cross_merge_kernels(ops, B, D, H, W):
     gm = g.transpose(1, 2)
     assert torch.equal(g2[:, 0], gm.contiguous())
     assert torch.equal(g2[:, 1], gm.reshape(B, D, H, W).transpose(2, 3).reshape(B, D, L))
+
+
+@pytest.mark.parametrize('D,dt', [(32, torch.float32), (128, torch.float32), (512, torch.float32), (256, torch.bfloat16)])
+def test_layer_norm_kernel(ops, D, dt):
+    """VSSBlock.norm / norm2 (vmamba.py:1190,1222): wave-per-token LayerNorm in the activation dtype vs F.layer_norm on the CPU."""
+    import torch.nn.functional as F
+    n = 211
+    x = (rnd((n, D), 1) * 2 + 0.5).to(dt).float()
+    gamma, beta = 1 + 0.2 * rnd((D,), 2), 0.1 * rnd((D,), 3)
+    cot = rnd((n, D), 4).to(dt).float()
+    xr, gr, br = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    ref = F.layer_norm(xr, (D,), gr, br, 1e-5)
+    (ref * cot).sum().backward()
+    xd, gd, bd = dev(x, dt).requires_grad_(), dev(gamma).requires_grad_(), dev(beta).requires_grad_()
+    out = ops.layer_norm(xd, gd, bd, 1e-5)
+    assert out.dtype == dt
+    (out.float() * dev(cot)).sum().backward()
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    assert_close(out.float(), ref, tol, tol, 'ln out')
+    assert_close(xd.grad.float(), xr.grad, 5 * tol, 5 * tol, 'ln dx')
+    assert_close(gd.grad, gr.grad, 5 * tol, 5 * tol * n ** 0.5, 'ln dgamma')
+    assert_close(bd.grad, br.grad, 5 * tol, 5 * tol * n ** 0.5, 'ln dbeta')
