@@ -187,6 +187,30 @@ __device__ __forceinline__ void stage_dtr(const float* __restrict__ Rp, int R, i
   }
 }
 
+// acc[i] += sum_q W[q] * s_dtr[q][4*lane + i]: the factors are walked in blocks of 8 so that the 8 tile reads (and the two
+// broadcast reads of the weights) of a block are in flight together; a runtime-R loop of single reads paid one LDS round trip
+// per factor (~300 cycles each with every wave of the CU doing the same)
+__device__ __forceinline__ void dtproj_row(const float* __restrict__ Wrow, const float (*s_dtr)[CHUNK], int R, int lane, float (&acc)[ITEMS]) {
+  int q = 0;
+  for (; q + 8 <= R; q += 8) {
+    const float4 w0 = *reinterpret_cast<const float4*>(Wrow + q), w1 = *reinterpret_cast<const float4*>(Wrow + q + 4);
+    const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    float4 f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = *reinterpret_cast<const float4*>(&s_dtr[q + j][lane * ITEMS]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc[0] = fmaf(w[j], f[j].x, acc[0]); acc[1] = fmaf(w[j], f[j].y, acc[1]);
+      acc[2] = fmaf(w[j], f[j].z, acc[2]); acc[3] = fmaf(w[j], f[j].w, acc[3]);
+    }
+  }
+  for (; q < R; ++q) {
+    const float w = Wrow[q];
+    const float4 f = *reinterpret_cast<const float4*>(&s_dtr[q][lane * ITEMS]);
+    acc[0] = fmaf(w, f.x, acc[0]); acc[1] = fmaf(w, f.y, acc[1]); acc[2] = fmaf(w, f.z, acc[2]); acc[3] = fmaf(w, f.w, acc[3]);
+  }
+}
+
 // sum over the 64 lanes, valid in lane 63 (row_shr 1,2,4,8 + row_bcast 15,31: no LDS round trip)
 __device__ __forceinline__ float wave_sum_dpp(float v) {
   v += dpp<0x111, 0xf>(0.f, v); v += dpp<0x112, 0xf>(0.f, v); v += dpp<0x114, 0xf>(0.f, v); v += dpp<0x118, 0xf>(0.f, v);
@@ -241,11 +265,7 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
     load4<VEC>(up, t, L, uu, 0.f, rev);
     if (dtr) {  // delta_t = <Wdt[kd, :], dtr[:, t]>: the [B, 4*d_inner, L] delta tensor of the reference is never materialised
       dt[0] = dt[1] = dt[2] = dt[3] = 0.f;
-      for (int r = 0; r < R; ++r) {
-        const float w = s_W[wave * RMAX + r];
-        const float4 f = *reinterpret_cast<const float4*>(&s_dtr[r][lane * ITEMS]);
-        dt[0] = fmaf(w, f.x, dt[0]); dt[1] = fmaf(w, f.y, dt[1]); dt[2] = fmaf(w, f.z, dt[2]); dt[3] = fmaf(w, f.w, dt[3]);
-      }
+      dtproj_row(s_W + wave * RMAX, s_dtr, R, lane, dt);
     } else {
       load4<VEC>(dp, t, L, dt, 0.f, rev);
     }
@@ -284,6 +304,16 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
   }
 }
 
+// In-kernel phase timing (build with -DSCAN_STAMP through tools/build_scan_variant.sh; tools/scan_stamps.py reads the sums that
+// wave 0 of workgroup (0, 0) leaves in the first floats of gu): s_memtime deltas accumulated per phase.
+#ifdef SCAN_STAMP
+#define STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#define STAMP(i) { unsigned long long st_now; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory"); st_acc[i] += st_now - st_last; st_last = st_now; }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#endif
+
 // Backward: BWD_WAVES waves x BWD_RPW rows each = BWD_ROWS rows of one (b, k) group per workgroup.
 template <bool VEC, int STG>
 __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_bwd_kernel(
@@ -300,6 +330,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
   float(*s_dC)[CHUNK] = sC;
   __shared__ float s_A[BWD_WAVES][BWD_RPW][NS], s_carry[BWD_WAVES][BWD_RPW][NS], s_dA[BWD_WAVES][BWD_RPW][NS];
   __shared__ float s_dD[BWD_WAVES][BWD_RPW], s_db[BWD_WAVES][BWD_RPW];
+  __shared__ float s_rc[BWD_WAVES][BWD_RPW][2];  // D and delta bias of the wave's rows (as scalar loads they missed the scalar cache: ~1 us per row)
   extern __shared__ float s_dyn[];  // fused dt projection: [R][CHUNK] factors | [BWD_ROWS][RMAX] Wdt rows | [BWD_ROWS][RMAX] gWdt sums
   float(*s_dtr)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(s_dyn);
   float* s_W = s_dyn + (size_t)R * CHUNK;
@@ -322,13 +353,15 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
   for (int r = 0; r < BWD_RPW; ++r) {
     const int kd = k * Dk + min(d0 + r, Dk - 1);
     if (lane < NS) { s_A[wave][r][lane] = Am[(size_t)kd * NS + lane]; s_carry[wave][r][lane] = 0.f; s_dA[wave][r][lane] = 0.f; }
-    if (lane == 0) { s_dD[wave][r] = 0.f; s_db[wave][r] = 0.f; }
+    if (lane == 0) { s_dD[wave][r] = 0.f; s_db[wave][r] = 0.f; s_rc[wave][r][0] = Dv[kd]; s_rc[wave][r][1] = dbias[kd]; }
     if (dtr && lane < R) { s_W[(wave * BWD_RPW + r) * RMAX + lane] = Wdt[(size_t)kd * R + lane]; s_gW[(wave * BWD_RPW + r) * RMAX + lane] = 0.f; }
   }
   const float* Rp = dtr ? dtr + (size_t)bk * R * L : nullptr;
 
+  STAMP_DECL
   for (int c = nchunk - 1; c >= 0; --c) {
     __syncthreads();  // previous chunk's tiles fully consumed / flushed
+    STAMP(0)  // 0: waiting at the chunk-top barrier
     // chunk-entry states of this wave's rows: 16 consecutive floats per row, requested now and consumed after the staging
     // barrier (read per state as wave-uniform scalars they cost ~8 % of the kernel in s_waitcnt on HBM-missing s_loads)
     if (h0_staged) {
@@ -342,6 +375,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
     stage_bc<BWD_WAVES * WAVE>(Bp, Cp, c * CHUNK, L, sB, sC, VEC, rev);
     if (dtr) stage_dtr<BWD_WAVES * WAVE>(Rp, R, c * CHUNK, L, s_dtr, VEC, rev);
     __syncthreads();
+    STAMP(1)  // 1: staging of the B/C/dt tiles + barrier
     const int t = c * CHUNK + lane * ITEMS;
     // The 16 states are walked in groups of STG: the dB/dC register tile is [STG][ITEMS] x 2 instead of [16][ITEMS] x 2 and
     // only STG states are in flight, which is what lets two waves share a SIMD (<= 256 VGPR, no AGPR shuttling, no scratch).
@@ -363,36 +397,52 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
         if (d < Dk) {  // wave-uniform
           const int kd = k * Dk + d;
           const size_t row = (size_t)(bk / K) * K * Dk + kd;
-          const float Dd = Dv[kd], bias = dbias[kd];
+          const float Dd = s_rc[wave][r][0], bias = s_rc[wave][r][1];
           const float* An = s_A[wave][r];
           float* carry = s_carry[wave][r];
           float uu[ITEMS], dl[ITEMS], dt[ITEMS], g[ITEMS], ddt[ITEMS], du[ITEMS], dtu[ITEMS];
           const float* up = xmode ? u + (((size_t)(bk / K) * 2 + (k & 1)) * Dk + d) * L : u + row * L;
+#ifndef SCAN_ABL_NO_ULOAD
           load4<VEC>(up, t, L, uu, 0.f, rev);
+#else
+#pragma unroll
+          for (int i = 0; i < ITEMS; ++i) uu[i] = 0.5f + 0.001f * lane;
+#endif
           const float* Wr = s_W + (wave * BWD_RPW + r) * RMAX;
           if (dtr) {
             dl[0] = dl[1] = dl[2] = dl[3] = 0.f;
-            for (int q = 0; q < R; ++q) {
-              const float w = Wr[q];
-              const float4 f = *reinterpret_cast<const float4*>(&s_dtr[q][lane * ITEMS]);
-              dl[0] = fmaf(w, f.x, dl[0]); dl[1] = fmaf(w, f.y, dl[1]); dl[2] = fmaf(w, f.z, dl[2]); dl[3] = fmaf(w, f.w, dl[3]);
-            }
+            dtproj_row(Wr, s_dtr, R, lane, dl);
           } else {
             load4<VEC>(delta + row * L, t, L, dl, 0.f, rev);
           }
+#ifndef SCAN_ABL_NO_ULOAD
           load4<VEC>((xmode & 2) ? gy + (((size_t)(bk / K) * 2 + (k & 1)) * Dk + d) * L : gy + row * L, t, L, g, 0.f, rev);
+#else
+#pragma unroll
+          for (int i = 0; i < ITEMS; ++i) g[i] = 0.25f - 0.002f * lane;
+#endif
           if (first) {
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) { ddt[i] = 0.f; du[i] = Dd * g[i]; }
           } else {  // partial sums left by the previous state group
+#ifndef SCAN_ABL_NO_PLOAD
             load4<VEC>(gu + row * L, t, L, du, 0.f, rev);
             load4<VEC>(gdelta + row * L, t, L, ddt, 0.f, rev);
+#else
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) { du[i] = g[i]; ddt[i] = uu[i]; }
+#endif
           }
+#ifdef SCAN_STAMP
+          __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): make the global-load wait visible as its own phase
+          STAMP(7)  // 7: dt projection (LDS) issued before + wait for the row's global loads
+#endif
 #pragma unroll
           for (int i = 0; i < ITEMS; ++i) {
             dt[i] = (t + i < L) ? softplus_f(dl[i] + bias) : 0.f;
             dtu[i] = dt[i] * uu[i];
           }
+          STAMP(2)  // 2: row prologue: loads of u, gy, partial sums; dt projection; softplus
           const float* hs = h0_staged ? s_h0 + (wave * BWD_RPW + r) * NS + n0 : hstate + (row * nchunk + (c > 0 ? c - 1 : 0)) * NS + n0;
 #pragma unroll
           for (int j = 0; j < STG; ++j) {
@@ -457,9 +507,14 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
             if (dA_n == 123.456f) s_dA[wave][r][n] += dA_n;
 #endif
           }
+          STAMP(3)  // 3: the STG states of the row
           if (!last) {
+#ifndef SCAN_ABL_NO_STORE
             store4<VEC>(gu + row * L, t, L, du, rev);
             store4<VEC>(gdelta + row * L, t, L, ddt, rev);
+#else
+            if (du[0] == 123.456f && ddt[1] == 654.321f) store4<VEC>(gu + row * L, t, L, du, rev);
+#endif
           } else {
             float gd[ITEMS];
             float dD = 0.f, dbs = 0.f;
@@ -492,6 +547,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
       if (accB[0][0] == 123.456f || accC[STG - 1][ITEMS - 1] == 123.456f) s_dD[wave][0] += accB[1][1] + accC[2][2];
       continue;
 #endif
+      STAMP(4)  // 4: row epilogue (stores; last group: gate of d(delta), dD, gW sums) - accumulated with the loop tail
       // ---- fold the BWD_WAVES register tiles of this state group into the LDS tile, one wave at a time (plain LDS traffic, no
       // atomics).  The tile aliases the B/C tiles: rows [n0, n0 + STG) of both are dead once every wave is past this group.
       __syncthreads();
@@ -516,6 +572,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
         __syncthreads();
       }
     }
+    STAMP(5)  // 5: folds of the register tiles (barriers included)
     // ---- plain, coalesced stores of this workgroup's partial dB/dC tile into its slab
     if (VEC) {
       for (int i = threadIdx.x; i < NS * CHUNK / 4; i += BWD_WAVES * WAVE) {
@@ -535,7 +592,13 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
         if (tg < L) { slabB[(size_t)n * L + pos] = s_dB[n][i % CHUNK]; slabC[(size_t)n * L + pos] = s_dC[n][i % CHUNK]; }
       }
     }
+    STAMP(6)  // 6: slab stores
   }
+#ifdef SCAN_STAMP
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    for (int i = 0; i < 8; ++i) gu[i] = (float)(st_acc[i] >> 6);  // units of 64 ticks
+  }
+#endif
 #pragma unroll
   for (int r = 0; r < BWD_RPW; ++r) {
     const int d = d0 + r;

@@ -92,7 +92,7 @@ class ManbaWorldDecoder(nn.Module):
         x = valid.to(feats.dtype) * feats
         lin, norm = self.enc_output[0], self.enc_output[1]
         # same [B*L, 512] x [512, 512] contraction as the value projection: bf16 activations take the MFMA kernel
-        memory = norm(ops.linear_bf16(x, lin.weight, lin.bias) if x.dtype == torch.bfloat16 else lin(x))
+        memory = VSSBlock._ln(norm, ops.linear_bf16(x, lin.weight, lin.bias) if x.dtype == torch.bfloat16 else lin(x))  # LayerNorm kernel in the activation dtype
         scores = self.enc_score_head(memory)
         top = torch.topk(scores.max(-1).values, self.num_queries, dim=1).indices
         bi = torch.arange(bs, device=feats.device).unsqueeze(-1)
