@@ -314,6 +314,25 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
 #define STAMP(i)
 #endif
 
+#ifndef SCAN_BWD_PREFETCH
+#define SCAN_BWD_PREFETCH 0  // measured: 18.1 vs 17.6 ms at level 0 with it on (256 VGPRs + scratch); kept for the record
+#endif
+// global streams of one backward row for one chunk: u, gy, and (from the second state group on) the partial du / d(delta) sums
+template <bool VEC>
+__device__ __forceinline__ void bwd_fetch_row(const float* __restrict__ u, const float* __restrict__ gy, const float* __restrict__ gu,
+                                              const float* __restrict__ gdelta, int bk, int K, int k, int Dk, int d, int L, int t, bool rev,
+                                              int xmode, bool first, float (&uu)[ITEMS], float (&g)[ITEMS], float (&pdu)[ITEMS],
+                                              float (&pddt)[ITEMS]) {
+  const size_t row = (size_t)(bk / K) * K * Dk + (size_t)k * Dk + d;
+  const size_t prow = ((size_t)(bk / K) * 2 + (k & 1)) * Dk + d;
+  load4<VEC>(xmode ? u + prow * L : u + row * L, t, L, uu, 0.f, rev);
+  load4<VEC>((xmode & 2) ? gy + prow * L : gy + row * L, t, L, g, 0.f, rev);
+  if (!first) {
+    load4<VEC>(gu + row * L, t, L, pdu, 0.f, rev);
+    load4<VEC>(gdelta + row * L, t, L, pddt, 0.f, rev);
+  }
+}
+
 // Backward: BWD_WAVES waves x BWD_RPW rows each = BWD_ROWS rows of one (b, k) group per workgroup.
 template <bool VEC, int STG>
 __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_bwd_kernel(
@@ -391,6 +410,14 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) { accB[j][i] = 0.f; accC[j][i] = 0.f; }
 
+#if SCAN_BWD_PREFETCH
+      // software pipeline over the rows: the streams of row r+1 (u, gy, partial sums) are requested before row r's arithmetic
+      // starts; in-kernel stamps put the exposed wait for these loads at ~25 % of the kernel without it
+      float n_uu[ITEMS], n_g[ITEMS], n_du[ITEMS], n_ddt[ITEMS];
+#pragma unroll
+      for (int i = 0; i < ITEMS; ++i) n_du[i] = n_ddt[i] = 0.f;
+      if (d0 < Dk) bwd_fetch_row<VEC>(u, gy, gu, gdelta, bk, K, k, Dk, d0, L, t, rev, xmode, first, n_uu, n_g, n_du, n_ddt);
+#endif
 #pragma unroll 1
       for (int r = 0; r < BWD_RPW; ++r) {
         const int d = d0 + r;
@@ -401,12 +428,13 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
           const float* An = s_A[wave][r];
           float* carry = s_carry[wave][r];
           float uu[ITEMS], dl[ITEMS], dt[ITEMS], g[ITEMS], ddt[ITEMS], du[ITEMS], dtu[ITEMS];
-          const float* up = xmode ? u + (((size_t)(bk / K) * 2 + (k & 1)) * Dk + d) * L : u + row * L;
-#ifndef SCAN_ABL_NO_ULOAD
-          load4<VEC>(up, t, L, uu, 0.f, rev);
-#else
+#if SCAN_BWD_PREFETCH
 #pragma unroll
-          for (int i = 0; i < ITEMS; ++i) uu[i] = 0.5f + 0.001f * lane;
+          for (int i = 0; i < ITEMS; ++i) { uu[i] = n_uu[i]; g[i] = n_g[i]; du[i] = n_du[i]; ddt[i] = n_ddt[i]; }
+          if (r + 1 < BWD_RPW && d + 1 < Dk) bwd_fetch_row<VEC>(u, gy, gu, gdelta, bk, K, k, Dk, d + 1, L, t, rev, xmode, first, n_uu, n_g, n_du, n_ddt);
+#else
+          const float* up = xmode ? u + (((size_t)(bk / K) * 2 + (k & 1)) * Dk + d) * L : u + row * L;
+          load4<VEC>(up, t, L, uu, 0.f, rev);
 #endif
           const float* Wr = s_W + (wave * BWD_RPW + r) * RMAX;
           if (dtr) {
@@ -415,24 +443,21 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
           } else {
             load4<VEC>(delta + row * L, t, L, dl, 0.f, rev);
           }
-#ifndef SCAN_ABL_NO_ULOAD
-          load4<VEC>((xmode & 2) ? gy + (((size_t)(bk / K) * 2 + (k & 1)) * Dk + d) * L : gy + row * L, t, L, g, 0.f, rev);
-#else
+#if SCAN_BWD_PREFETCH
+          if (first) {
 #pragma unroll
-          for (int i = 0; i < ITEMS; ++i) g[i] = 0.25f - 0.002f * lane;
-#endif
+            for (int i = 0; i < ITEMS; ++i) { ddt[i] = 0.f; du[i] = Dd * g[i]; }
+          }
+#else
+          load4<VEC>((xmode & 2) ? gy + (((size_t)(bk / K) * 2 + (k & 1)) * Dk + d) * L : gy + row * L, t, L, g, 0.f, rev);
           if (first) {
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) { ddt[i] = 0.f; du[i] = Dd * g[i]; }
           } else {  // partial sums left by the previous state group
-#ifndef SCAN_ABL_NO_PLOAD
             load4<VEC>(gu + row * L, t, L, du, 0.f, rev);
             load4<VEC>(gdelta + row * L, t, L, ddt, 0.f, rev);
-#else
-#pragma unroll
-            for (int i = 0; i < ITEMS; ++i) { du[i] = g[i]; ddt[i] = uu[i]; }
-#endif
           }
+#endif
 #ifdef SCAN_STAMP
           __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): make the global-load wait visible as its own phase
           STAMP(7)  // 7: dt projection (LDS) issued before + wait for the row's global loads
