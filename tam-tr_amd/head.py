@@ -47,8 +47,10 @@ class ManbaWorldDecoder(nn.Module):
         self._reset_parameters()
 
     def forward(self, x, text, batch=None):
-        x = [blk(f.permute(0, 2, 3, 1)).permute(0, 3, 1, 2) for blk, f in zip(self.VSSBlocks, x)]
-        feats, shapes = self._get_encoder_input(x)
+        # VSS blocks run channels-last ([B,H,W,C], head.py:1136-1140); their outputs stay token-major: the 1x1 input projection
+        # is a GEMM over tokens and its result is already in the [B, L, hd] layout of the token memory
+        toks = [blk(f.permute(0, 2, 3, 1)) for blk, f in zip(self.VSSBlocks, x)]
+        feats, shapes = self._get_encoder_input(toks)
         dn_embed, dn_bbox, attn_mask, dn_meta = get_cdn_group(batch, self.nc, self.num_queries,
                                                               self.denoising_class_embed.weight, self.num_denoising,
                                                               self.label_noise_ratio, self.box_noise_scale, self.training)
@@ -78,12 +80,26 @@ class ManbaWorldDecoder(nn.Module):
         a, valid = self._anchor_cache[key]
         return a.to(dtype), valid
 
-    def _get_encoder_input(self, x):
+    def _get_encoder_input(self, toks):
+        """input_proj (Conv1x1 no bias + BatchNorm, head.py:1087) on channels-last tokens + concatenation over the levels
+        (head.py:1202-1219).  toks: list of [B, H, W, C].  A 1x1 convolution IS a per-token linear map, so it runs as a
+        [B*H*W, C] x [C, hd] GEMM (bf16: the MFMA kernel) and BatchNorm takes its batch statistics over the token axis -
+        no NCHW round trip, no transposing concatenation."""
         feats, shapes = [], []
-        for proj, f in zip(self.input_proj, x):
-            y = proj(f)
-            feats.append(y.flatten(2).permute(0, 2, 1))
-            shapes.append([y.shape[2], y.shape[3]])
+        for proj, t in zip(self.input_proj, toks):
+            conv, bn = proj[0], proj[1]
+            B, H, W, C = t.shape
+            t2 = t.reshape(B * H * W, C)
+            w = conv.weight.view(conv.out_channels, C)
+            if t2.is_cuda and t2.dtype == torch.bfloat16 and C % 64 == 0 and conv.out_channels % 128 == 0:
+                y = ops.linear_bf16(t2, w, None)
+            else:
+                y = torch.nn.functional.linear(t2, w.to(t2.dtype))
+            if bn.training and bn.track_running_stats:
+                bn.num_batches_tracked += 1
+            y = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
+            feats.append(y.view(B, H * W, -1))
+            shapes.append([H, W])
         return torch.cat(feats, 1), shapes
 
     def _get_decoder_input(self, feats, shapes, dn_embed=None, dn_bbox=None, text=None):
