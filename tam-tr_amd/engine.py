@@ -1,0 +1,285 @@
+"""Train / validate harness around the hot path: the pieces of the reference's engine that decide numbers.
+
+  build_optimizer      ultralytics/engine/trainer.py:624-681   (three parameter groups: biases, norm weights, decayed weights)
+  lr schedule, warm-up ultralytics/engine/trainer.py:276-279,330-340
+  train_step           ultralytics/engine/trainer.py:343-357,471-479   (autocast forward, backward, clip 0.1, step, EMA)
+  ModelEMA             ultralytics/utils/torch_utils.py:392-419
+  postprocess          ultralytics/models/rtdetrworld/val.py:102-128  (conf filter, class-offset NMS; torchvision is not in the
+                       image: the greedy NMS is restated here)
+  match_predictions    ultralytics/engine/validator.py:208-247, models/yolo/detect/val.py:169-183
+  ap_per_class, compute_ap, smooth, box_iou   ultralytics/utils/metrics.py:49-68,941-946,999-1029,1032-1128
+  Validator            models/rtdetrworld/val.py:130-173 + models/yolo/detect/val.py get_stats
+
+Host-side PyTorch / numpy by design (the reference's is too); dataset decoding, augmentation and the CLIP text encoder stay
+out of scope - batches arrive as tensors (img, txt_feats, cls, bboxes, batch_idx [, ori_shape]).
+"""
+import math
+from copy import deepcopy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+# ------------------------------------------------------------------------------------------------ training side
+def build_optimizer(model, name='AdamW', lr=0.001, momentum=0.9, decay=1e-5, iterations=1e5):
+    """Parameter groups exactly as the reference: [0] every '*bias*' (no decay), then weights with decay, then weights of
+    normalisation layers (no decay).  name='auto' picks SGD(0.01) above 10 000 iterations, else AdamW(lr = 0.002*5/(4+nc))."""
+    g = [], [], []
+    norms = tuple(v for k, v in nn.__dict__.items() if 'Norm' in k)
+    if name == 'auto':
+        nc = getattr(model, 'nc', 10)
+        lr_fit = round(0.002 * 5 / (4 + nc), 6)
+        name, lr, momentum = ('SGD', 0.01, 0.9) if iterations > 10000 else ('AdamW', lr_fit, 0.9)
+    for module_name, module in model.named_modules():
+        for param_name, param in module.named_parameters(recurse=False):
+            fullname = f'{module_name}.{param_name}' if module_name else param_name
+            if 'bias' in fullname:
+                g[2].append(param)
+            elif isinstance(module, norms):
+                g[1].append(param)
+            else:
+                g[0].append(param)
+    if name in ('Adam', 'Adamax', 'AdamW', 'NAdam', 'RAdam'):
+        opt = getattr(torch.optim, name)(g[2], lr=lr, betas=(momentum, 0.999), weight_decay=0.0)
+    elif name == 'RMSProp':
+        opt = torch.optim.RMSprop(g[2], lr=lr, momentum=momentum)
+    elif name == 'SGD':
+        opt = torch.optim.SGD(g[2], lr=lr, momentum=momentum, nesterov=True)
+    else:
+        raise NotImplementedError(f"Optimizer '{name}' not found in [Adam, AdamW, NAdam, RAdam, RMSProp, SGD, auto]")
+    opt.add_param_group({'params': g[0], 'weight_decay': decay})
+    opt.add_param_group({'params': g[1], 'weight_decay': 0.0})
+    return opt
+
+
+def linear_lr(epochs, lrf):
+    """lf(epoch): 1 -> lrf linearly (trainer.py:278)."""
+    return lambda x: (1 - x / epochs) * (1.0 - lrf) + lrf
+
+
+def warmup(optimizer, ni, nw, lf_epoch, warmup_bias_lr=0.0, warmup_momentum=0.8, momentum=0.937):
+    """Linear warm-up of lr (bias group from warmup_bias_lr, others from 0) and momentum over the first nw iterations
+    (trainer.py:330-340; group 0 is the bias group)."""
+    if ni > nw:
+        return
+    for j, x in enumerate(optimizer.param_groups):
+        x['lr'] = float(np.interp(ni, [0, nw], [warmup_bias_lr if j == 0 else 0.0, x['initial_lr'] * lf_epoch]))
+        if 'momentum' in x:
+            x['momentum'] = float(np.interp(ni, [0, nw], [warmup_momentum, momentum]))
+
+
+class ModelEMA:
+    """EMA of every floating-point state_dict entry, decay ramp d(n) = decay * (1 - exp(-n / tau))."""
+
+    def __init__(self, model, decay=0.9999, tau=2000, updates=0):
+        self.ema = deepcopy(model).eval()
+        self.updates = updates
+        self.decay = lambda x: decay * (1 - math.exp(-x / tau))
+        for p in self.ema.parameters():
+            p.requires_grad_(False)
+        self.enabled = True
+
+    @torch.no_grad()
+    def update(self, model):
+        if not self.enabled:
+            return
+        self.updates += 1
+        d = self.decay(self.updates)
+        msd = model.state_dict()
+        dst, src = [], []
+        for k, v in self.ema.state_dict().items():
+            if v.dtype.is_floating_point:
+                dst.append(v)
+                src.append(msd[k].detach())
+        torch._foreach_mul_(dst, d)            # v = d * v + (1 - d) * m, a few multi-tensor kernels instead of 2 per tensor
+        torch._foreach_add_(dst, src, alpha=1 - d)
+
+
+def train_step(model, batch, optimizer, ema=None, max_norm=0.1):
+    """One optimisation step as the reference trainer runs it for RT-DETR models (bf16 autocast replaces the fp16 scaler)."""
+    loss, items = model(batch)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], max_norm=max_norm)
+    optimizer.step()
+    optimizer.zero_grad(set_to_none=True)
+    if ema is not None:
+        ema.update(model)
+    return loss.detach(), items
+
+
+# ------------------------------------------------------------------------------------------------ validation side
+def xywh2xyxy(b):
+    half = b[..., 2:] / 2
+    return torch.cat([b[..., :2] - half, b[..., :2] + half], -1)
+
+
+def box_iou(box1, box2, eps=1e-7):
+    """[N,4] x [M,4] xyxy -> [N,M]."""
+    (a1, a2), (b1, b2) = box1.unsqueeze(1).chunk(2, 2), box2.unsqueeze(0).chunk(2, 2)
+    inter = (torch.min(a2, b2) - torch.max(a1, b1)).clamp_(0).prod(2)
+    return inter / ((a2 - a1).prod(2) + (b2 - b1).prod(2) - inter + eps)
+
+
+def nms(boxes, scores, iou_thres):
+    """Greedy NMS (torchvision.ops.nms semantics: keep in descending score order, suppress IoU > thres); <= a few hundred boxes."""
+    order = scores.argsort(descending=True)
+    if order.numel() == 0:
+        return order
+    iou = box_iou(boxes[order], boxes[order], eps=0.0).cpu().numpy()
+    alive = np.ones(len(order), dtype=bool)
+    keep = []
+    for i in range(len(order)):
+        if alive[i]:
+            keep.append(i)
+            alive &= ~(iou[i] > iou_thres)
+            alive[i] = False
+    return order[torch.as_tensor(keep, dtype=torch.long, device=order.device)]
+
+
+def postprocess(preds, imgsz, conf=0.001, iou=0.7, single_cls=False, max_wh=7680):
+    """Eval output [B, nq, 4 + nc] (xywh in 0..1, sigmoid scores) -> list of [n, 6] (xyxy pixels, conf, cls), conf-sorted and
+    class-aware NMS'ed, as RTDETRValidator.postprocess."""
+    y = preds[0] if isinstance(preds, (list, tuple)) else preds
+    nd = y.shape[-1]
+    bboxes, scores = y.split((4, nd - 4), dim=-1)
+    bboxes = bboxes * imgsz
+    out = []
+    for i, bbox in enumerate(bboxes):
+        bbox = xywh2xyxy(bbox)
+        score, cls = scores[i].max(-1)
+        pred = torch.cat([bbox, score[..., None], cls[..., None].to(bbox.dtype)], -1)
+        order = score.argsort(descending=True)
+        pred = pred[order][(score > conf)[order]]
+        c = pred[:, 5:6] * (0 if single_cls else max_wh)
+        out.append(pred[nms(pred[:, :4] + c, pred[:, 4], iou)])
+    return out
+
+
+IOUV = torch.linspace(0.5, 0.95, 10)
+
+
+def match_predictions(pred_classes, true_classes, iou, iouv=IOUV):
+    """correct[N, 10]: detection n is a true positive at IoU threshold t (one detection per label, best IoU first)."""
+    correct = np.zeros((pred_classes.shape[0], iouv.shape[0])).astype(bool)
+    correct_class = true_classes[:, None] == pred_classes
+    iou = (iou * correct_class).cpu().numpy()
+    for i, threshold in enumerate(iouv.cpu().tolist()):
+        matches = np.array(np.nonzero(iou >= threshold)).T
+        if matches.shape[0]:
+            if matches.shape[0] > 1:
+                matches = matches[iou[matches[:, 0], matches[:, 1]].argsort()[::-1]]
+                matches = matches[np.unique(matches[:, 1], return_index=True)[1]]
+                matches = matches[np.unique(matches[:, 0], return_index=True)[1]]
+            correct[matches[:, 1].astype(int), i] = True
+    return torch.tensor(correct, dtype=torch.bool, device=pred_classes.device)
+
+
+def process_batch(detections, labels, iouv=IOUV):
+    """detections [N, 6] xyxy conf cls; labels [M, 5] cls xyxy."""
+    return match_predictions(detections[:, 5], labels[:, 0], box_iou(labels[:, 1:], detections[:, :4]), iouv)
+
+
+def smooth(y, f=0.05):
+    nf = round(len(y) * f * 2) // 2 + 1
+    p = np.ones(nf // 2)
+    yp = np.concatenate((p * y[0], y, p * y[-1]), 0)
+    return np.convolve(yp, np.ones(nf) / nf, mode='valid')
+
+
+def compute_ap(recall, precision):
+    mrec = np.concatenate(([0.0], recall, [1.0]))
+    mpre = np.concatenate(([1.0], precision, [0.0]))
+    mpre = np.flip(np.maximum.accumulate(np.flip(mpre)))
+    x = np.linspace(0, 1, 101)
+    return np.trapezoid(np.interp(x, mrec, mpre), x), mpre, mrec
+
+
+def ap_per_class(tp, conf, pred_cls, target_cls, eps=1e-16):
+    """-> tp, fp, p, r, f1 (at the max-F1 confidence), ap [nc, 10], unique_classes."""
+    i = np.argsort(-conf)
+    tp, conf, pred_cls = tp[i], conf[i], pred_cls[i]
+    unique_classes, nt = np.unique(target_cls, return_counts=True)
+    nc = unique_classes.shape[0]
+    x = np.linspace(0, 1, 1000)
+    ap, p_curve, r_curve = np.zeros((nc, tp.shape[1])), np.zeros((nc, 1000)), np.zeros((nc, 1000))
+    for ci, c in enumerate(unique_classes):
+        i = pred_cls == c
+        n_l, n_p = nt[ci], i.sum()
+        if n_p == 0 or n_l == 0:
+            continue
+        fpc = (1 - tp[i]).cumsum(0)
+        tpc = tp[i].cumsum(0)
+        recall = tpc / (n_l + eps)
+        r_curve[ci] = np.interp(-x, -conf[i], recall[:, 0], left=0)
+        precision = tpc / (tpc + fpc)
+        p_curve[ci] = np.interp(-x, -conf[i], precision[:, 0], left=1)
+        for j in range(tp.shape[1]):
+            ap[ci, j], _, _ = compute_ap(recall[:, j], precision[:, j])
+    f1_curve = 2 * p_curve * r_curve / (p_curve + r_curve + eps)
+    i = smooth(f1_curve.mean(0), 0.1).argmax()
+    p, r, f1 = p_curve[:, i], r_curve[:, i], f1_curve[:, i]
+    tpn = (r * nt).round()
+    fpn = (tpn / (p + eps) - tpn).round()
+    return tpn, fpn, p, r, f1, ap, unique_classes.astype(int)
+
+
+class Validator:
+    """Accumulates (correct, conf, pred_cls, target_cls) over batches and reduces to mp, mr, mAP50, mAP50-95."""
+
+    def __init__(self, imgsz=640, conf=0.001, iou=0.7, single_cls=False):
+        self.imgsz, self.conf, self.iou, self.single_cls = imgsz, conf, iou, single_cls
+        self.stats, self.seen = [], 0
+
+    @torch.no_grad()
+    def update(self, preds, batch):
+        dev = preds[0].device if isinstance(preds, (list, tuple)) else preds.device
+        iouv = IOUV.to(dev)
+        for si, pred in enumerate(postprocess(preds, self.imgsz, self.conf, self.iou, self.single_cls)):
+            idx = batch['batch_idx'].view(-1).to(dev) == si
+            cls = batch['cls'].to(dev).view(-1, 1)[idx].float()
+            bbox = batch['bboxes'].to(dev)[idx].float()
+            shape = batch['ori_shape'][si] if 'ori_shape' in batch else (self.imgsz, self.imgsz)
+            nl, npr = cls.shape[0], pred.shape[0]
+            correct = torch.zeros(npr, iouv.numel(), dtype=torch.bool, device=dev)
+            self.seen += 1
+            if npr == 0:
+                if nl:
+                    self.stats.append((correct, torch.zeros(0, device=dev), torch.zeros(0, device=dev), cls.squeeze(-1)))
+                continue
+            if self.single_cls:
+                pred[:, 5] = 0
+            predn = pred.clone()
+            predn[..., [0, 2]] *= shape[1] / self.imgsz
+            predn[..., [1, 3]] *= shape[0] / self.imgsz
+            if nl:
+                tbox = xywh2xyxy(bbox)
+                tbox[..., [0, 2]] *= shape[1]
+                tbox[..., [1, 3]] *= shape[0]
+                correct = process_batch(predn.float(), torch.cat((cls, tbox), 1), iouv)
+            self.stats.append((correct, pred[:, 4], pred[:, 5], cls.squeeze(-1)))
+
+    def results(self):
+        if not self.stats:
+            return {'precision': 0.0, 'recall': 0.0, 'mAP50': 0.0, 'mAP50-95': 0.0, 'seen': self.seen}
+        stats = [torch.cat(x, 0).cpu().numpy() for x in zip(*self.stats)]
+        if not stats[0].any():
+            return {'precision': 0.0, 'recall': 0.0, 'mAP50': 0.0, 'mAP50-95': 0.0, 'seen': self.seen}
+        _, _, p, r, _, ap, _ = ap_per_class(*stats)
+        return {'precision': float(p.mean()), 'recall': float(r.mean()), 'mAP50': float(ap[:, 0].mean()),
+                'mAP50-95': float(ap.mean()), 'seen': self.seen}
+
+
+@torch.no_grad()
+def validate(model, batches, imgsz=640, conf=0.001, iou=0.7, autocast_dtype=None):
+    """model in eval mode over an iterable of batches -> metric dict (valTAMTR.py's flow without the dataset plumbing)."""
+    was_training = model.training
+    model.eval()
+    v = Validator(imgsz, conf, iou)
+    for batch in batches:
+        img = batch['img']
+        with torch.autocast(img.device.type, dtype=autocast_dtype or torch.bfloat16, enabled=autocast_dtype is not None):
+            preds = model(img, txt_feats=batch.get('txt_feats'))
+        v.update(preds, batch)
+    model.train(was_training)
+    return v.results()

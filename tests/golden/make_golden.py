@@ -536,6 +536,62 @@ def _gen_e2e(wseed):
     return True
 
 
+def gen_metrics():
+    """Validation / training harness numbers from the reference's own functions: ap_per_class, match_predictions, box_iou
+    (utils/metrics.py, engine/validator.py), ModelEMA (utils/torch_utils.py), build_optimizer grouping (engine/trainer.py)."""
+    import types as _t
+    from ultralytics.engine.trainer import BaseTrainer
+    from ultralytics.engine.validator import BaseValidator
+    from ultralytics.utils.metrics import ap_per_class, box_iou
+    from ultralytics.utils.torch_utils import ModelEMA
+    g = np.random.default_rng(11)
+    d = {}
+    n, ncls = 400, 6
+    conf = g.random(n).astype(np.float32)
+    pred_cls = g.integers(0, ncls - 1, n).astype(np.float32)          # class 5 never predicted
+    target_cls = g.integers(0, ncls, 150).astype(np.float32)
+    tp = (g.random((n, 10)) < np.linspace(0.7, 0.1, 10)[None] * conf[:, None] ** 0.3)
+    tp = np.logical_and.accumulate(tp, 1)                              # a TP at a stricter IoU implies the looser ones
+    out = ap_per_class(tp, conf, pred_cls, target_cls, plot=False, names={i: str(i) for i in range(ncls)})
+    d.update({'ap.tp': tp, 'ap.conf': conf, 'ap.pred_cls': pred_cls, 'ap.target_cls': target_cls})
+    for k, v in zip(('tpn', 'fpn', 'p', 'r', 'f1', 'ap', 'classes'), out[:7]):
+        d['ap.out.' + k] = np.asarray(v)
+    # matching
+    b1 = torch.tensor(g.random((40, 4)).astype(np.float32)) * 300
+    b1[:, 2:] = b1[:, :2] + 20 + b1[:, 2:] * 0.5
+    b2 = b1[g.integers(0, 40, 90)] + torch.tensor(g.normal(0, 6, (90, 4)).astype(np.float32))
+    pc, tc = torch.tensor(g.integers(0, 3, 90)).float(), torch.tensor(g.integers(0, 3, 40)).float()
+    iou = box_iou(b1, b2)
+    dummy = _t.SimpleNamespace(iouv=torch.linspace(0.5, 0.95, 10))
+    correct = BaseValidator.match_predictions(dummy, pc, tc, iou)
+    d.update({'match.labels_xyxy': b1.numpy(), 'match.dets_xyxy': b2.numpy(), 'match.pred_cls': pc.numpy(), 'match.true_cls': tc.numpy(),
+              'match.iou': iou.numpy(), 'match.correct': correct.numpy()})
+    # EMA
+    torch.manual_seed(3)
+    net = nn.Sequential(nn.Conv2d(3, 4, 3), nn.BatchNorm2d(4), nn.Flatten(), nn.Linear(4, 2))
+    ema = ModelEMA(net, decay=0.9999, tau=2000)
+    for step in range(3):
+        with torch.no_grad():
+            for q, p_ in enumerate(net.parameters()):
+                p_.add_(0.1 * (step + 1) * (q + 1))
+            net[1].running_mean.add_(0.5)
+        ema.update(net)
+    for k, v in ema.ema.state_dict().items():
+        d['ema.' + k] = v.numpy()
+    d['ema.updates'] = np.array(ema.updates)
+    # optimizer groups on the TAMTR head-like mixture of layer types
+    torch.manual_seed(4)
+    mix = nn.Sequential(nn.Conv2d(3, 8, 3, bias=False), nn.BatchNorm2d(8), nn.Linear(8, 8), nn.LayerNorm(8), nn.Embedding(5, 8),
+                        nn.MultiheadAttention(8, 2))
+    tr = _t.SimpleNamespace(args=_t.SimpleNamespace(lr0=0.01, momentum=0.9, warmup_bias_lr=0.1))
+    opt = BaseTrainer.build_optimizer(tr, mix, name='AdamW', lr=0.002, momentum=0.9, decay=5e-4)
+    names = {id(p_): n_ for n_, p_ in mix.named_parameters()}
+    for gi, grp in enumerate(opt.param_groups):
+        d[f'opt.group{gi}.names'] = np.array([names[id(p_)] for p_ in grp['params']])
+        d[f'opt.group{gi}.wd'] = np.array(grp['weight_decay'])
+    save('metrics', d)
+
+
 def gen_e2e():
     for wseed in range(71, 91):
         if _gen_e2e(wseed):
@@ -546,6 +602,6 @@ def gen_e2e():
 if __name__ == '__main__':
     _import_reference()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['gate', 'msdeform', 'contrastive', 'decoder', 'cdn', 'loss', 'vss', 'head', 'e2e']
+    which = sys.argv[1:] or ['gate', 'msdeform', 'contrastive', 'decoder', 'cdn', 'loss', 'vss', 'head', 'e2e', 'metrics']
     for w in which:
         globals()['gen_' + w]()

@@ -530,3 +530,29 @@ def test_full_model_real_vss_vs_oracle(pkg):
         yref = O.tamtr_predict({k: v.detach() for k, v in so.items()}, img, txt, None, False)
     for b in range(B):
         assert_rows_match(y[b], yref[b], 2e-3, f'eval (real VSS) image {b}')
+
+
+def test_engine_train_and_validate_on_gpu(pkg):
+    """The harness end to end on the real graph (small images): optimizer groups as the reference, two optimisation steps with
+    EMA, then the validation pass (eval forward -> postprocess -> matching -> AP)."""
+    import tamtr_amd.engine as E
+    torch.manual_seed(0)
+    model = pkg.model.RTDETRDetectionWorldModel(nc=10).cuda().train()
+    model.autocast_dtype = torch.bfloat16
+    opt = E.build_optimizer(model, name='AdamW', lr=1e-4, momentum=0.9, decay=1e-4)
+    n_params = sum(len(g['params']) for g in opt.param_groups)
+    assert n_params == len(list(model.parameters())) and opt.param_groups[1]['weight_decay'] == 1e-4
+    ema = E.ModelEMA(model)
+    g = torch.Generator().manual_seed(5)
+    B, S = 2, 128
+    batch = {'img': torch.rand(B, 3, S, S, generator=g).cuda(),
+             'txt_feats': torch.nn.functional.normalize(torch.randn(B, 10, 512, generator=g), dim=-1).cuda(),
+             'cls': torch.randint(0, 10, (6, 1), generator=g).float(),
+             'bboxes': torch.cat([0.2 + 0.6 * torch.rand(6, 2, generator=g), 0.05 + 0.2 * torch.rand(6, 2, generator=g)], 1),
+             'batch_idx': torch.tensor([0., 0, 0, 1, 1, 1])}
+    l0, _ = E.train_step(model, batch, opt, ema)
+    l1, items = E.train_step(model, batch, opt, ema)
+    assert torch.isfinite(l0).item() and torch.isfinite(l1).item() and items.shape == (3,) and ema.updates == 2
+    res = E.validate(model, [batch], imgsz=S, autocast_dtype=torch.bfloat16)
+    assert res['seen'] == B and 0.0 <= res['mAP50'] <= 1.0 and 0.0 <= res['mAP50-95'] <= res['mAP50'] + 1e-9
+    assert model.training
