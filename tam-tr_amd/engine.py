@@ -150,7 +150,7 @@ def postprocess(preds, imgsz, conf=0.001, iou=0.7, single_cls=False, max_wh=7680
         score, cls = scores[i].max(-1)
         pred = torch.cat([bbox, score[..., None], cls[..., None].to(bbox.dtype)], -1)
         order = score.argsort(descending=True)
-        pred = pred[order][(score > conf)[order]]
+        pred = pred[order][score > conf]  # the reference applies the UNSORTED confidence mask to the sorted rows (val.py:113-121): kept
         c = pred[:, 5:6] * (0 if single_cls else max_wh)
         out.append(pred[nms(pred[:, :4] + c, pred[:, 4], iou)])
     return out
