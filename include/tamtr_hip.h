@@ -254,6 +254,19 @@ int tamtr_layernorm_fwd(const void* x, const float* gamma, const float* beta, vo
 int tamtr_layernorm_bwd(const void* gout, const void* x, const float* gamma, const float* stats, void* gx, float* partials,
                         long long ntok, int D, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * trunk  Training-mode BatchNorm2d (+ SiLU).  Replaces `self.act(self.bn(y))` of Conv.forward, ultralytics/nn/modules/conv.py:36-40,
+ *      in train mode (batch statistics, running-stat update with the unbiased variance, as nn.BatchNorm2d).
+ *      x, y, gy, gx (T) [B, C, HW] (NCHW maps); gamma, beta, running_mean, running_var f32 [C] (running_* may be NULL);
+ *      mean_rstd f32 [C, 2] saved for the backward; partials: caller workspace of C * tamtr_bn_slices(B, HW) * 3 floats
+ *      (forward) / * 2 floats (backward).  act: 0 = identity, 1 = SiLU.  Backward returns d(gamma), d(beta) f32 [C].
+ */
+int tamtr_bn_slices(int B, int HW);
+int tamtr_bn_act_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y,
+                     float* mean_rstd, float* partials, int B, int C, int HW, float eps, float momentum, int act, int dtype, void* stream);
+int tamtr_bn_act_bwd(const void* gy, const void* x, const float* gamma, const float* beta, const float* mean_rstd, void* gx,
+                     float* ggamma, float* gbeta, float* partials, int B, int C, int HW, int act, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

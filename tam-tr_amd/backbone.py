@@ -28,7 +28,12 @@ class Conv(nn.Module):
         self.act = nn.SiLU() if act is True else act if isinstance(act, nn.Module) else nn.Identity()
 
     def forward(self, x):
-        return self.act(self.bn(self.conv(x)))
+        y = self.conv(x)
+        if y.is_cuda and self.bn.training and self.bn.affine and type(self.act) in (nn.SiLU, nn.Identity) \
+                and y.dtype in (torch.bfloat16, torch.float32):
+            from . import ops
+            return ops.bn_act(y, self.bn, isinstance(self.act, nn.SiLU))  # BatchNorm (batch stats) + SiLU: csrc/bn.hip
+        return self.act(self.bn(y))
 
 
 class RepConvN(nn.Module):

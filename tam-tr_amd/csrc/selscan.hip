@@ -459,7 +459,9 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
           }
 #endif
 #ifdef SCAN_STAMP
+#if !SCAN_BWD_PREFETCH
           __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): make the global-load wait visible as its own phase
+#endif
           STAMP(7)  // 7: dt projection (LDS) issued before + wait for the row's global loads
 #endif
 #pragma unroll

@@ -718,3 +718,46 @@ class _LayerNorm(torch.autograd.Function):
 
 def layer_norm(x, gamma, beta, eps=1e-5):
     return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+class _BNAct(torch.autograd.Function):
+    """Training-mode BatchNorm2d (+ SiLU) on an NCHW map - csrc/bn.hip.  running_mean / running_var are updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, silu):
+        require_gpu(x, gamma, beta)
+        x = _c(x)
+        B, C = x.shape[:2]
+        HW = x.numel() // (B * C)
+        g32, b32 = _c(gamma.float()), _c(beta.float())
+        y = torch.empty_like(x)
+        mr = torch.empty(C, 2, device=x.device, dtype=torch.float32)
+        part = torch.empty(C * _lib.lib().tamtr_bn_slices(B, HW) * 3, device=x.device, dtype=torch.float32)
+        call('tamtr_bn_act_fwd', ptr(x), ptr(g32), ptr(b32), ptr(running_mean), ptr(running_var), ptr(y), ptr(mr), ptr(part), B, C, HW,
+             float(eps), float(momentum), int(bool(silu)), dtype_code(x), stream_ptr())
+        ctx.save_for_backward(x, g32, b32, mr)
+        ctx.cfg = (int(bool(silu)), gamma.dtype, beta.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, g32, b32, mr = ctx.saved_tensors
+        act, g_dt, b_dt = ctx.cfg
+        B, C = x.shape[:2]
+        HW = x.numel() // (B * C)
+        gy = _c(gy.to(x.dtype))
+        gx = torch.empty_like(x)
+        gg, gb = torch.empty(C, device=x.device, dtype=torch.float32), torch.empty(C, device=x.device, dtype=torch.float32)
+        part = torch.empty(C * _lib.lib().tamtr_bn_slices(B, HW) * 2, device=x.device, dtype=torch.float32)
+        call('tamtr_bn_act_bwd', ptr(gy), ptr(x), ptr(g32), ptr(b32), ptr(mr), ptr(gx), ptr(gg), ptr(gb), ptr(part), B, C, HW, act,
+             dtype_code(x), stream_ptr())
+        return gx, gg.to(g_dt), gb.to(b_dt), None, None, None, None, None
+
+
+def bn_act(x, bn, silu):
+    """act(bn(x)) for an nn.BatchNorm2d in training mode (batch statistics; running stats and num_batches_tracked updated)."""
+    if bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+    return _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                        bn.running_var if bn.track_running_stats else None, bn.eps, mom, silu)

@@ -343,3 +343,37 @@ def test_layer_norm_kernel(ops, D, dt):
     assert_close(xd.grad.float(), xr.grad, 5 * tol, 5 * tol, 'ln dx')
     assert_close(gd.grad, gr.grad, 5 * tol, 5 * tol * n ** 0.5, 'ln dgamma')
     assert_close(bd.grad, br.grad, 5 * tol, 5 * tol * n ** 0.5, 'ln dbeta')
+
+
+@pytest.mark.parametrize('B,C,H,W,silu,dt', [(4, 8, 20, 20, True, torch.float32), (2, 3, 7, 9, False, torch.float32), (2, 16, 96, 96, True, torch.float32),
+                                             (3, 5, 3, 3, True, torch.float32), (2, 32, 40, 40, True, torch.bfloat16)])
+def test_bn_act_vs_torch(ops, B, C, H, W, silu, dt):
+    """Training-mode BatchNorm2d (+SiLU) kernels vs nn.BatchNorm2d + F.silu on the CPU (conv.py:36-40 with the reference's eps 1e-3 /
+    momentum 0.03): output, running statistics, and the gradients of x, gamma, beta."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    x = (rnd((B, C, H, W), 1) * 1.7 + 0.4).to(dt).float()
+    cot = rnd((B, C, H, W), 2).to(dt).float()
+    ref_bn = nn.BatchNorm2d(C, eps=1e-3, momentum=0.03)
+    with torch.no_grad():
+        ref_bn.weight.copy_(1 + 0.3 * rnd((C,), 3)); ref_bn.bias.copy_(0.2 * rnd((C,), 4))
+        ref_bn.running_mean.copy_(0.1 * rnd((C,), 5)); ref_bn.running_var.copy_(1 + 0.1 * rnd((C,), 6).abs())
+    import copy
+    dev_bn = copy.deepcopy(ref_bn).cuda()
+    xr = x.clone().requires_grad_()
+    z = ref_bn(xr)
+    ref = F.silu(z) if silu else z
+    (ref * cot).sum().backward()
+    xd = dev(x, dt).requires_grad_()
+    out = ops.bn_act(xd, dev_bn, silu)
+    (out.float() * dev(cot)).sum().backward()
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    assert out.dtype == dt
+    assert_close(out.float(), ref, tol, tol, 'bn out')
+    assert_close(dev_bn.running_mean, ref_bn.running_mean, 1e-5, 1e-6, 'running_mean')
+    assert_close(dev_bn.running_var, ref_bn.running_var, 1e-5, 1e-6, 'running_var')
+    assert int(dev_bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == 1
+    n = B * H * W
+    assert_close(xd.grad.float(), xr.grad, 10 * tol, 10 * tol, 'bn dx')
+    assert_close(dev_bn.weight.grad, ref_bn.weight.grad, 10 * tol, 10 * tol * n ** 0.5, 'bn dgamma')
+    assert_close(dev_bn.bias.grad, ref_bn.bias.grad, 10 * tol, 10 * tol * n ** 0.5, 'bn dbeta')
