@@ -215,6 +215,125 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const T* __res
   }
 }
 
+// ---- channels-last variant: x [N, C] with C contiguous (token-major maps: the MEH input projection output).  A workgroup owns
+// CL_ROWS rows x all C columns; a thread owns 4 consecutive columns and every RL-th row (RL = 256 / (C / 4) row lanes).
+constexpr int CL_ROWS = 128;
+
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bncl_stats_kernel(const T* __restrict__ x, float* __restrict__ part, int N, int C) {
+  __shared__ float s_acc[BN_THREADS][8];
+  const int cg = C / 4, rl = BN_THREADS / cg;          // column groups, row lanes
+  const int g = threadIdx.x % cg, r = threadIdx.x / cg;
+  const int row0 = blockIdx.x * CL_ROWS, nrow = min(CL_ROWS, N - row0), S = gridDim.x;
+  float k[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (r < rl) {
+    Elt<T>::ld4(x + (size_t)row0 * C + g * 4, k);       // shift by the block's first row: sums of (x - k) stay well conditioned
+    for (int i = r; i < nrow; i += rl) {
+      float v[4];
+      Elt<T>::ld4(x + (size_t)(row0 + i) * C + g * 4, v);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = v[j] - k[j]; s1[j] += d; s2[j] = fmaf(d, d, s2[j]); }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s_acc[threadIdx.x][j] = s1[j]; s_acc[threadIdx.x][4 + j] = s2[j]; }
+  __syncthreads();
+  if (r == 0) {
+    for (int q = 1; q < rl; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s1[j] += s_acc[q * cg + g][j]; s2[j] += s_acc[q * cg + g][4 + j]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float* o = part + ((size_t)(g * 4 + j) * S + blockIdx.x) * 3;
+      const float n = (float)nrow, m = s1[j] / n;
+      o[0] = n; o[1] = k[j] + m; o[2] = s2[j] - s1[j] * m;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bncl_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean_rstd,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 T* __restrict__ y, size_t n4, int C, int act) {
+  const size_t i = (size_t)blockIdx.x * BN_THREADS + threadIdx.x;   // one float4-group of 4 columns
+  if (i >= n4) return;
+  const int c = (int)(i % (C / 4)) * 4;
+  float v[4];
+  Elt<T>::ld4(x + i * 4, v);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = act_fwd(fmaf(v[j] - mean_rstd[2 * (c + j)], mean_rstd[2 * (c + j) + 1] * gamma[c + j], beta[c + j]), act);
+  Elt<T>::st4(y + i * 4, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bncl_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restrict__ x,
+                                                                      const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                                                      const float* __restrict__ beta, float* __restrict__ part, int N, int C,
+                                                                      int act) {
+  __shared__ float s_acc[BN_THREADS][8];
+  const int cg = C / 4, rl = BN_THREADS / cg;
+  const int g = threadIdx.x % cg, r = threadIdx.x / cg;
+  const int row0 = blockIdx.x * CL_ROWS, nrow = min(CL_ROWS, N - row0), S = gridDim.x;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (r < rl) {
+    float mean[4], rstd[4], gm[4], be[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mean[j] = mean_rstd[2 * (g * 4 + j)]; rstd[j] = mean_rstd[2 * (g * 4 + j) + 1]; gm[j] = gamma[g * 4 + j]; be[j] = beta[g * 4 + j]; }
+    for (int i = r; i < nrow; i += rl) {
+      float xv[4], gv[4];
+      Elt<T>::ld4(x + (size_t)(row0 + i) * C + g * 4, xv);
+      Elt<T>::ld4(gy + (size_t)(row0 + i) * C + g * 4, gv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xh = (xv[j] - mean[j]) * rstd[j];
+        const float dz = gv[j] * act_bwd(fmaf(xh, gm[j], be[j]), act);
+        s1[j] += dz; s2[j] = fmaf(dz, xh, s2[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s_acc[threadIdx.x][j] = s1[j]; s_acc[threadIdx.x][4 + j] = s2[j]; }
+  __syncthreads();
+  if (r == 0) {
+    for (int q = 1; q < rl; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s1[j] += s_acc[q * cg + g][j]; s2[j] += s_acc[q * cg + g][4 + j]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { float* o = part + ((size_t)(g * 4 + j) * S + blockIdx.x) * 2; o[0] = s1[j]; o[1] = s2[j]; }
+  }
+}
+
+// sums[c][2] = sum over the S row blocks (one wave per channel)
+__global__ __launch_bounds__(WAVE) void bncl_sum_kernel(const float* __restrict__ part, float* __restrict__ sums, float* __restrict__ ggamma,
+                                                        float* __restrict__ gbeta, int S) {
+  const int c = blockIdx.x;
+  float a = 0.f, b = 0.f;
+  for (int s = threadIdx.x; s < S; s += WAVE) { a += part[((size_t)c * S + s) * 2]; b += part[((size_t)c * S + s) * 2 + 1]; }
+  a = group_sum<WAVE>(a); b = group_sum<WAVE>(b);
+  if (threadIdx.x == 0) { sums[2 * c] = a; sums[2 * c + 1] = b; gbeta[c] = a; ggamma[c] = b; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bncl_bwd_apply_kernel(const T* __restrict__ gy, const T* __restrict__ x,
+                                                                     const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, const float* __restrict__ sums,
+                                                                     T* __restrict__ gx, size_t n4, int C, int act, float inv_count) {
+  const size_t i = (size_t)blockIdx.x * BN_THREADS + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)(i % (C / 4)) * 4;
+  float xv[4], gv[4], o[4];
+  Elt<T>::ld4(x + i * 4, xv);
+  Elt<T>::ld4(gy + i * 4, gv);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float rstd = mean_rstd[2 * (c + j) + 1], g = gamma[c + j];
+    const float xh = (xv[j] - mean_rstd[2 * (c + j)]) * rstd;
+    const float dz = gv[j] * act_bwd(fmaf(xh, g, beta[c + j]), act);
+    o[j] = g * rstd * (dz - sums[2 * (c + j)] * inv_count - xh * sums[2 * (c + j) + 1] * inv_count);
+  }
+  Elt<T>::st4(gx + i * 4, o);
+}
+
 }  // namespace
 
 extern "C" int tamtr_bn_slices(int B, int HW) { return B * ((HW + BN_SLICE - 1) / BN_SLICE); }
@@ -270,5 +389,64 @@ extern "C" int tamtr_bn_act_bwd(const void* gy, const void* x, const float* gamm
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma,
                        beta, partials, (bf16_t*)gx, ggamma, gbeta, C, HW, vec, act, inv);
   }
+  return tamtr_launch_status();
+}
+
+// ---- channels-last entry points: x [N, C], C contiguous
+extern "C" int tamtr_bncl_blocks(long long N) { return (int)((N + CL_ROWS - 1) / CL_ROWS); }
+
+static int bncl_check(const void* a, const void* b, long long N, int C, int dtype, int act) {
+  if (!a || !b || N <= 0 || C <= 0) return TAMTR_EINVAL;
+  if ((dtype != TAMTR_F32 && dtype != TAMTR_BF16) || (act != 0 && act != 1)) return TAMTR_EINVAL;
+  const int cg = C / 4;
+  if (C % 4 || cg > BN_THREADS || (BN_THREADS % cg) || N > 2000000000LL) return TAMTR_EUNSUP;  // C in {4, 8, ..., 1024} with 256 % (C/4) == 0
+  return TAMTR_OK;
+}
+
+extern "C" int tamtr_bncl_act_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y,
+                                  float* mean_rstd, float* partials, long long N, int C, float eps, float momentum, int act, int dtype,
+                                  void* stream) {
+  const int rc = bncl_check(x, y, N, C, dtype, act);
+  if (rc) return rc;
+  if (!gamma || !beta || !mean_rstd || !partials) return TAMTR_EINVAL;
+  const int S = tamtr_bncl_blocks(N);
+  const size_t n4 = (size_t)N * C / 4;
+  const unsigned ab = (unsigned)((n4 + BN_THREADS - 1) / BN_THREADS);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == TAMTR_F32) hipLaunchKernelGGL(bncl_stats_kernel<float>, dim3(S), dim3(BN_THREADS), 0, s, (const float*)x, partials, (int)N, C);
+  else hipLaunchKernelGGL(bncl_stats_kernel<bf16_t>, dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)x, partials, (int)N, C);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(WAVE), 0, s, partials, mean_rstd, running_mean, running_var, S, eps, momentum);
+  if (dtype == TAMTR_F32)
+    hipLaunchKernelGGL(bncl_apply_kernel<float>, dim3(ab), dim3(BN_THREADS), 0, s, (const float*)x, mean_rstd, gamma, beta, (float*)y, n4, C, act);
+  else
+    hipLaunchKernelGGL(bncl_apply_kernel<bf16_t>, dim3(ab), dim3(BN_THREADS), 0, s, (const bf16_t*)x, mean_rstd, gamma, beta, (bf16_t*)y, n4, C,
+                       act);
+  return tamtr_launch_status();
+}
+
+extern "C" int tamtr_bncl_act_bwd(const void* gy, const void* x, const float* gamma, const float* beta, const float* mean_rstd, void* gx,
+                                  float* ggamma, float* gbeta, float* partials, long long N, int C, int act, int dtype, void* stream) {
+  const int rc = bncl_check(gy, x, N, C, dtype, act);
+  if (rc) return rc;
+  if (!gamma || !beta || !mean_rstd || !gx || !ggamma || !gbeta || !partials) return TAMTR_EINVAL;
+  const int S = tamtr_bncl_blocks(N);
+  const size_t n4 = (size_t)N * C / 4;
+  const unsigned ab = (unsigned)((n4 + BN_THREADS - 1) / BN_THREADS);
+  hipStream_t s = (hipStream_t)stream;
+  float* sums = partials + (size_t)C * S * 2;  // [C][2] after the per-block partials
+  const float inv = 1.f / (float)N;
+  if (dtype == TAMTR_F32)
+    hipLaunchKernelGGL(bncl_bwd_reduce_kernel<float>, dim3(S), dim3(BN_THREADS), 0, s, (const float*)gy, (const float*)x, mean_rstd, gamma, beta,
+                       partials, (int)N, C, act);
+  else
+    hipLaunchKernelGGL(bncl_bwd_reduce_kernel<bf16_t>, dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma,
+                       beta, partials, (int)N, C, act);
+  hipLaunchKernelGGL(bncl_sum_kernel, dim3(C), dim3(WAVE), 0, s, partials, sums, ggamma, gbeta, S);
+  if (dtype == TAMTR_F32)
+    hipLaunchKernelGGL(bncl_bwd_apply_kernel<float>, dim3(ab), dim3(BN_THREADS), 0, s, (const float*)gy, (const float*)x, mean_rstd, gamma, beta,
+                       sums, (float*)gx, n4, C, act, inv);
+  else
+    hipLaunchKernelGGL(bncl_bwd_apply_kernel<bf16_t>, dim3(ab), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma,
+                       beta, sums, (bf16_t*)gx, n4, C, act, inv);
   return tamtr_launch_status();
 }

@@ -95,9 +95,13 @@ class ManbaWorldDecoder(nn.Module):
                 y = ops.linear_bf16(t2, w, None)
             else:
                 y = torch.nn.functional.linear(t2, w.to(t2.dtype))
-            if bn.training and bn.track_running_stats:
-                bn.num_batches_tracked += 1
-            y = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
+            C2 = y.shape[1]
+            if y.is_cuda and bn.training and C2 % 4 == 0 and C2 <= 1024 and 256 % (C2 // 4) == 0:
+                y = ops.bn_act(y, bn, False)  # channels-last BatchNorm kernels (csrc/bn.hip)
+            else:
+                if bn.training and bn.track_running_stats:
+                    bn.num_batches_tracked += 1
+                y = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
             feats.append(y.view(B, H * W, -1))
             shapes.append([H, W])
         return torch.cat(feats, 1), shapes

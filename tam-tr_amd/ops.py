@@ -754,10 +754,43 @@ class _BNAct(torch.autograd.Function):
         return gx, gg.to(g_dt), gb.to(b_dt), None, None, None, None, None
 
 
+class _BNActCL(torch.autograd.Function):
+    """Same on a channels-last [N, C] map (token-major)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, silu):
+        require_gpu(x, gamma, beta)
+        x = _c(x)
+        N, C = x.shape
+        g32, b32 = _c(gamma.float()), _c(beta.float())
+        y = torch.empty_like(x)
+        mr = torch.empty(C, 2, device=x.device, dtype=torch.float32)
+        part = torch.empty(C * _lib.lib().tamtr_bncl_blocks(N) * 3, device=x.device, dtype=torch.float32)
+        call('tamtr_bncl_act_fwd', ptr(x), ptr(g32), ptr(b32), ptr(running_mean), ptr(running_var), ptr(y), ptr(mr), ptr(part), N, C,
+             float(eps), float(momentum), int(bool(silu)), dtype_code(x), stream_ptr())
+        ctx.save_for_backward(x, g32, b32, mr)
+        ctx.cfg = (int(bool(silu)), gamma.dtype, beta.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, g32, b32, mr = ctx.saved_tensors
+        act, g_dt, b_dt = ctx.cfg
+        N, C = x.shape
+        gy = _c(gy.to(x.dtype))
+        gx = torch.empty_like(x)
+        gg, gb = torch.empty(C, device=x.device, dtype=torch.float32), torch.empty(C, device=x.device, dtype=torch.float32)
+        part = torch.empty(C * _lib.lib().tamtr_bncl_blocks(N) * 2 + 2 * C, device=x.device, dtype=torch.float32)
+        call('tamtr_bncl_act_bwd', ptr(gy), ptr(x), ptr(g32), ptr(b32), ptr(mr), ptr(gx), ptr(gg), ptr(gb), ptr(part), N, C, act,
+             dtype_code(x), stream_ptr())
+        return gx, gg.to(g_dt), gb.to(b_dt), None, None, None, None, None
+
+
 def bn_act(x, bn, silu):
     """act(bn(x)) for an nn.BatchNorm2d in training mode (batch statistics; running stats and num_batches_tracked updated)."""
     if bn.track_running_stats:
         bn.num_batches_tracked += 1
     mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-    return _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
-                        bn.running_var if bn.track_running_stats else None, bn.eps, mom, silu)
+    fn = _BNActCL if x.dim() == 2 else _BNAct   # [N, C] token-major map vs NCHW
+    return fn.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                    bn.running_var if bn.track_running_stats else None, bn.eps, mom, silu)

@@ -377,3 +377,29 @@ def test_bn_act_vs_torch(ops, B, C, H, W, silu, dt):
     assert_close(xd.grad.float(), xr.grad, 10 * tol, 10 * tol, 'bn dx')
     assert_close(dev_bn.weight.grad, ref_bn.weight.grad, 10 * tol, 10 * tol * n ** 0.5, 'bn dgamma')
     assert_close(dev_bn.bias.grad, ref_bn.bias.grad, 10 * tol, 10 * tol * n ** 0.5, 'bn dbeta')
+
+
+@pytest.mark.parametrize('N,C,dt', [(1000, 512, torch.float32), (333, 64, torch.float32), (4096, 256, torch.bfloat16), (130, 1024, torch.float32)])
+def test_bn_channels_last_vs_torch(ops, N, C, dt):
+    """Token-major BatchNorm (the MEH input projection's BatchNorm over [B*L, hd], head.py:1087) vs nn.BatchNorm1d on the CPU."""
+    import copy
+    import torch.nn as nn
+    x = (rnd((N, C), 1) * 1.3 - 0.7).to(dt).float()
+    cot = rnd((N, C), 2).to(dt).float()
+    ref_bn = nn.BatchNorm1d(C, eps=1e-3, momentum=0.03)
+    with torch.no_grad():
+        ref_bn.weight.copy_(1 + 0.3 * rnd((C,), 3)); ref_bn.bias.copy_(0.2 * rnd((C,), 4))
+    dev_bn = copy.deepcopy(ref_bn).cuda()
+    xr = x.clone().requires_grad_()
+    ref = ref_bn(xr)
+    (ref * cot).sum().backward()
+    xd = dev(x, dt).requires_grad_()
+    out = ops.bn_act(xd, dev_bn, False)
+    (out.float() * dev(cot)).sum().backward()
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    assert_close(out.float(), ref, tol, tol, 'bncl out')
+    assert_close(dev_bn.running_mean, ref_bn.running_mean, 1e-5, 1e-6, 'running_mean')
+    assert_close(dev_bn.running_var, ref_bn.running_var, 1e-5, 1e-6, 'running_var')
+    assert_close(xd.grad.float(), xr.grad, 10 * tol, 10 * tol, 'bncl dx')
+    assert_close(dev_bn.weight.grad, ref_bn.weight.grad, 10 * tol, 10 * tol * N ** 0.5, 'bncl dgamma')
+    assert_close(dev_bn.bias.grad, ref_bn.bias.grad, 10 * tol, 10 * tol * N ** 0.5, 'bncl dbeta')
