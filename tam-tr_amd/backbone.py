@@ -32,6 +32,11 @@ class Conv(nn.Module):
         if y.is_cuda and self.bn.training and self.bn.affine and type(self.act) in (nn.SiLU, nn.Identity) \
                 and y.dtype in (torch.bfloat16, torch.float32):
             from . import ops
+            if y.dim() == 4 and not y.is_contiguous() and y.is_contiguous(memory_format=torch.channels_last) and y.shape[1] % 4 == 0 \
+                    and y.shape[1] <= 1024 and 256 % (y.shape[1] // 4) == 0:
+                B, C, H, W = y.shape  # channels-last map: the [B*H*W, C] kernels, result stays channels-last
+                o = ops.bn_act(y.permute(0, 2, 3, 1).reshape(B * H * W, C), self.bn, isinstance(self.act, nn.SiLU))
+                return o.view(B, H, W, C).permute(0, 3, 1, 2)
             return ops.bn_act(y, self.bn, isinstance(self.act, nn.SiLU))  # BatchNorm (batch stats) + SiLU: csrc/bn.hip
         return self.act(self.bn(y))
 

@@ -63,6 +63,10 @@ def build_graph(spec, ch=3, nc=10):
     return nn.Sequential(*layers), sorted(set(save))
 
 
+import os
+_CHANNELS_LAST = os.environ.get('TAMTR_CHANNELS_LAST') == '1'  # experiment: NHWC trunk (needs PYTORCH_MIOPEN_SUGGEST_NHWC=1)
+
+
 class _CastGroup(torch.autograd.Function):
     """fp32 master conv weights of one graph layer -> bf16 compute copies in ONE multi-tensor kernel, and their gradients back
     to fp32 in one.  autocast casts every weight (and every weight gradient) with its own ~13 us kernel: 400 + 340 launches
@@ -128,6 +132,8 @@ class RTDETRDetectionWorldModel(nn.Module):
             txt = txt.repeat(len(x), 1, 1)
         head = self.model[-1]
         with torch.autocast('cuda', dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None):
+            if _CHANNELS_LAST and x.is_cuda:
+                x = x.contiguous(memory_format=torch.channels_last)
             y = []
             grouped_cast = self.autocast_dtype == torch.bfloat16 and x.is_cuda and torch.is_grad_enabled()
             for m in self.model[:-1]:
