@@ -111,11 +111,27 @@ __device__ __forceinline__ float next_lane(float old, float v) { return dpp<0x13
 // inclusive suffix scan g -> A*g + B (later map applied first): row_shl 1,2,4,8 inside the rows; the two cross-row
 // levels fetch the composite held by the FIRST lane of row r+1 / r+2 with ds_bpermute (there is no "broadcast to the
 // previous row" DPP mode).  addr1/addr2: byte addresses of those lanes, or -1 when the row does not exist.
+#ifndef SCAN_SUFFIX_READLANE
+#define SCAN_SUFFIX_READLANE 1
+#endif
+__device__ __forceinline__ float rdlane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 __device__ __forceinline__ void wave_scan_suffix(float& A, float& Bv, int addr1, int addr2) {
   SCAN_STEP(0x101, 0xf) SCAN_STEP(0x102, 0xf) SCAN_STEP(0x104, 0xf) SCAN_STEP(0x108, 0xf)
 #ifdef SCAN_ABL_NO_BPERMUTE
   return;
 #endif
+#if SCAN_SUFFIX_READLANE
+  // cross-row levels without LDS: only the three row totals T1, T2, T3 (held by lanes 16, 32, 48) matter; they are read into
+  // scalars, composed (wave-uniform) and selected by row.  (ds_bpermute put two dependent LDS round trips into every state.)
+  const float a1 = rdlane(A, 16), b1 = rdlane(Bv, 16), a2 = rdlane(A, 32), b2 = rdlane(Bv, 32), a3 = rdlane(A, 48), b3 = rdlane(Bv, 48);
+  const float a23 = a2 * a3, b23 = fmaf(a2, b3, b2);          // T2 o T3
+  const float a123 = a1 * a23, b123 = fmaf(a1, b23, b1);      // T1 o T2 o T3
+  const int row = addr1 < 0 ? 3 : (addr2 < 0 ? 2 : (addr1 == 128 ? 1 : 0));
+  const float pa = row == 0 ? a123 : row == 1 ? a23 : row == 2 ? a3 : 1.f;
+  const float pb = row == 0 ? b123 : row == 1 ? b23 : row == 2 ? b3 : 0.f;
+  Bv = fmaf(A, pb, Bv);
+  A *= pa;
+#else
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int ad = s ? addr2 : addr1;
@@ -125,6 +141,7 @@ __device__ __forceinline__ void wave_scan_suffix(float& A, float& Bv, int addr1,
     Bv = fmaf(A, pb, Bv);
     A *= pa;
   }
+#endif
 }
 
 // cooperative load of the chunk's B and C tiles ([NS][CHUNK] each) into LDS, zero beyond L
