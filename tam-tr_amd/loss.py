@@ -79,10 +79,16 @@ class HungarianMatcher(nn.Module):
 
     @torch.no_grad()
     def forward(self, pred_bboxes, pred_scores, gt_bboxes, gt_cls, gt_groups, masks=None, gt_mask=None):
+        """pred_* [bs, nq, .] -> Matches (the reference's signature), or [layers, bs, nq, .] -> list of Matches: the cost matrices
+        of all decoder layers come out of ONE set of elementwise kernels, only the assignment runs per layer."""
         from scipy.optimize import linear_sum_assignment
-        bs, nq, nc = pred_scores.shape
+        layered = pred_scores.dim() == 4
+        if not layered:
+            pred_bboxes, pred_scores = pred_bboxes.unsqueeze(0), pred_scores.unsqueeze(0)
+        Lr, bs, nq, nc = pred_scores.shape
         if sum(gt_groups) == 0:
-            return [(torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long)) for _ in range(bs)]
+            empty = [[(torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long)) for _ in range(bs)] for _ in range(Lr)]
+            return empty if layered else empty[0]
         ps = pred_scores.detach().float().reshape(-1, nc)
         ps = (ps.sigmoid() if self.use_fl else ps.softmax(-1))[:, gt_cls]
         pb = pred_bboxes.detach().float().reshape(-1, 4)
@@ -95,24 +101,29 @@ class HungarianMatcher(nn.Module):
         c_l1 = (pb.unsqueeze(1) - gt_bboxes.unsqueeze(0)).abs().sum(-1)
         c_iou = 1.0 - bbox_iou(pb.unsqueeze(1), gt_bboxes.unsqueeze(0), xywh=True, RIOU=True).squeeze(-1)
         C = self.cost_gain['class'] * c_cls + self.cost_gain['bbox'] * c_l1 + self.cost_gain['giou'] * c_iou
-        C = torch.where(torch.isfinite(C), C, torch.zeros_like(C)).view(bs, nq, -1)
+        C = torch.where(torch.isfinite(C), C, torch.zeros_like(C)).view(Lr, bs, nq, -1)
         groups = [int(n) for n in gt_groups]
+        sizes = [min(nq, n) for n in groups]
+        res = []
         if C.is_cuda and not _SCIPY_MATCHER:
             from . import ops
-            bi, si, gi = ops.lsap_assign(C, groups)  # HIP solver, scipy's pairs in scipy's order, nothing leaves the GPU
-            sizes = [min(nq, n) for n in groups]
-            out = Matches(zip(si.split(sizes), gi.split(sizes)))
-            out.flat = (bi, si, gi)
-            return out
+            for l in range(Lr):
+                bi, si, gi = ops.lsap_assign(C[l], groups)  # HIP solver, scipy's pairs in scipy's order, nothing leaves the GPU
+                out = Matches(zip(si.split(sizes), gi.split(sizes)))
+                out.flat = (bi, si, gi)
+                res.append(out)
+            return res if layered else res[0]
         dev, C = C.device, C.cpu()  # reference behaviour: device->host sync, scipy per image
-        out, off = Matches(), 0
-        for i, c in enumerate(C.split(groups, -1)):
-            r, k = linear_sum_assignment(c[i].numpy())
-            out.append((torch.as_tensor(r, dtype=torch.long), torch.as_tensor(k, dtype=torch.long) + off))
-            off += groups[i]
-        if dev.type != 'cpu':
-            out.flat = tuple(t.to(dev) for t in flat_matches(out, 'cpu'))
-        return out
+        for l in range(Lr):
+            out, off = Matches(), 0
+            for i, c in enumerate(C[l].split(groups, -1)):
+                r, k = linear_sum_assignment(c[i].numpy())
+                out.append((torch.as_tensor(r, dtype=torch.long), torch.as_tensor(k, dtype=torch.long) + off))
+                off += groups[i]
+            if dev.type != 'cpu':
+                out.flat = tuple(t.to(dev) for t in flat_matches(out, 'cpu'))
+            res.append(out)
+        return res if layered else res[0]
 
 
 def get_cdn_group(batch, num_classes, num_queries, class_embed, num_dn=100, cls_noise_ratio=0.5, box_noise_scale=1.0,
@@ -201,32 +212,43 @@ class DETRLoss(nn.Module):
         self.matcher = HungarianMatcher(cost_gain={'class': 2, 'bbox': 5, 'giou': 2})
         self.aux_loss, self.use_fl, self.use_vfl = aux_loss, use_fl, use_vfl
 
-    def _layer(self, pb, ps, gt_bboxes, gt_cls, gt_groups, match):
-        """(class, bbox, giou) of one decoder layer."""
+    def _layers(self, pb, ps, gt_bboxes, gt_cls, gt_groups, match):
+        """(class, bbox, giou) of ALL decoder layers at once: pb [layers, bs, nq, 4], ps [layers, bs, nq, nc] -> three [layers]
+        tensors.  Same arithmetic per layer as loss.py:282-326 of the reference; stacking the layers turns eight passes of
+        ~40 tiny kernels (and as many in the backward) into one."""
         dev = pb.device
+        Lr, bs, nq = pb.shape[:3]
         if match is None:
-            match = self.matcher(pb, ps, gt_bboxes, gt_cls, gt_groups)
-        bi, si, gi = flat_matches(match, dev)
-        bs, nq = pb.shape[:2]
-        p_sel, g_sel = pb[bi, si].float(), gt_bboxes[gi]
-        n = int(g_sel.shape[0])
-        targets = torch.full((bs, nq), self.nc, device=dev, dtype=gt_cls.dtype)
-        targets[bi, si] = gt_cls[gi]
-        gt_scores = torch.zeros(bs, nq, device=dev)
+            flats = [flat_matches(m, dev) for m in self.matcher(pb, ps, gt_bboxes, gt_cls, gt_groups)]
+        else:
+            flats = [flat_matches(match, dev)] * Lr
+        n = int(flats[0][0].shape[0])  # matched pairs per layer (every layer matches all boxes: the same count)
+        li = torch.arange(Lr, device=dev).repeat_interleave(n)
+        bi, si, gi = (torch.cat([f[j] for f in flats]) for j in range(3))
+        p_sel, g_sel = pb[li, bi, si].float(), gt_bboxes[gi]
+        targets = torch.full((Lr, bs, nq), self.nc, device=dev, dtype=gt_cls.dtype)
+        targets[li, bi, si] = gt_cls[gi]
+        gt_scores = torch.zeros(Lr, bs, nq, device=dev)
         if n:
-            gt_scores[bi, si] = bbox_iou(p_sel.detach(), g_sel, xywh=True).squeeze(-1)
+            gt_scores[li, bi, si] = bbox_iou(p_sel.detach(), g_sel, xywh=True).squeeze(-1)
         one_hot = F.one_hot(targets, self.nc + 1)[..., :-1]
         ps = ps.float()
-        if n and self.use_vfl:
-            l_cls = varifocal_loss(ps, gt_scores.view(bs, nq, 1) * one_hot, one_hot)
-        else:
-            l_cls = focal_loss(ps, one_hot.float())
+        if n and self.use_vfl:  # varifocal_loss per layer: (...).mean(1).sum() over [bs, nq, nc]
+            label, score = one_hot, gt_scores.unsqueeze(-1) * one_hot
+            w = 0.75 * ps.sigmoid().pow(2.0) * (1 - label) + score * label
+            l_cls = (F.binary_cross_entropy_with_logits(ps, score.float(), reduction='none') * w).mean(2).sum((1, 2))
+        else:  # focal_loss per layer
+            label = one_hot.float()
+            bce = F.binary_cross_entropy_with_logits(ps, label, reduction='none')
+            p = ps.sigmoid()
+            pt = label * p + (1 - label) * (1 - p)
+            l_cls = (bce * (1.0 - pt) ** 1.5 * (label * 0.25 + (1 - label) * 0.75)).mean(2).sum((1, 2))
         l_cls = l_cls / (max(n, 1) / nq) * self.loss_gain['class']
         if n == 0:
-            z = torch.zeros((), device=dev)
+            z = torch.zeros(Lr, device=dev)
             return l_cls, z, z.clone()
-        l_box = self.loss_gain['bbox'] * F.l1_loss(p_sel, g_sel, reduction='sum') / n
-        l_iou = self.loss_gain['giou'] * (1.0 - bbox_iou(p_sel, g_sel, xywh=True, RIOU=True)).sum() / n
+        l_box = self.loss_gain['bbox'] * (p_sel - g_sel).abs().view(Lr, n, 4).sum((1, 2)) / n
+        l_iou = self.loss_gain['giou'] * (1.0 - bbox_iou(p_sel, g_sel, xywh=True, RIOU=True)).view(Lr, n).sum(1) / n
         return l_cls, l_box, l_iou
 
     def forward(self, pred_bboxes, pred_scores, batch, postfix='', match_indices=None):
@@ -235,15 +257,12 @@ class DETRLoss(nn.Module):
             fixed = Matches(match_indices)
             fixed.flat = flat_matches(match_indices, pred_bboxes.device)
             match_indices = fixed
-        out = {}
-        c, b, g = self._layer(pred_bboxes[-1], pred_scores[-1], gt_bboxes, gt_cls, gt_groups, match_indices)
-        out[f'loss_class{postfix}'], out[f'loss_bbox{postfix}'], out[f'loss_giou{postfix}'] = c, b, g
+        if not self.aux_loss:
+            pred_bboxes, pred_scores = pred_bboxes[-1:], pred_scores[-1:]
+        c, b, g = self._layers(pred_bboxes, pred_scores, gt_bboxes, gt_cls, gt_groups, match_indices)
+        out = {f'loss_class{postfix}': c[-1], f'loss_bbox{postfix}': b[-1], f'loss_giou{postfix}': g[-1]}
         if self.aux_loss:
-            aux = [torch.zeros((), device=pred_bboxes.device) for _ in range(3)]
-            for i in range(len(pred_bboxes) - 1):
-                t = self._layer(pred_bboxes[i], pred_scores[i], gt_bboxes, gt_cls, gt_groups, match_indices)
-                aux = [a + v for a, v in zip(aux, t)]
-            out[f'loss_class_aux{postfix}'], out[f'loss_bbox_aux{postfix}'], out[f'loss_giou_aux{postfix}'] = aux
+            out[f'loss_class_aux{postfix}'], out[f'loss_bbox_aux{postfix}'], out[f'loss_giou_aux{postfix}'] = c[:-1].sum(), b[:-1].sum(), g[:-1].sum()
         return out
 
 
