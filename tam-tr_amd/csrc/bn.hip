@@ -6,8 +6,10 @@
 // [16, 64, 320, 320] map of the first layer ran on 64 workgroups of a 256-CU chip (954 us for 630 MB of traffic, 0.66 TB/s),
 // and SiLU was a further full pass each way.  Here a channel is split over B x ceil(HW / 4096) workgroups:
 //   bn_stats     : per-slice (count, mean, M2) with the slice held in registers (exact two-pass inside the slice)
-//   bn_finalize  : Chan-combines the slices of a channel -> batch mean / biased var -> rstd; running stats (unbiased var)
-//   bn_apply     : y = act(gamma * (x - mean) * rstd + beta), act = identity | SiLU, 16-B loads and stores
+//   bn_apply     : every workgroup Chan-combines the channel's slices -> batch mean / biased var -> rstd (the first slice also
+//                  publishes them and updates the running stats with the unbiased var), then
+//                  y = act(gamma * (x - mean) * rstd + beta), act = identity | SiLU, 16-B loads and stores
+//   bn_finalize  : the same combination as its own one-wave-per-channel kernel (channels-last variant)
 //   bn_bwd_reduce: per-slice sums of dz and dz * xhat, dz = gy * act'(z) with z recomputed from x
 //   bn_bwd_apply : gx = gamma * rstd * (dz - mean(dz) - xhat * mean(dz * xhat)); the slice sums of the channel are re-added
 //                  by every workgroup (<= a few hundred floats), d(gamma) / d(beta) are written by the first slice
@@ -117,14 +119,69 @@ __global__ __launch_bounds__(WAVE) void bn_finalize_kernel(const float* __restri
   }
 }
 
+// Chan-combine the S slice partials of channel c inside a workgroup (every apply workgroup redoes it: S <= a few hundred
+// triples, against a 4096-element slice of real work; saves the separate one-wave-per-channel finalize launch)
+__device__ __forceinline__ void combine_slices(const float* __restrict__ part, int c, int S, float* s_tri, float& mean_o, float& m2_o, float& n_o) {
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int s = threadIdx.x; s < S; s += BN_THREADS) {
+    const float* p = part + ((size_t)c * S + s) * 3;
+    const float nb = p[0], mb = p[1], m2b = p[2];
+    const float nt = n + nb, d = mb - mean;
+    mean += d * (nb / nt);
+    m2 += m2b + d * d * (n * nb / nt);
+    n = nt;
+  }
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) {
+    const float nb = __shfl_xor(n, o, WAVE), mb = __shfl_xor(mean, o, WAVE), m2b = __shfl_xor(m2, o, WAVE);
+    const float nt = n + nb;
+    if (nt > 0.f) {
+      const float d = mb - mean;
+      mean += d * (nb / nt);
+      m2 += m2b + d * d * (n * nb / nt);
+    }
+    n = nt;
+  }
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+  if (lane == 0) { s_tri[wave * 3] = n; s_tri[wave * 3 + 1] = mean; s_tri[wave * 3 + 2] = m2; }
+  __syncthreads();
+  n = 0.f; mean = 0.f; m2 = 0.f;
+#pragma unroll
+  for (int w = 0; w < BN_THREADS / WAVE; ++w) {
+    const float nb = s_tri[w * 3], mb = s_tri[w * 3 + 1], m2b = s_tri[w * 3 + 2];
+    const float nt = n + nb;
+    if (nt > 0.f) {
+      const float d = mb - mean;
+      mean += d * (nb / nt);
+      m2 += m2b + d * d * (n * nb / nt);
+    }
+    n = nt;
+  }
+  mean_o = mean; m2_o = m2; n_o = n;
+}
+
 template <typename T>
-__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean_rstd,
-                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               T* __restrict__ y, int C, int HW, int vec, int act) {
-  const int s = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ part,
+                                                               float* __restrict__ mean_rstd, float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, T* __restrict__ y, int C, int HW, int vec,
+                                                               int act, float eps, float momentum) {
+  __shared__ float s_tri[3 * BN_THREADS / WAVE];
+  const int s = blockIdx.x, c = blockIdx.y, b = blockIdx.z, S = gridDim.x * gridDim.z;
+  float mean, m2, cnt_all;
+  combine_slices(part, c, S, s_tri, mean, m2, cnt_all);
+  const float var = m2 / cnt_all, rstd = rsqrtf(var + eps);
+  if (s == 0 && b == 0 && threadIdx.x == 0) {  // the first slice of the channel publishes the statistics
+    mean_rstd[2 * c] = mean;
+    mean_rstd[2 * c + 1] = rstd;
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (cnt_all > 1.f ? m2 / (cnt_all - 1.f) : var);
+    }
+  }
   const int n = min(BN_SLICE, HW - s * BN_SLICE);
   const size_t off = ((size_t)b * C + c) * HW + (size_t)s * BN_SLICE;
-  const float mean = mean_rstd[2 * c], a = mean_rstd[2 * c + 1] * gamma[c], be = beta[c];
+  const float a = rstd * gamma[c], be = beta[c];
   const int base = threadIdx.x * BN_EPT;
   const int cnt = max(0, min(BN_EPT, n - base));
   if (vec && cnt == BN_EPT) {
@@ -360,12 +417,12 @@ extern "C" int tamtr_bn_act_fwd(const void* x, const float* gamma, const float* 
   hipStream_t s = (hipStream_t)stream;
   if (dtype == TAMTR_F32) hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(BN_THREADS), 0, s, (const float*)x, partials, C, HW, vec);
   else hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, dim3(BN_THREADS), 0, s, (const bf16_t*)x, partials, C, HW, vec);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(WAVE), 0, s, partials, mean_rstd, running_mean, running_var, sh * B, eps, momentum);
   if (dtype == TAMTR_F32)
-    hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(BN_THREADS), 0, s, (const float*)x, mean_rstd, gamma, beta, (float*)y, C, HW, vec, act);
+    hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(BN_THREADS), 0, s, (const float*)x, partials, mean_rstd, running_mean, running_var,
+                       gamma, beta, (float*)y, C, HW, vec, act, eps, momentum);
   else
-    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(BN_THREADS), 0, s, (const bf16_t*)x, mean_rstd, gamma, beta, (bf16_t*)y, C, HW, vec,
-                       act);
+    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(BN_THREADS), 0, s, (const bf16_t*)x, partials, mean_rstd, running_mean,
+                       running_var, gamma, beta, (bf16_t*)y, C, HW, vec, act, eps, momentum);
   return tamtr_launch_status();
 }
 

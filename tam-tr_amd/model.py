@@ -134,6 +134,8 @@ class RTDETRDetectionWorldModel(nn.Module):
         with torch.autocast('cuda', dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None):
             if _CHANNELS_LAST and x.is_cuda:
                 x = x.contiguous(memory_format=torch.channels_last)
+            from . import ops
+            counters = ops.begin_bn_counter_batch() if self.training else None
             y = []
             grouped_cast = self.autocast_dtype == torch.bfloat16 and x.is_cuda and torch.is_grad_enabled()
             for m in self.model[:-1]:
@@ -147,7 +149,10 @@ class RTDETRDetectionWorldModel(nn.Module):
                 else:
                     x = m(*args)
                 y.append(x if m.i in self.save else None)
-            return head([y[j] for j in head.f], txt.clone(), batch)
+            out = head([y[j] for j in head.f], txt.clone(), batch)
+            if counters is not None:
+                ops.end_bn_counter_batch()  # num_batches_tracked += 1 of every BatchNorm that ran, in one multi-tensor kernel
+            return out
 
     def loss(self, batch, preds=None):
         if not hasattr(self, 'criterion'):
@@ -175,4 +180,4 @@ class RTDETRDetectionWorldModel(nn.Module):
         terms = self.criterion((dec_bboxes, dec_scores), targets, dn_bboxes=dn_bboxes, dn_scores=dn_scores, dn_meta=dn_meta)
         self.last_loss_terms = terms
         items = torch.stack([terms[k].detach() for k in ('loss_giou', 'loss_class', 'loss_bbox')])
-        return sum(terms.values()), items
+        return torch.stack(list(terms.values())).sum(), items  # 12 terms (loss.py:384-416): one stack + one sum

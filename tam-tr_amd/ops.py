@@ -786,10 +786,30 @@ class _BNActCL(torch.autograd.Function):
         return gx, gg.to(g_dt), gb.to(b_dt), None, None, None, None, None
 
 
+_BN_COUNTERS = None
+
+
+def begin_bn_counter_batch():
+    """Defer the `num_batches_tracked += 1` of every bn_act call (170 one-element kernels per step) to end_bn_counter_batch()."""
+    global _BN_COUNTERS
+    _BN_COUNTERS = []
+    return _BN_COUNTERS
+
+
+def end_bn_counter_batch():
+    global _BN_COUNTERS
+    pending, _BN_COUNTERS = _BN_COUNTERS, None
+    if pending:
+        torch._foreach_add_(pending, 1)
+
+
 def bn_act(x, bn, silu):
     """act(bn(x)) for an nn.BatchNorm2d in training mode (batch statistics; running stats and num_batches_tracked updated)."""
     if bn.track_running_stats:
-        bn.num_batches_tracked += 1
+        if _BN_COUNTERS is not None and bn.momentum is not None:
+            _BN_COUNTERS.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked += 1
     mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
     fn = _BNActCL if x.dim() == 2 else _BNAct   # [N, C] token-major map vs NCHW
     return fn.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
