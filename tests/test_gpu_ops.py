@@ -403,3 +403,45 @@ def test_bn_channels_last_vs_torch(ops, N, C, dt):
     assert_close(xd.grad.float(), xr.grad, 10 * tol, 10 * tol, 'bncl dx')
     assert_close(dev_bn.weight.grad, ref_bn.weight.grad, 10 * tol, 10 * tol * N ** 0.5, 'bncl dgamma')
     assert_close(dev_bn.bias.grad, ref_bn.bias.grad, 10 * tol, 10 * tol * N ** 0.5, 'bncl dbeta')
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE-size properties
+def test_bn_act_full_size_statistics(ops):
+    """[16, 64, 320, 320] bf16 (the first trunk layer at 640 px, bs 16): after BatchNorm every channel has mean beta and standard
+    deviation gamma (size-independent property); running statistics moved by momentum * (batch - running)."""
+    import torch.nn as nn
+    g = torch.Generator(device='cuda').manual_seed(0)
+    x = (torch.randn(16, 64, 320, 320, device='cuda', generator=g) * 2.5 + 1.0).bfloat16()
+    bn = nn.BatchNorm2d(64, eps=1e-3, momentum=0.03).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 2.0, 64)); bn.bias.copy_(torch.linspace(-1, 1, 64))
+    y = ops.bn_act(x, bn, False).detach().float()
+    assert float((y.mean((0, 2, 3)) - bn.bias.detach()).abs().max()) < 2e-2
+    assert float((y.std((0, 2, 3)) / bn.weight.detach() - 1).abs().max()) < 2e-2
+    xm = x.float().mean((0, 2, 3))
+    assert_close(bn.running_mean, 0.03 * xm, 1e-3, 1e-4, 'running mean after one step')
+    assert int(bn.num_batches_tracked) == 1
+
+
+def test_dwconv_full_size_identity_kernel(ops):
+    """Level-0 shape (bs 16, 160 x 160, d_inner 256): with the centre-tap kernel the op is SiLU(xi) laid out in both flattenings."""
+    g = torch.Generator(device='cuda').manual_seed(1)
+    B, H, W, D = 16, 160, 160, 256
+    xz = torch.randn(B, H, W, 2 * D, device='cuda', generator=g).bfloat16()
+    w = torch.zeros(D, 1, 3, 3, device='cuda'); w[:, 0, 1, 1] = 1.0
+    u2 = ops.dwconv_silu_cross(xz, w, None, D)
+    a = torch.nn.functional.silu(xz[..., :D].float()).permute(0, 3, 1, 2)   # [B, D, H, W]
+    assert_close(u2[:, 0].view(B, D, H, W)[3:5], a[3:5], 1e-6, 1e-6, 'row-major plane')
+    assert_close(u2[:, 1].view(B, D, W, H)[11], a[11].transpose(1, 2), 1e-6, 1e-6, 'column-major plane')
+    assert float((u2[:, 0].sum() - u2[:, 1].sum()).abs()) < 1e-3 * float(u2[:, 0].abs().sum())
+
+
+def test_ln_gate_full_size_row_statistics(ops):
+    """409 600 tokens x 256 channels: with gamma = 1, beta = 0 the un-gated rows have zero mean and unit variance."""
+    g = torch.Generator(device='cuda').manual_seed(2)
+    ntok, D = 16 * 160 * 160, 256
+    x = torch.randn(1, ntok, D, device='cuda', generator=g) * 3 + 2
+    xz = torch.zeros(1, ntok, 1, 2 * D, device='cuda', dtype=torch.bfloat16)
+    xz[..., D:] = 20.0   # SiLU(20) = 20 (to 2e-9): the gate becomes a known constant
+    out = ops.ln_gate(x, xz, torch.ones(D, device='cuda'), torch.zeros(D, device='cuda'), 1e-5).float() / 20.0
+    assert float(out.mean(-1).abs().max()) < 2e-2 and float((out.var(-1, unbiased=False) - 1).abs().max()) < 3e-2
