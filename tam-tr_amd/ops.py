@@ -201,7 +201,7 @@ class _LinearSplitK(torch.autograd.Function):
         x2 = _c(x.reshape(-1, x.shape[-1]))
         gx = (g2 @ w16).view(x.shape) if ctx.needs_input_grad[0] else None
         gw = dw_splitk(g2, x2).to(w_dt) if ctx.needs_input_grad[1] else None
-        gb = g2.float().sum(0).to(b_dt) if (b_dt is not None and ctx.needs_input_grad[2]) else None
+        gb = g2.sum(0, dtype=torch.float32).to(b_dt) if (b_dt is not None and ctx.needs_input_grad[2]) else None
         return gx, gw, gb
 
 
@@ -251,7 +251,7 @@ class _LinearBF16(torch.autograd.Function):
             else:
                 gx = (g2 @ w16).view(xshape)
         gw = dw_splitk(g2, x2).to(w_dt) if ctx.needs_input_grad[1] else None
-        gb = g2.float().sum(0).to(b_dt) if (b_dt is not None and ctx.needs_input_grad[2]) else None
+        gb = g2.sum(0, dtype=torch.float32).to(b_dt) if (b_dt is not None and ctx.needs_input_grad[2]) else None
         return gx, gw, gb
 
 
