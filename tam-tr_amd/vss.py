@@ -156,6 +156,17 @@ class VSSBlock(nn.Module):
             return ops.layer_norm(x, norm.weight, norm.bias, norm.eps)  # activation dtype in and out (no autocast casts around it)
         return norm(x)
 
+    def _residual(self, x, branch):
+        """x + DropPath(branch) in one kernel: the per-sample keep mask / (1 - p) is a [B,1,1,1] factor of an addcmul (timm's
+        DropPath as separate ops is a mul, a div and an add over the whole map)."""
+        p = self.drop_path.drop_prob
+        if p == 0.0 or not self.training:
+            return x + branch
+        keep = 1.0 - p
+        scale = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep) / keep
+        return torch.addcmul(x, branch, scale)
+
     def forward(self, x):
-        x = x + self.drop_path(self.op(self._ln(self.norm, x)))
-        return x + self.drop_path(self.mlp(self._ln(self.norm2, x)))
+        x = x.contiguous()  # the head hands in a permuted NCHW view: one copy here keeps both residual adds contiguous
+        x = self._residual(x, self.op(self._ln(self.norm, x)))
+        return self._residual(x, self.mlp(self._ln(self.norm2, x)))
