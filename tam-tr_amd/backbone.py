@@ -126,6 +126,21 @@ class CPAM(nn.Module):
         return ops.cpam(x)  # fused HIP kernels; no torch fallback
 
 
+class Upsample(nn.Upsample):
+    """nn.Upsample (TAMTR.yaml uses nearest with scale 2.0 and 0.5).  For exactly those two factors nearest resampling is an index
+    pattern: x[..., ::2, ::2] and a 2x2 repeat.  Under autocast F.interpolate is an fp32 op: the [16,128,320,320] map of layer 29
+    was cast to fp32 (840 MB) just to be subsampled."""
+
+    def forward(self, x):
+        if self.mode == 'nearest' and x.dim() == 4 and self.size is None and isinstance(self.scale_factor, (int, float)):
+            if self.scale_factor == 0.5 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+                return x[..., ::2, ::2]
+            if self.scale_factor == 2.0:
+                B, C, H, W = x.shape
+                return x[:, :, :, None, :, None].expand(B, C, H, 2, W, 2).reshape(B, C, 2 * H, 2 * W)
+        return super().forward(x)
+
+
 class Concat(nn.Module):
     def __init__(self, dimension=1):
         super().__init__()

@@ -7,7 +7,7 @@ keys are `model.{i}.…` and reference checkpoints' state_dicts load with strict
 import torch
 import torch.nn as nn
 
-from .backbone import CPAM, Concat, Conv, RepNCSPELAN4, SPPELAN
+from .backbone import CPAM, Concat, Conv, RepNCSPELAN4, SPPELAN, Upsample
 from .head import ManbaWorldDecoder
 from .hostio import stager
 from .loss import RTDETRDetectionLoss
@@ -45,7 +45,7 @@ def build_graph(spec, ch=3, nc=10):
         elif name == 'SPPELAN':
             m, c2 = SPPELAN(cin, *args), args[0]
         elif name == 'Upsample':
-            m, c2 = nn.Upsample(None, args[0], 'nearest'), cin
+            m, c2 = Upsample(None, args[0], 'nearest'), cin
         elif name == 'Concat':
             m, c2 = Concat(*args), sum(chans[j] for j in f)
         elif name == 'CPAM':
