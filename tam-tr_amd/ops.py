@@ -509,16 +509,16 @@ class _XProjCross(torch.autograd.Function):
         Bn, _, D, L = ub.shape
         C = R + 2 * N
         S = _split_len(L)
-        gws, gus = [], []
+        gws = []
+        gu2 = torch.empty(Bn, 2, D, L, device=ub.device, dtype=u_dt)  # each product is cast straight into its plane (no stack + cast)
         with torch.autocast('cuda', enabled=False):
             for i, w in ((0, wa), (1, wb)):
                 gx = torch.cat([gdtr[:, i], gBs[:, i], gCs[:, i], gdtr[:, i + 2], gBs[:, i + 2], gCs[:, i + 2]], 1).to(cdt)  # [B, 2C, L]
-                gus.append(torch.matmul(w.t(), gx))
+                gu2[:, i].copy_(torch.matmul(w.t(), gx))
                 ga = gx.view(Bn, 2 * C, S, L // S).transpose(1, 2).reshape(Bn * S, 2 * C, L // S)
                 ua = ub[:, i].reshape(Bn, D, S, L // S).transpose(1, 2).reshape(Bn * S, D, L // S)
                 gws.append(torch.bmm(ga, ua.transpose(1, 2)).float().sum(0))  # [2C, D]
         gwx = torch.stack([gws[0][:C], gws[1][:C], gws[0][C:], gws[1][C:]], 0).to(w_dt)
-        gu2 = torch.stack(gus, 1).to(u_dt)
         return gwx, gu2, None, None
 
 
