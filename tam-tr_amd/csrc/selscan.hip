@@ -235,7 +235,12 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return v;
 }
 
-// Forward: FWD_ROWS waves = FWD_ROWS rows of ONE (b, k) group per workgroup.
+// Forward: FWD_ROWS waves x FWD_RPW rows each = rows of ONE (b, k) group per workgroup; the chunk's B/C/dt tiles are staged once
+// for all of them.
+#ifndef SCAN_FWD_RPW
+#define SCAN_FWD_RPW 4   // measured fwd ms (level 0 / 1 / 2): 1 row per wave 3.87 / 2.00 / 1.22, 2 rows 3.71 / 1.85 / 1.13, 4 rows 3.67 / 1.78 / 1.03
+#endif
+constexpr int FWD_RPW = SCAN_FWD_RPW;
 template <bool VEC>
 __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float* __restrict__ u, const float* __restrict__ delta,
                                                                       const float* __restrict__ Am, const float* __restrict__ Bm,
@@ -246,78 +251,85 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
                                                                       const float* __restrict__ Wdt, int R) {
   __shared__ float sB[NS][CHUNK];
   __shared__ float sC[NS][CHUNK];
-  __shared__ float s_A[FWD_ROWS][NS], s_h[FWD_ROWS][NS];  // wave-private, wave-uniform per-state values (A*log2e, carried h)
-  extern __shared__ float s_dyn[];                        // fused dt projection: [R][CHUNK] factors + [FWD_ROWS][RMAX] rows of Wdt
+  __shared__ float s_A[FWD_ROWS][FWD_RPW][NS], s_h[FWD_ROWS][FWD_RPW][NS];  // wave-private per-state values (A*log2e, carried h)
+  __shared__ float s_rc[FWD_ROWS][FWD_RPW][2];                               // D and delta bias of the wave's rows
+  extern __shared__ float s_dyn[];  // fused dt projection: [R][CHUNK] factors + [FWD_ROWS * FWD_RPW][RMAX] rows of Wdt
   float(*s_dtr)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(s_dyn);
   float* s_W = s_dyn + (size_t)R * CHUNK;
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-  const int d = blockIdx.x * FWD_ROWS + wave;
-  const bool live = d < Dk;
+  const int d0 = (blockIdx.x * FWD_ROWS + wave) * FWD_RPW;
   const int bk = blockIdx.y, k = bk % K;
-  const int kd = k * Dk + (live ? d : 0);
-  const size_t row = (size_t)(bk / K) * K * Dk + kd;
   // cross-scan layout (xmode): u is [B, 2, Dk, L] (k & 1 picks the row-major / column-major copy) and directions k >= 2
   // walk every time-indexed buffer back to front
   const bool rev = xmode && k >= 2;
-  const float* up = xmode ? u + (((size_t)(bk / K) * 2 + (k & 1)) * Dk + (live ? d : 0)) * L : u + row * L;
-  const float* dp = delta + row * L;
   const float* Bp = Bm + (size_t)bk * NS * L;
   const float* Cp = Cm + (size_t)bk * NS * L;
-  float* yp = y + row * L;
-  float* An = s_A[wave];
-  float* h = s_h[wave];
-  if (lane < NS) { An[lane] = Am[(size_t)kd * NS + lane] * LOG2E; h[lane] = 0.f; }
-  if (dtr && lane < R) s_W[wave * RMAX + lane] = Wdt[(size_t)kd * R + lane];
+#pragma unroll
+  for (int r = 0; r < FWD_RPW; ++r) {
+    const int kd = k * Dk + min(d0 + r, Dk - 1);
+    if (lane < NS) { s_A[wave][r][lane] = Am[(size_t)kd * NS + lane] * LOG2E; s_h[wave][r][lane] = 0.f; }
+    if (lane == 0) { s_rc[wave][r][0] = Dv[kd]; s_rc[wave][r][1] = dbias[kd]; }
+    if (dtr && lane < R) s_W[(wave * FWD_RPW + r) * RMAX + lane] = Wdt[(size_t)kd * R + lane];
+  }
   const float* Rp = dtr ? dtr + (size_t)bk * R * L : nullptr;
-  const float Dd = Dv[kd], bias = dbias[kd];
 
   for (int c = 0; c < nchunk; ++c) {
     __syncthreads();  // previous chunk's tile fully consumed
     stage_bc<FWD_ROWS * WAVE>(Bp, Cp, c * CHUNK, L, sB, sC, VEC, rev);
     if (dtr) stage_dtr<FWD_ROWS * WAVE>(Rp, R, c * CHUNK, L, s_dtr, VEC, rev);
     __syncthreads();
-    if (!live) continue;
     const int t = c * CHUNK + lane * ITEMS;
-    float uu[ITEMS], dt[ITEMS], dtu[ITEMS], yy[ITEMS];
-    load4<VEC>(up, t, L, uu, 0.f, rev);
-    if (dtr) {  // delta_t = <Wdt[kd, :], dtr[:, t]>: the [B, 4*d_inner, L] delta tensor of the reference is never materialised
-      dt[0] = dt[1] = dt[2] = dt[3] = 0.f;
-      dtproj_row(s_W + wave * RMAX, s_dtr, R, lane, dt);
-    } else {
-      load4<VEC>(dp, t, L, dt, 0.f, rev);
-    }
+#pragma unroll 1
+    for (int r = 0; r < FWD_RPW; ++r) {
+      const int d = d0 + r;
+      if (d >= Dk) break;  // wave-uniform
+      const int kd = k * Dk + d;
+      const size_t row = (size_t)(bk / K) * K * Dk + kd;
+      const float* up = xmode ? u + (((size_t)(bk / K) * 2 + (k & 1)) * Dk + d) * L : u + row * L;
+      const float* An = s_A[wave][r];
+      float* h = s_h[wave][r];
+      const float Dd = s_rc[wave][r][0], bias = s_rc[wave][r][1];
+      float uu[ITEMS], dt[ITEMS], dtu[ITEMS], yy[ITEMS];
+      load4<VEC>(up, t, L, uu, 0.f, rev);
+      if (dtr) {  // delta_t = <Wdt[kd, :], dtr[:, t]>: the [B, 4*d_inner, L] delta tensor of the reference is never materialised
+        dt[0] = dt[1] = dt[2] = dt[3] = 0.f;
+        dtproj_row(s_W + (wave * FWD_RPW + r) * RMAX, s_dtr, R, lane, dt);
+      } else {
+        load4<VEC>(delta + row * L, t, L, dt, 0.f, rev);
+      }
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-      dt[i] = (t + i < L) ? softplus_f(dt[i] + bias) : 0.f;  // steps beyond L become the identity map (a = 1, b = 0)
-      dtu[i] = dt[i] * uu[i];
-      yy[i] = Dd * uu[i];
-    }
+      for (int i = 0; i < ITEMS; ++i) {
+        dt[i] = (t + i < L) ? softplus_f(dt[i] + bias) : 0.f;  // steps beyond L become the identity map (a = 1, b = 0)
+        dtu[i] = dt[i] * uu[i];
+        yy[i] = Dd * uu[i];
+      }
 #pragma unroll 4
-    for (int n = 0; n < NS; ++n) {
-      const float4 b4 = *reinterpret_cast<const float4*>(&sB[n][lane * ITEMS]);
-      const float4 c4 = *reinterpret_cast<const float4*>(&sC[n][lane * ITEMS]);
-      float bb[ITEMS] = {b4.x, b4.y, b4.z, b4.w}, cc[ITEMS] = {c4.x, c4.y, c4.z, c4.w}, a[ITEMS];
-      const float An_n = An[n];
-      float A = 1.f, Bv = 0.f;
+      for (int n = 0; n < NS; ++n) {
+        const float4 b4 = *reinterpret_cast<const float4*>(&sB[n][lane * ITEMS]);
+        const float4 c4 = *reinterpret_cast<const float4*>(&sC[n][lane * ITEMS]);
+        float bb[ITEMS] = {b4.x, b4.y, b4.z, b4.w}, cc[ITEMS] = {c4.x, c4.y, c4.z, c4.w}, a[ITEMS];
+        const float An_n = An[n];
+        float A = 1.f, Bv = 0.f;
 #pragma unroll
-      for (int i = 0; i < ITEMS; ++i) {
-        a[i] = __builtin_amdgcn_exp2f(dt[i] * An_n);
-        bb[i] *= dtu[i];
-        Bv = fmaf(a[i], Bv, bb[i]);
-        A *= a[i];
-      }
-      wave_scan_prefix(A, Bv);
-      const float EA = prev_lane(1.f, A), EB = prev_lane(0.f, Bv);
-      float hh = fmaf(EA, h[n], EB);  // state entering this lane's first step
+        for (int i = 0; i < ITEMS; ++i) {
+          a[i] = __builtin_amdgcn_exp2f(dt[i] * An_n);
+          bb[i] *= dtu[i];
+          Bv = fmaf(a[i], Bv, bb[i]);
+          A *= a[i];
+        }
+        wave_scan_prefix(A, Bv);
+        const float EA = prev_lane(1.f, A), EB = prev_lane(0.f, Bv);
+        float hh = fmaf(EA, h[n], EB);  // state entering this lane's first step
 #pragma unroll
-      for (int i = 0; i < ITEMS; ++i) {
-        hh = fmaf(a[i], hh, bb[i]);
-        yy[i] = fmaf(cc[i], hh, yy[i]);
+        for (int i = 0; i < ITEMS; ++i) {
+          hh = fmaf(a[i], hh, bb[i]);
+          yy[i] = fmaf(cc[i], hh, yy[i]);
+        }
+        if (lane == WAVE - 1) h[n] = hh;  // state after the chunk
       }
-      if (lane == WAVE - 1) h[n] = hh;  // state after the chunk
+      store4<VEC>(y + row * L, t, L, yy, rev);
+      if (lane < NS) hstate[(row * nchunk + c) * NS + lane] = h[lane];
     }
-    store4<VEC>(yp, t, L, yy, rev);
-    if (lane < NS) hstate[(row * nchunk + c) * NS + lane] = h[lane];
   }
 }
 
@@ -738,9 +750,9 @@ static int scan_fwd_launch(const float* u, const float* delta, const float* dtr,
   if (xmode != 0 && xmode != 1) return TAMTR_EINVAL;
   if (N != NS || (long long)B * K > 65535 || (xmode && K != 4) || (dtr && (R < 1 || R > RMAX))) return TAMTR_EUNSUP;
   const int nchunk = (L + CHUNK - 1) / CHUNK;
-  dim3 grid((Dk + FWD_ROWS - 1) / FWD_ROWS, B * K);
+  dim3 grid((Dk + FWD_ROWS * FWD_RPW - 1) / (FWD_ROWS * FWD_RPW), B * K);
   hipStream_t s = (hipStream_t)stream;
-  const size_t dyn = dtr ? ((size_t)R * CHUNK + FWD_ROWS * RMAX) * sizeof(float) : 0;
+  const size_t dyn = dtr ? ((size_t)R * CHUNK + FWD_ROWS * FWD_RPW * RMAX) * sizeof(float) : 0;
   if (L % 4 == 0)
     hipLaunchKernelGGL(selscan_fwd_kernel<true>, grid, dim3(FWD_ROWS * WAVE), dyn, s, u, delta, A, Bm, Cm, D, dbias, y, hstate, K, Dk,
                        L, nchunk, xmode, dtr, Wdt, R);
