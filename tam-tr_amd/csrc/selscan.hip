@@ -709,7 +709,11 @@ __global__ __launch_bounds__(256) void dtproj_gdtr_kernel(const float* __restric
 #pragma unroll
   for (int r = 0; r < RT; ++r) acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f;
   const float* gp = gdelta + (size_t)bk * Dk * L;
-  for (int d0 = 0; d0 < Dk; d0 += 64) {
+  // gridDim.z > 1: the Dk rows are split over z (short sequences alone do not fill the chip: L = 1600 gives 2 x 64 workgroups);
+  // the slices are then combined with float atomics into a zeroed gdtr (<= 16 adders per element)
+  const int dper = ((Dk + (int)gridDim.z - 1) / (int)gridDim.z + 63) / 64 * 64;
+  const int dbeg = blockIdx.z * dper, dend = min(Dk, dbeg + dper);
+  for (int d0 = dbeg; d0 < dend; d0 += 64) {
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * RT; i += 256) {
       const int dd = i / RT, r = i % RT;
@@ -717,7 +721,7 @@ __global__ __launch_bounds__(256) void dtproj_gdtr_kernel(const float* __restric
     }
     __syncthreads();
     if (live) {
-      const int dn = min(64, Dk - d0);
+      const int dn = min(64, dend - d0);
       for (int dd = 0; dd < dn; ++dd) {
         const float4 g = *reinterpret_cast<const float4*>(gp + (size_t)(d0 + dd) * L + l0);
 #pragma unroll
@@ -732,7 +736,11 @@ __global__ __launch_bounds__(256) void dtproj_gdtr_kernel(const float* __restric
   if (live) {
 #pragma unroll
     for (int r = 0; r < RT; ++r)
-      if (r < R) *reinterpret_cast<float4*>(gdtr + ((size_t)bk * R + r) * L + l0) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+      if (r < R) {
+        float* o = gdtr + ((size_t)bk * R + r) * L + l0;
+        if (gridDim.z == 1) *reinterpret_cast<float4*>(o) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+        else if (dbeg < dend) { atomicAdd(o, acc[r][0]); atomicAdd(o + 1, acc[r][1]); atomicAdd(o + 2, acc[r][2]); atomicAdd(o + 3, acc[r][3]); }
+      }
   }
 }
 
@@ -830,6 +838,11 @@ static int scan_bwd_launch(const float* gy, const float* u, const float* delta, 
     hipLaunchKernelGGL(dtproj_gdtr_scalar_kernel, dim3((L + 255) / 256, B * K), dim3(256), 0, s, gdelta, Wdt, gdtr, K, Dk, R, L);
   } else if (dtr) {  // gdtr = Wdt^T gdelta (position space, un-reversed)
     dim3 g2((L / 4 + 255) / 256, B * K);
+    const int wgs = (int)g2.x * B * K;
+    if (wgs < 768 && Dk >= 128) {  // not enough workgroups for 256 CUs: split the rows, combine with atomics
+      g2.z = (unsigned)min(Dk / 64, (1024 + wgs - 1) / wgs);
+      (void)hipMemsetAsync(gdtr, 0, (size_t)B * K * R * L * sizeof(float), s);
+    }
     if (R <= 8) hipLaunchKernelGGL(dtproj_gdtr_kernel<8>, g2, dim3(256), 0, s, gdelta, Wdt, gdtr, K, Dk, R, L);
     else if (R <= 16) hipLaunchKernelGGL(dtproj_gdtr_kernel<16>, g2, dim3(256), 0, s, gdelta, Wdt, gdtr, K, Dk, R, L);
     else hipLaunchKernelGGL(dtproj_gdtr_kernel<32>, g2, dim3(256), 0, s, gdelta, Wdt, gdtr, K, Dk, R, L);
