@@ -130,40 +130,48 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_cross_bwd_kernel(const floa
     s_g[c][py][px] = (h >= 0 && h < H && w >= 0 && w < W) ? g2[((size_t)(b * 2) * D + d0 + c) * L + (size_t)h * W + w] : 0.f;
   }
   __syncthreads();
-  // + gradient of the column-major plane, lanes along y; then times SiLU'(conv) with the conv recomputed from the staged input
-  for (int it = threadIdx.x; it < CB * GS * GS; it += DW_THREADS) {
-    const int c = it / (GS * GS), r = it - c * (GS * GS), px = r / GS, py = r - px * GS;
-    const int h = h0 + py - 1, w = w0 + px - 1;
-    float g = 0.f;
-    if (h >= 0 && h < H && w >= 0 && w < W) {
-      g = s_g[c][py][px] + g2[((size_t)(b * 2 + 1) * D + d0 + c) * L + (size_t)w * H + h];
-      float acc = s_w[c][9];
+  // + gradient of the column-major plane (lanes along y), times SiLU'(conv) with the conv recomputed from the staged input.
+  // 16 threads per channel walk its 18 x 18 halo pixels: the nine inputs loaded for the conv are exactly the factors of
+  // d(weight) for that pixel, so the per-(channel, tap) sums ride along in registers (core pixels only) and are combined over
+  // the 16 threads at the end - no separate pass over the tile.
+  {
+    static_assert(DW_THREADS == CB * 16, "16 threads per channel");
+    const int c = threadIdx.x / 16, sub = threadIdx.x % 16;
+    float wk[9], dwk[10];
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+    for (int k9 = 0; k9 < 9; ++k9) { wk[k9] = s_w[c][k9]; dwk[k9] = 0.f; }
+    dwk[9] = 0.f;
+    const float bc = s_w[c][9];
+    for (int r = sub; r < GS * GS; r += 16) {
+      const int px = r / GS, py = r - px * GS;
+      const int h = h0 + py - 1, w = w0 + px - 1;
+      float g = 0.f;
+      if (h >= 0 && h < H && w >= 0 && w < W) {
+        g = s_g[c][py][px] + g2[((size_t)(b * 2 + 1) * D + d0 + c) * L + (size_t)w * H + h];
+        float xin[9], acc = bc;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) acc = fmaf(s_w[c][ky * 3 + kx], s_x[c][py + ky][px + kx], acc);
-      const float sg = 1.f / (1.f + __expf(-acc));
-      g *= sg * (1.f + acc * (1.f - sg));
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) { xin[ky * 3 + kx] = s_x[c][py + ky][px + kx]; acc = fmaf(wk[ky * 3 + kx], xin[ky * 3 + kx], acc); }
+        const float sg = 1.f / (1.f + __expf(-acc));
+        g *= sg * (1.f + acc * (1.f - sg));
+        if (py >= 1 && py <= TS && px >= 1 && px <= TS) {  // core pixel of this tile: counts once over all tiles
+#pragma unroll
+          for (int k9 = 0; k9 < 9; ++k9) dwk[k9] = fmaf(g, xin[k9], dwk[k9]);
+          dwk[9] += g;
+        }
+      }
+      s_g[c][py][px] = g;
     }
-    s_g[c][py][px] = g;
+#pragma unroll
+    for (int k9 = 0; k9 < 10; ++k9) dwk[k9] = group_sum<16>(dwk[k9]);
+    if (sub == 0) {
+      float* o = ws + (((size_t)b * tiles + blockIdx.x) * D + d0 + c) * 10;
+#pragma unroll
+      for (int k9 = 0; k9 < 10; ++k9) o[k9] = dwk[k9];
+    }
   }
   __syncthreads();
-  // d(weight) / d(bias) partials of this tile: thread (c, tap) sums over the 256 core pixels
-  if (threadIdx.x < CB * 10) {
-    const int c = threadIdx.x / 10, k = threadIdx.x - c * 10;
-    const int ky = k / 3, kx = k - ky * 3;
-    float acc = 0.f;
-    if (k < 9) {
-      for (int py = 0; py < TS; ++py)
-#pragma unroll
-        for (int px = 0; px < TS; ++px) acc = fmaf(s_g[c][py + 1][px + 1], s_x[c][py + 1 + ky][px + 1 + kx], acc);
-    } else {
-      for (int py = 0; py < TS; ++py)
-#pragma unroll
-        for (int px = 0; px < TS; ++px) acc += s_g[c][py + 1][px + 1];
-    }
-    ws[(((size_t)b * tiles + blockIdx.x) * D + d0 + c) * 10 + k] = acc;
-  }
   // d(input) on the core: transposed 3x3 of dL/d(conv)
   const int ty = threadIdx.x / TS, tx = threadIdx.x % TS;
   float dxv[CB];
