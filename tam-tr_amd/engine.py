@@ -10,10 +10,15 @@
   ap_per_class, compute_ap, smooth, box_iou   ultralytics/utils/metrics.py:49-68,941-946,999-1029,1032-1128
   Validator            models/rtdetrworld/val.py:130-173 + models/yolo/detect/val.py get_stats
 
-Host-side PyTorch / numpy by design (the reference's is too); dataset decoding, augmentation and the CLIP text encoder stay
-out of scope - batches arrive as tensors (img, txt_feats, cls, bboxes, batch_idx [, ori_shape]).
+  fit                  ultralytics/engine/trainer.py:262-281,285-420 (the epoch loop: warm-up, step, schedule, EMA validation,
+                       last / best checkpoints) over data.py's loaders
+
+Host-side PyTorch / numpy by design (the reference's is too).  Batches arrive as tensors (img, txt_feats, cls, bboxes, batch_idx
+[, ori_shape]) - from data.py's loaders or synthetic; the CLIP text encoder stays out of scope (precomputed table, data.py).
 """
 import math
+import os
+import time
 from copy import deepcopy
 
 import numpy as np
@@ -283,3 +288,77 @@ def validate(model, batches, imgsz=640, conf=0.001, iou=0.7, autocast_dtype=None
         v.update(preds, batch)
     model.train(was_training)
     return v.results()
+
+
+# ------------------------------------------------------------------------------------------------ the epoch loop
+def fitness(metrics):
+    """0.1 * mAP50 + 0.9 * mAP50-95 (utils/metrics.py:1252-1256)."""
+    return 0.1 * metrics['mAP50'] + 0.9 * metrics['mAP50-95']
+
+
+def fit(model, train_loader, prepare, epochs, val_loader=None, lr0=1e-4, lrf=1.0, momentum=0.9, weight_decay=1e-4, optimizer='AdamW',
+        warmup_iters=2000, warmup_bias_lr=0.1, warmup_momentum=0.8, close_mosaic=0, imgsz=640, reducer=None, rank=0, world=1,
+        save_dir=None, max_steps=None, log=None):
+    """Train `model` for `epochs` passes over train_loader; defaults are the reference's shipped hyper-parameters
+    (cfg/default.yaml:23,84-90; this fork sets nbs = batch, so there is no gradient accumulation and weight decay is unscaled, and
+    reads warmup_epochs as an iteration count: trainer.py:263-265,294).
+
+    prepare(batch, training) -> batch on the device (data.preprocess_batch with the prompt table bound).  reducer: dist.GradReducer for
+    world > 1 - gradients are SUMMED over ranks, which is the reference's mean-reduce of a loss pre-multiplied by world_size
+    (trainer.py:346-347).  Rank 0 validates the EMA weights after every epoch and keeps last.pt / best.pt under save_dir.
+    Returns the per-epoch records."""
+    nb = len(train_loader)
+    opt = build_optimizer(model, name=optimizer, lr=lr0, momentum=momentum, decay=weight_decay,
+                          iterations=math.ceil(len(train_loader.dataset) / max(train_loader.batch_size or 1, 1)) * epochs)
+    lf = linear_lr(epochs, lrf)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lf)
+    ema = ModelEMA(model) if rank == 0 else None
+    history, best, steps = [], None, 0
+    for epoch in range(epochs):
+        model.train()
+        if hasattr(train_loader.sampler, 'set_epoch'):
+            train_loader.sampler.set_epoch(epoch)
+        if close_mosaic and epoch == epochs - close_mosaic and hasattr(train_loader.dataset, 'close_mosaic'):
+            train_loader.dataset.close_mosaic()
+        t0, mean_items = time.time(), None
+        opt.zero_grad(set_to_none=True)
+        for i, batch in enumerate(train_loader):
+            warmup(opt, i + nb * epoch, warmup_iters, lf(epoch), warmup_bias_lr, warmup_momentum, momentum)
+            batch = prepare(batch, True)
+            if reducer is not None:
+                reducer.prepare()
+            loss, items = model(batch)
+            loss.backward()
+            if reducer is not None:
+                reducer.finish()
+            torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], max_norm=0.1)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            if ema is not None:
+                ema.update(model)
+            mean_items = items.detach() if mean_items is None else (mean_items * i + items.detach()) / (i + 1)   # no host sync
+            steps += 1
+            if max_steps is not None and steps >= max_steps:
+                break
+        rec = {'epoch': epoch, 'steps': steps, 'seconds': time.time() - t0, 'lr': [g['lr'] for g in opt.param_groups],
+               'loss_items': mean_items.float().cpu().tolist() if mean_items is not None else []}
+        sched.step()
+        if rank == 0:
+            if val_loader is not None:
+                rec.update(validate(ema.ema, (prepare(b, False) for b in val_loader), imgsz=imgsz,
+                                    autocast_dtype=getattr(model, 'autocast_dtype', None)))
+                rec['fitness'] = fitness(rec)
+            if save_dir is not None:
+                os.makedirs(save_dir, exist_ok=True)
+                ckpt = {'epoch': epoch, 'model': model.state_dict(), 'ema': ema.ema.state_dict(), 'updates': ema.updates,
+                        'optimizer': opt.state_dict(), 'metrics': {k: v for k, v in rec.items() if isinstance(v, float)}}
+                torch.save(ckpt, os.path.join(save_dir, 'last.pt'))
+                if val_loader is not None and (best is None or rec['fitness'] >= best):
+                    best = rec['fitness']
+                    torch.save(ckpt, os.path.join(save_dir, 'best.pt'))
+            if log:
+                log(rec)
+        history.append(rec)
+        if max_steps is not None and steps >= max_steps:
+            break
+    return history

@@ -17,6 +17,7 @@ identity (head / end-to-end fixtures; flag recorded) or driven through forward_c
 argument with a closed-form surrogate (vss fixture) so that everything *around* the scan is pinned.
 """
 import importlib.machinery
+import math
 import os
 import sys
 import types
@@ -592,6 +593,200 @@ def gen_metrics():
     save('metrics', d)
 
 
+def gen_data():
+    """Data path through the reference's own host functions: verify_image_label / img2label_paths
+    (data/utils.py), Instances conversions (utils/instance.py), RandomPerspective's box path, RandomFlip, RandomLoadText, Mosaic,
+    MixUp, Format (data/augment.py) and YOLODataset.collate_fn (data/dataset.py).
+
+    cv2 is an inert placeholder in this container, so for RandomPerspective two of its entry points are given here:
+    getRotationMatrix2D as OpenCV documents it for centre (0, 0) ([[a, b, 0], [-b, a, 0]], a = s cos, b = s sin) and a warpAffine
+    that returns a blank canvas of the requested size - only the random draws, the matrix and the box path of that transform are
+    stored, never its image."""
+    import random
+    import tempfile
+    import types as _t
+    import cv2
+    from PIL import Image
+    from ultralytics.data.augment import Format, MixUp, Mosaic, RandomFlip, RandomLoadText, RandomPerspective
+    from ultralytics.data.dataset import YOLODataset
+    from ultralytics.data.utils import img2label_paths, verify_image_label
+    from ultralytics.utils.instance import Instances
+    g = np.random.default_rng(21)
+    d = {}
+
+    # --- label files ------------------------------------------------------------------------------------------
+    paths = ['/d/images/train/a.jpg', '/d/images/images/b.c.png', 'rel/images/x/y.jpeg']
+    d['paths.in'], d['paths.out'] = np.array(paths), np.array(img2label_paths(paths))
+    cases = {
+        'plain': '3 0.5 0.5 0.2 0.1\n0 0.25 0.75 0.1 0.3\n9 0.9 0.1 0.05 0.05\n',
+        'dups': '1 0.5 0.5 0.2 0.2\n4 0.3 0.3 0.1 0.1\n1 0.5 0.5 0.2 0.2\n0 0.1 0.2 0.05 0.06\n4 0.3 0.3 0.1 0.1\n',
+        'blank_lines': '\n2 0.4 0.4 0.1 0.1\n\n5 0.6 0.6 0.2 0.2\n\n',
+        'empty': '',
+        'six_cols': '1 0.5 0.5 0.2 0.2 0.9\n',
+        'four_cols': '1 0.5 0.5 0.2\n',
+        'out_of_bounds': '1 0.5 1.5 0.2 0.2\n',
+        'negative': '1 0.5 -0.1 0.2 0.2\n',
+        'big_class': '11 0.5 0.5 0.2 0.2\n',
+        'class_eq_nc': '10 0.5 0.5 0.2 0.2\n',
+    }
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(f'{tmp}/images'), os.makedirs(f'{tmp}/labels')
+        for name, text in list(cases.items()) + [('missing', None)]:
+            Image.fromarray(g.integers(0, 255, (24, 40, 3), dtype=np.uint8)).save(f'{tmp}/images/{name}.png')
+            if text is not None:
+                with open(f'{tmp}/labels/{name}.txt', 'w') as f:
+                    f.write(text)
+            r = verify_image_label((f'{tmp}/images/{name}.png', f'{tmp}/labels/{name}.txt', '', False, 10, 0, 0))
+            d[f'labels.{name}.text'] = np.array('' if text is None else text)
+            d[f'labels.{name}.ok'] = np.array(r[0] is not None)
+            if r[0] is not None:
+                d[f'labels.{name}.lb'], d[f'labels.{name}.shape'] = r[1], np.array(r[2])
+    d['labels.names'] = np.array(list(cases) + ['missing'])
+
+    # --- box conversions --------------------------------------------------------------------------------------
+    n = 12
+    xywhn = np.concatenate([g.uniform(0.1, 0.9, (n, 2)), g.uniform(0.01, 0.2, (n, 2))], 1).astype(np.float32)
+    ins = Instances(xywhn.copy(), bbox_format='xywh', normalized=True)
+    ins.convert_bbox('xyxy')
+    ins.denormalize(640, 480)
+    d['box.xywhn'], d['box.xyxy_px'] = xywhn, ins.bboxes.copy()
+    ins.add_padding(13, -7)
+    ins.clip(600, 470)
+    d['box.padded_clipped'] = ins.bboxes.copy()
+    ins.convert_bbox('xywh')
+    ins.normalize(600, 470)
+    d['box.back_xywhn'] = ins.bboxes.copy()
+
+    # --- RandomPerspective: draws, matrix, boxes, filter ------------------------------------------------------
+    cv2.getRotationMatrix2D = lambda angle, center, scale: np.array(
+        [[scale * math.cos(math.radians(angle)), scale * math.sin(math.radians(angle)), 0.0],
+         [-scale * math.sin(math.radians(angle)), scale * math.cos(math.radians(angle)), 0.0]])
+    cv2.warpAffine = lambda img, M, dsize, borderValue: np.zeros((dsize[1], dsize[0], img.shape[2]), np.uint8)
+    for ci, (kw, border, seed) in enumerate([(dict(degrees=0.0, translate=0.1, scale=0.9, shear=0.0), None, 5),
+                                               (dict(degrees=10.0, translate=0.2, scale=0.5, shear=2.0), None, 6),
+                                               (dict(degrees=0.0, translate=0.1, scale=0.5, shear=0.0), (-32, -32), 7)]):
+        h, w = (64, 64) if border is None else (128, 128)
+        nb = 20
+        b = np.concatenate([g.uniform(0.05, 0.95, (nb, 2)), g.uniform(0.02, 0.4, (nb, 2))], 1).astype(np.float32)
+        cls = g.integers(0, 10, (nb, 1)).astype(np.float32)
+        lab = {'img': np.zeros((h, w, 3), np.uint8), 'cls': cls.copy(), 'instances': Instances(b.copy(), bbox_format='xywh', normalized=True)}
+        if border is not None:
+            lab['mosaic_border'] = border
+        t = RandomPerspective(pre_transform=None, **kw)
+        random.seed(seed)
+        captured = {}
+        orig = t.affine_transform
+
+        def spy(img, brd, _o=orig, _c=captured):
+            out = _o(img, brd)
+            _c['M'], _c['s'] = out[1].copy(), out[2]
+            return out
+        t.affine_transform = spy
+        out = t(lab)
+        p = f'affine{ci}.'
+        d[p + 'kw'] = np.array([kw['degrees'], kw['translate'], kw['scale'], kw['shear']])
+        d[p + 'border'] = np.array(border if border is not None else (0, 0))
+        d[p + 'seed'], d[p + 'hw'] = np.array(seed), np.array((h, w))
+        d[p + 'in.boxes'], d[p + 'in.cls'] = b, cls
+        d[p + 'M'], d[p + 's'] = captured['M'], np.array(captured['s'])
+        d[p + 'out.boxes'], d[p + 'out.cls'] = out['instances'].bboxes.copy(), out['cls'].copy()
+        d[p + 'out.shape'] = np.array(out['img'].shape)
+        d[p + 'next_draw'] = np.array(random.random())
+
+    # --- RandomFlip -------------------------------------------------------------------------------------------
+    img = g.integers(0, 255, (10, 14, 3), dtype=np.uint8)
+    b = np.concatenate([g.uniform(0.1, 0.9, (6, 2)), g.uniform(0.02, 0.2, (6, 2))], 1).astype(np.float32)
+    d['flip.img'], d['flip.boxes'] = img, b
+    for direction in ('horizontal', 'vertical'):
+        for normalized in (True, False):
+            for seed in (0, 1, 2, 3):
+                bb = b.copy() if normalized else b * np.array([14, 10, 14, 10], np.float32)
+                lab = {'img': img.copy(), 'instances': Instances(bb.copy(), bbox_format='xywh', normalized=normalized)}
+                random.seed(seed)
+                out = RandomFlip(p=0.5, direction=direction)(lab)
+                p = f'flip.{direction}.{int(normalized)}.{seed}.'
+                d[p + 'img'], d[p + 'boxes'] = out['img'], out['instances'].bboxes.copy()
+
+    # --- RandomLoadText ---------------------------------------------------------------------------------------
+    names10 = ['pedestrian', 'people', 'bicycle', 'car', 'van', 'truck', 'tricycle', 'awning-tricycle', 'bus', 'motor']
+    names_syn = ['person/human/pedestrian', 'car/automobile', 'bus', 'bike/bicycle/cycle', 'dog', 'cat/kitten']
+    cfgs = [('visdrone', names10, dict(max_samples=10, padding=True), [3, 3, 0, 9, 4, 3]),
+            ('visdrone_one', names10, dict(max_samples=10, padding=True), [5]),
+            ('visdrone_none', names10, dict(max_samples=10, padding=True), []),
+            ('syn_budget', names_syn, dict(max_samples=4, neg_samples=(1, 3), padding=True), [1, 4, 4]),
+            ('syn_nopad', names_syn, dict(max_samples=80, neg_samples=(0, 2), padding=False), [0, 5, 2, 2]),
+            ('syn_fmt', names_syn, dict(max_samples=3, neg_samples=(80, 80), padding=True, prompt_format='a photo of {}', padding_value='-'), [3])]
+    d['text.cases'] = np.array([c[0] for c in cfgs])
+    for name, names, kw, cl in cfgs:
+        for seed in (0, 1, 2):
+            cls = np.array(cl, np.float32).reshape(-1, 1)
+            bx = g.uniform(0.1, 0.9, (len(cl), 4)).astype(np.float32)
+            lab = {'texts': [v.split('/') for v in names], 'cls': cls.copy(), 'instances': Instances(bx.copy(), bbox_format='xywh', normalized=True)}
+            random.seed(seed)
+            out = RandomLoadText(**kw)(lab)
+            p = f'text.{name}.{seed}.'
+            d[p + 'in.cls'], d[p + 'in.boxes'] = cls, bx
+            d[p + 'out.cls'] = np.asarray(out['cls']).reshape(-1).astype(np.int64)
+            d[p + 'out.boxes'], d[p + 'out.texts'] = out['instances'].bboxes.copy(), np.array(out['texts'])
+            d[p + 'next_draw'] = np.array(random.random())
+    d['text.names10'], d['text.names_syn'] = np.array(names10), np.array(names_syn)
+
+    # --- Mosaic (numpy only) and MixUp ------------------------------------------------------------------------
+    s = 16
+
+    class FakeSet:
+        def __init__(self):
+            self.buffer = list(range(5))
+            self.imgs = [g.integers(0, 255, (s, s, 3), dtype=np.uint8) for _ in range(5)]
+            self.boxes = [np.concatenate([g.uniform(0.1, 0.9, (k + 1, 2)), g.uniform(0.05, 0.5, (k + 1, 2))], 1).astype(np.float32) for k in range(5)]
+            self.cls = [g.integers(0, 10, (k + 1, 1)).astype(np.float32) for k in range(5)]
+
+        def __len__(self):
+            return 5
+
+        def get_image_and_label(self, i):
+            return {'im_file': f'{i}.jpg', 'ori_shape': (s, s), 'resized_shape': (s, s), 'img': self.imgs[i].copy(), 'cls': self.cls[i].copy(),
+                    'instances': Instances(self.boxes[i].copy(), bbox_format='xywh', normalized=True)}
+    fs = FakeSet()
+    for k in range(5):
+        d[f'mosaic.src{k}.img'], d[f'mosaic.src{k}.boxes'], d[f'mosaic.src{k}.cls'] = fs.imgs[k], fs.boxes[k], fs.cls[k]
+    for seed in (0, 1, 2, 3):
+        random.seed(seed)
+        out = Mosaic(fs, imgsz=s, p=1.0, n=4)(fs.get_image_and_label(seed))
+        p = f'mosaic.{seed}.'
+        d[p + 'img'], d[p + 'boxes'], d[p + 'cls'] = out['img'], out['instances'].bboxes.copy(), out['cls'].copy()
+        d[p + 'border'] = np.array(out['mosaic_border'])
+    random.seed(4)
+    np.random.seed(4)
+    base = fs.get_image_and_label(0)
+    base['instances'].convert_bbox('xyxy')
+    out = MixUp(fs, pre_transform=None, p=1.0)(base)
+    d['mixup.img'], d['mixup.boxes'], d['mixup.cls'] = out['img'], out['instances'].bboxes.copy(), out['cls'].copy()
+
+    # --- Format + collate -------------------------------------------------------------------------------------
+    fmt = Format(bbox_format='xywh', normalize=True, return_mask=False, return_keypoint=False, batch_idx=True, mask_ratio=4, mask_overlap=True)
+    samples = []
+    for k, nb in enumerate((3, 0, 2)):
+        img = g.integers(0, 255, (8, 12, 3), dtype=np.uint8)
+        bx = (np.concatenate([g.uniform(1, 7, (nb, 2)), g.uniform(8, 11, (nb, 2))], 1)[:, [0, 1, 2, 3]]).astype(np.float32)
+        bx[:, 2:] = bx[:, :2] + 1 + bx[:, 2:] * 0.1
+        cls = np.arange(nb).reshape(-1, 1) if k != 2 else g.integers(0, 10, (nb, 1)).astype(np.float32)
+        lab = {'im_file': f'{k}.jpg', 'ori_shape': (20, 30), 'resized_shape': (8, 12), 'img': img.copy(), 'cls': cls,
+               'instances': Instances(bx.copy(), bbox_format='xyxy', normalized=False), 'texts': ['car', 'bus', '']}
+        d[f'format.{k}.in.img'], d[f'format.{k}.in.boxes'], d[f'format.{k}.in.cls'] = img, bx, np.asarray(cls)
+        out = fmt(lab)
+        # the reference holds BGR and flips the channel axis; the build holds RGB: store the RGB view of the same picture
+        d[f'format.{k}.out.img_bgr_flipped'] = out['img'].numpy()
+        d[f'format.{k}.out.cls'], d[f'format.{k}.out.bboxes'] = out['cls'].numpy(), out['bboxes'].numpy()
+        d[f'format.{k}.out.batch_idx'] = out['batch_idx'].numpy().copy()   # collate_fn adds the image index in place
+        samples.append(out)
+    bt = YOLODataset.collate_fn(samples)
+    d['collate.img'], d['collate.cls'], d['collate.bboxes'] = bt['img'].numpy(), bt['cls'].numpy(), bt['bboxes'].numpy()
+    d['collate.batch_idx'] = bt['batch_idx'].numpy()
+    d['collate.im_file'], d['collate.ori_shape'] = np.array(bt['im_file']), np.array(bt['ori_shape'])
+    save('data', d)
+
+
 def gen_e2e():
     for wseed in range(71, 91):
         if _gen_e2e(wseed):
@@ -602,6 +797,6 @@ def gen_e2e():
 if __name__ == '__main__':
     _import_reference()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['gate', 'msdeform', 'contrastive', 'decoder', 'cdn', 'loss', 'vss', 'head', 'e2e', 'metrics']
+    which = sys.argv[1:] or ['gate', 'msdeform', 'contrastive', 'decoder', 'cdn', 'loss', 'vss', 'head', 'e2e', 'metrics', 'data']
     for w in which:
         globals()['gen_' + w]()

@@ -556,3 +556,35 @@ def test_engine_train_and_validate_on_gpu(pkg):
     res = E.validate(model, [batch], imgsz=S, autocast_dtype=torch.bfloat16)
     assert res['seen'] == B and 0.0 <= res['mAP50'] <= 1.0 and 0.0 <= res['mAP50-95'] <= res['mAP50'] + 1e-9
     assert model.training
+
+
+def test_fit_from_image_files_on_gpu(pkg, tmp_path):
+    """Files -> decode -> stretch -> transforms -> prompts -> fit() on the real graph (small images): a training batch can hold
+    an image without boxes and int64 class ids, and the validation pass runs the EMA weights with the vocabulary set in advance."""
+    import numpy as np
+    from PIL import Image
+    import tamtr_amd.engine as E
+    from tamtr_amd import data as D
+    g = np.random.default_rng(0)
+    (tmp_path / 'images').mkdir(), (tmp_path / 'labels').mkdir()
+    names = ['pedestrian', 'people', 'bicycle', 'car', 'van', 'truck', 'tricycle', 'awning-tricycle', 'bus', 'motor']
+    for i in range(4):
+        Image.fromarray(g.integers(0, 255, (90, 120, 3), dtype=np.uint8)).save(tmp_path / 'images' / f'{i}.png')
+        rows = [f'{int(g.integers(0, 10))} {g.uniform(0.3, 0.7):.5f} {g.uniform(0.3, 0.7):.5f} {g.uniform(0.2, 0.4):.5f} {g.uniform(0.2, 0.4):.5f}'
+                for _ in range(0 if i == 1 else 3)]
+        (tmp_path / 'labels' / f'{i}.txt').write_text('\n'.join(rows))
+    S = 128
+    train = D.PromptDetDataset(str(tmp_path / 'images'), names, imgsz=S, augment=True, hyp={'scale': 0.2}, batch_size=2)
+    val = D.PromptDetDataset(str(tmp_path / 'images'), names, imgsz=S, augment=False)
+    tl, vl = D.build_dataloader(train, 2, workers=0, shuffle=False), D.build_dataloader(val, 2, workers=0, shuffle=False)
+    tf = D.TextFeatures.synthetic(names + [''], dim=512, seed=2)
+    torch.manual_seed(0)
+    model = pkg.model.RTDETRDetectionWorldModel(nc=10).cuda().train()
+    model.autocast_dtype = torch.bfloat16
+    model.set_text_features(tf.encode(names)[None])
+    hist = E.fit(model, tl, lambda b, training: D.preprocess_batch(b, tf if training else None, 'cuda'), epochs=1, val_loader=vl,
+                 warmup_iters=10, imgsz=S, save_dir=str(tmp_path / 'run'))
+    assert len(hist) == 1 and hist[0]['steps'] == 2 and all(np.isfinite(hist[0]['loss_items']))
+    assert hist[0]['seen'] == 4 and 0.0 <= hist[0]['mAP50'] <= 1.0
+    ck = torch.load(tmp_path / 'run' / 'last.pt')
+    assert ck['updates'] == 2 and all(torch.isfinite(v).all() for v in ck['ema'].values() if v.is_floating_point())

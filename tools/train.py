@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Train TAM-TR on a YOLO-format dataset (the reference's trainTAMTR.py flow on tam-tr_amd/engine.py + data.py).
+
+    python tools/train.py --data dataset.yaml --text-feats clip_vitb32.npz --epochs 300 --batch 6 --save-dir runs/train/TAMTR
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/train.py ...   # one rank per GPU
+
+dataset.yaml: `path`, `train`, `val` (image directories or list files) and `names` (index -> class name, `a/b` = synonyms), as
+dataset/visdrone.yaml in the reference.  --text-feats: .npz {texts [n], feats [n, 512]} or a torch-saved {text: vector} with one
+CLIP ViT-B/32 text embedding per prompt, every synonym and the padding prompt "" included (the text encoder itself is not part of
+this repo).  --synthetic N writes N random images + labels into a temporary directory instead, to exercise the loop end to end.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+import yaml
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+VISDRONE = ['pedestrian', 'people', 'bicycle', 'car', 'van', 'truck', 'tricycle', 'awning-tricycle', 'bus', 'motor']
+
+
+def synthetic_dataset(root, n, size=(540, 960), seed=0):
+    from PIL import Image
+    g = np.random.default_rng(seed)
+    os.makedirs(f'{root}/images'), os.makedirs(f'{root}/labels')
+    for i in range(n):
+        Image.fromarray(g.integers(0, 255, (*size, 3), dtype=np.uint8)).save(f'{root}/images/{i:05d}.jpg', quality=90)
+        with open(f'{root}/labels/{i:05d}.txt', 'w') as f:
+            for _ in range(int(g.integers(1, 9))):
+                f.write(f'{int(g.integers(0, 10))} {g.uniform(0.2, 0.8):.6f} {g.uniform(0.2, 0.8):.6f} {g.uniform(0.02, 0.22):.6f} {g.uniform(0.02, 0.22):.6f}\n')
+    return {'train': f'{root}/images', 'val': f'{root}/images', 'names': dict(enumerate(VISDRONE))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--data')
+    ap.add_argument('--text-feats')
+    ap.add_argument('--synthetic', type=int, default=0)
+    ap.add_argument('--epochs', type=int, default=300)
+    ap.add_argument('--batch', type=int, default=6, help='images per GPU')
+    ap.add_argument('--imgsz', type=int, default=640)
+    ap.add_argument('--workers', type=int, default=8)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--lr0', type=float, default=1e-4)
+    ap.add_argument('--close-mosaic', type=int, default=0)
+    ap.add_argument('--mosaic', type=float, default=0.0)
+    ap.add_argument('--max-steps', type=int)
+    ap.add_argument('--weights', help='state_dict checkpoint (last.pt / best.pt of an earlier run) to start from')
+    ap.add_argument('--save-dir', default='runs/train/TAMTR')
+    args = ap.parse_args()
+
+    import tamtr_amd  # noqa: F401  (raises if the HIP library is missing)
+    from tamtr_amd import data as D, dist as tdist, engine as E
+    from tamtr_amd.model import RTDETRDetectionWorldModel
+    rank, local, world = tdist.init_from_env()
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    tmp = None
+    if args.synthetic:
+        tmp = tempfile.TemporaryDirectory()
+        spec = synthetic_dataset(tmp.name, args.synthetic)
+    else:
+        with open(args.data) as f:
+            spec = yaml.safe_load(f)
+        root = spec.get('path', os.path.dirname(os.path.abspath(args.data)))
+        spec = {**spec, **{k: os.path.normpath(os.path.join(root, spec[k])) for k in ('train', 'val') if k in spec}}
+    names = spec['names'] if isinstance(spec['names'], dict) else dict(enumerate(spec['names']))
+    prompts = sorted({p for v in names.values() for p in v.split('/')} | {''})
+    tf = D.TextFeatures.load(args.text_feats) if args.text_feats else D.TextFeatures.synthetic(prompts, 512, seed=0)
+    if not args.text_feats and rank == 0:
+        print('no --text-feats: random prompt embeddings (loop exercise only)', file=sys.stderr)
+
+    train = D.PromptDetDataset(spec['train'], names, args.imgsz, augment=True, hyp={'mosaic': args.mosaic}, batch_size=args.batch)
+    tl = D.build_dataloader(train, args.batch, args.workers, shuffle=True, rank=rank if world > 1 else -1)
+    vl = None
+    if rank == 0 and 'val' in spec:
+        vl = D.build_dataloader(D.PromptDetDataset(spec['val'], names, args.imgsz, augment=False), args.batch * 2, args.workers, shuffle=False)
+
+    torch.manual_seed(0)
+    model = RTDETRDetectionWorldModel(nc=len(names)).to(dev).train()
+    if args.weights:
+        model.load_state_dict(torch.load(args.weights, map_location=dev)['model'])
+    model.autocast_dtype = torch.bfloat16 if args.dtype == 'bf16' else None
+    model.names = names
+    model.set_text_features(tf.encode([v.split('/')[0] for v in names.values()])[None].to(dev))     # validation vocabulary
+    reducer = tdist.GradReducer(model.named_parameters(), skip=lambda n: '.attn.' in n) if world > 1 else None
+
+    def prepare(batch, training):
+        return D.preprocess_batch(batch, tf if training else None, dev)
+
+    def log(rec):
+        print(json.dumps({k: (round(v, 5) if isinstance(v, float) else v) for k, v in rec.items()}), flush=True)
+    E.fit(model, tl, prepare, args.epochs, val_loader=vl, lr0=args.lr0, close_mosaic=args.close_mosaic, imgsz=args.imgsz, reducer=reducer,
+          rank=rank, world=world, save_dir=args.save_dir if rank == 0 else None, max_steps=args.max_steps, log=log)
+    if tmp is not None:
+        tmp.cleanup()
+
+
+if __name__ == '__main__':
+    main()
