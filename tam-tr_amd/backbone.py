@@ -16,8 +16,22 @@ def batchnorm(c):
     return nn.BatchNorm2d(c, eps=BN_EPS, momentum=BN_MOMENTUM)
 
 
+def fold_bn(conv, bn):
+    """conv followed by BatchNorm with frozen statistics == one biased conv (ultralytics/utils/torch_utils.py:159-180).
+    Returned frozen (requires_grad False), as the reference's fused evaluation graph holds it."""
+    fused = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, conv.dilation, conv.groups,
+                      bias=True).requires_grad_(False).to(conv.weight.device)
+    with torch.no_grad():
+        scale = bn.weight.div(torch.sqrt(bn.eps + bn.running_var))
+        fused.weight.copy_((scale[:, None] * conv.weight.reshape(conv.out_channels, -1)).view(fused.weight.shape))
+        b = torch.zeros(conv.out_channels, device=conv.weight.device) if conv.bias is None else conv.bias
+        fused.bias.copy_(scale * b + (bn.bias - bn.weight.mul(bn.running_mean).div(torch.sqrt(bn.running_var + bn.eps))))
+    return fused
+
+
 class Conv(nn.Module):
-    """conv (no bias, 'same' padding) -> BatchNorm -> SiLU | identity.  Args as the reference: (c1, c2, k, s, p, g, d, act)."""
+    """conv (no bias, 'same' padding) -> BatchNorm -> SiLU | identity.  Args as the reference: (c1, c2, k, s, p, g, d, act).
+    After fuse() the BatchNorm is folded into the conv (evaluation graph, nn/tasks.py:121-152)."""
 
     def __init__(self, c1, c2, k=1, s=1, p=None, g=1, d=1, act=True):
         super().__init__()
@@ -27,8 +41,15 @@ class Conv(nn.Module):
         self.bn = batchnorm(c2)
         self.act = nn.SiLU() if act is True else act if isinstance(act, nn.Module) else nn.Identity()
 
+    def fuse(self):
+        if 'bn' in self._modules:
+            self.conv = fold_bn(self.conv, self.bn)
+            del self.bn
+
     def forward(self, x):
         y = self.conv(x)
+        if 'bn' not in self._modules:
+            return self.act(y)
         if y.is_cuda and self.bn.training and self.bn.affine and type(self.act) in (nn.SiLU, nn.Identity) \
                 and y.dtype in (torch.bfloat16, torch.float32):
             from . import ops
@@ -42,7 +63,8 @@ class Conv(nn.Module):
 
 
 class RepConvN(nn.Module):
-    """Training-time RepVGG pair: SiLU(3x3 conv+BN  +  1x1 conv+BN)."""
+    """Training-time RepVGG pair: SiLU(3x3 conv+BN  +  1x1 conv+BN); switch_to_deploy() merges the pair into one biased 3x3
+    conv for evaluation (ultralytics/nn/extra_modules/block.py:53-124)."""
 
     def __init__(self, c1, c2, k=3, s=1, p=1, g=1, d=1, act=True, bn=False, deploy=False):
         super().__init__()
@@ -52,7 +74,27 @@ class RepConvN(nn.Module):
         self.act = nn.SiLU() if act is True else act if isinstance(act, nn.Module) else nn.Identity()
 
     def forward(self, x):
+        if 'conv' in self._modules:
+            return self.act(self.conv(x))
         return self.act(self.conv1(x) + self.conv2(x))
+
+    @staticmethod
+    def _branch(branch):
+        bn = branch.bn
+        std = (bn.running_var + bn.eps).sqrt()
+        return branch.conv.weight * (bn.weight / std).reshape(-1, 1, 1, 1), bn.bias - bn.running_mean * bn.weight / std
+
+    def switch_to_deploy(self):
+        if 'conv' in self._modules:
+            return
+        with torch.no_grad():
+            (k3, b3), (k1, b1) = self._branch(self.conv1), self._branch(self.conv2)
+            c = self.conv1.conv
+            self.conv = nn.Conv2d(c.in_channels, c.out_channels, c.kernel_size, c.stride, c.padding, c.dilation, c.groups,
+                                  bias=True).requires_grad_(False).to(c.weight.device)
+            self.conv.weight.copy_(k3 + F.pad(k1, [1, 1, 1, 1]))
+            self.conv.bias.copy_(b3 + b1)
+        del self.conv1, self.conv2
 
 
 class RepNBottleneck(nn.Module):

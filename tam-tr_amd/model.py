@@ -126,6 +126,25 @@ class RTDETRDetectionWorldModel(nn.Module):
         self.txt_feats = txt_feats.reshape(-1, txt_feats.shape[-2], txt_feats.shape[-1])
         self.model[-1].nc = self.txt_feats.shape[1]
 
+    def fuse(self, verbose=False):
+        """Evaluation graph (nn/tasks.py:121-152, what valTAMTR.py / AutoBackend(fuse=True) run): every RepConvN collapses to one
+        3x3 conv, every Conv's BatchNorm folds into its conv (the gates' proj_conv included); the head's input_proj
+        (Sequential(Conv2d, BatchNorm2d), not a Conv) stays as it is.  Weights are frozen; not for training."""
+        from .backbone import Conv, RepConvN
+        if not self.is_fused():
+            for m in list(self.modules()):
+                if isinstance(m, RepConvN):
+                    m.switch_to_deploy()
+            for m in list(self.modules()):
+                if isinstance(m, Conv):
+                    m.fuse()
+                if hasattr(m, '_tamtr_conv_names'):
+                    del m._tamtr_conv_names
+        return self
+
+    def is_fused(self, thresh=10):
+        return sum(isinstance(v, nn.BatchNorm2d) for v in self.modules()) < thresh
+
     def predict(self, x, profile=False, visualize=False, batch=None, augment=False, txt_feats=None):
         txt = (self.txt_feats if txt_feats is None else txt_feats).to(device=x.device, dtype=torch.float32)
         if len(txt) != len(x):

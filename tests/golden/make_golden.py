@@ -787,6 +787,62 @@ def gen_data():
     save('data', d)
 
 
+def gen_fuse():
+    """The evaluation graph after fuse() (nn/tasks.py:121-152; SURVEY 8g "Fused eval graph"): fuse_conv_and_bn
+    (utils/torch_utils.py:159-180), RepConvN.switch_to_deploy (extra_modules/block.py:53-124), and the full model's fused
+    state_dict keys + eval predictions on the e2e fixture's weights and inputs (VSSBlocks := identity as there)."""
+    from ultralytics.nn.extra_modules.block import RepConvN
+    from ultralytics.nn.tasks import RTDETRDetectionWorldModel, yaml_model_load
+    from ultralytics.utils.torch_utils import fuse_conv_and_bn
+    d = {}
+    for name, (c1, c2, k, s_, g_, bias) in {'plain': (6, 8, 3, 1, 1, False), 'biased_grouped': (8, 12, 1, 2, 4, True)}.items():
+        torch.manual_seed(len(name))
+        conv = nn.Conv2d(c1, c2, k, s_, k // 2, groups=g_, bias=bias)
+        bn = nn.BatchNorm2d(c2, eps=1e-3, momentum=0.03)
+        with torch.no_grad():
+            bn.weight.copy_(urnd((c2,), 3, 0.5, 1.5)), bn.bias.copy_(rnd((c2,), 4, 0.3))
+            bn.running_mean.copy_(rnd((c2,), 5, 0.5)), bn.running_var.copy_(urnd((c2,), 6, 0.2, 2.0))
+        f = fuse_conv_and_bn(conv, bn)
+        p = f'conv.{name}.'
+        d[p + 'cfg'] = np.array([c1, c2, k, s_, g_, int(bias)])
+        d[p + 'w'], d[p + 'b'] = conv.weight.detach(), (conv.bias.detach() if bias else np.zeros(0, np.float32))
+        for kk in ('weight', 'bias', 'running_mean', 'running_var'):
+            d[p + 'bn.' + kk] = getattr(bn, kk).detach()
+        d[p + 'fused.w'], d[p + 'fused.b'] = f.weight.detach(), f.bias.detach()
+    rep = set_bn(RepConvN(6, 6, 3, 1))
+    d['rep.wsum'] = load_filled(rep, seed=41)
+    rep.eval()
+    x = rnd((2, 6, 9, 9), 7)
+    with torch.no_grad():
+        d['rep.x'], d['rep.y_before'] = x, rep(x)
+        rep.switch_to_deploy()
+        d['rep.w'], d['rep.b'], d['rep.y_after'] = rep.conv.weight.detach(), rep.conv.bias.detach(), rep(x)
+    d['rep.keys'] = np.array(sorted(rep.state_dict()))
+    # full model
+    e2e = np.load(os.path.join(HERE, 'e2e.npz'))
+    torch.manual_seed(0)
+    m = RTDETRDetectionWorldModel(yaml_model_load(REF + '/ultralytics/cfg/models/TAMTR/TAMTR.yaml'), nc=10, verbose=False)
+    m.nc = 10
+    m.model[-1].VSSBlocks = nn.ModuleList([nn.Identity() for _ in range(3)])
+    wsum = load_filled(m, seed=int(e2e['wseed']))
+    assert abs(float(wsum) - float(e2e['wsum'])) < 1e-6 * abs(float(e2e['wsum']))
+    m.eval()
+    S = int(e2e['S'])
+    img, txt = urnd((2, 3, S, S), 1), torch.from_numpy(e2e['txt'])
+    with torch.no_grad():
+        y0, _ = m.predict(img, txt_feats=txt)
+        m.fuse(verbose=False)
+        y1, _ = m.predict(img, txt_feats=txt)
+    d['model.keys'] = np.array(sorted(m.state_dict()))
+    d['model.n_bn'] = np.array(sum(isinstance(v, nn.BatchNorm2d) for v in m.modules()))
+    d['model.y_eval'], d['model.y_eval_fused'] = y0, y1     # (fresh running statistics: e2e.npz's y_eval follows two training forwards)
+    d['model.wseed'], d['model.S'], d['model.txt'] = e2e['wseed'], e2e['S'], e2e['txt']
+    d['model.max_shift'] = np.array(float((y1 - y0).abs().max()))
+    pack(d, 'model.w0', summarize(m.model[0].conv.weight))
+    d['model.b0'] = m.model[0].conv.bias.detach()
+    save('fuse', d)
+
+
 def gen_e2e():
     for wseed in range(71, 91):
         if _gen_e2e(wseed):
@@ -797,6 +853,6 @@ def gen_e2e():
 if __name__ == '__main__':
     _import_reference()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['gate', 'msdeform', 'contrastive', 'decoder', 'cdn', 'loss', 'vss', 'head', 'e2e', 'metrics', 'data']
+    which = sys.argv[1:] or ['gate', 'msdeform', 'contrastive', 'decoder', 'cdn', 'loss', 'vss', 'head', 'e2e', 'metrics', 'data', 'fuse']
     for w in which:
         globals()['gen_' + w]()

@@ -588,3 +588,28 @@ def test_fit_from_image_files_on_gpu(pkg, tmp_path):
     assert hist[0]['seen'] == 4 and 0.0 <= hist[0]['mAP50'] <= 1.0
     ck = torch.load(tmp_path / 'run' / 'last.pt')
     assert ck['updates'] == 2 and all(torch.isfinite(v).all() for v in ck['ema'].values() if v.is_floating_point())
+
+
+def test_fused_eval_graph_vs_reference_fixture(pkg, golden):
+    """SURVEY 8g "Fused eval graph": eval predictions before and after fuse() against the reference's own (un)fused model on
+    the same weights (VSS := identity in the test, as in the generator); fusing moves the output by rounding only."""
+    fx = golden('fuse')
+    model = pkg.model.RTDETRDetectionWorldModel(nc=10)
+    model.model[-1].VSSBlocks = nn.ModuleList([nn.Identity() for _ in range(3)])
+    model.load_state_dict(fill_state(model.state_dict(), int(fx['model.wseed'])))
+    model.cuda().eval()
+    S = int(fx['model.S'])
+    img, txt = dev(urnd((2, 3, S, S), 1)), dev(T(fx['model.txt']))
+    with torch.no_grad():
+        y0, _ = model(img, txt_feats=txt)
+        model.fuse()
+        y1, _ = model(img, txt_feats=txt)
+    assert model.is_fused() and y0.shape == tuple(fx['model.y_eval'].shape)
+    for b in range(2):
+        assert_rows_match(y0[b], fx['model.y_eval'][b], 2e-3, f'unfused eval image {b}')
+        assert_rows_match(y1[b], fx['model.y_eval_fused'][b], 2e-3, f'fused eval image {b}')
+        assert_rows_match(y1[b], y0[b], 1e-4, f'fused vs unfused image {b}')
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):   # the bf16 evaluation path runs the folded convs too
+        model.autocast_dtype = torch.bfloat16
+        yb, _ = model(img, txt_feats=txt)
+    assert torch.isfinite(yb).all()

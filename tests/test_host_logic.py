@@ -6,9 +6,9 @@ import pytest
 import torch
 import torch.nn as nn
 
-from conftest import T, assert_close
+from conftest import T, assert_close, check_summary
 from oracle import specs
-from weights import checksum, fill_state
+from weights import checksum, fill_state, rnd
 
 
 def _keys(m):
@@ -134,3 +134,55 @@ def test_modules_refuse_cpu_forward():
         m(torch.zeros(1, 32, 4, 4), torch.zeros(1, 3, 512))
     with pytest.raises(TamtrHipError):
         M.ContrastiveHeadMLP()(torch.zeros(1, 2, 64), torch.zeros(1, 3, 64))
+
+
+def test_fused_eval_graph_matches_reference(golden):
+    """fuse() (SURVEY 8g "Fused eval graph"): BatchNorm folding and the RepConvN merge against the reference's own functions, and
+    the fused model's state_dict keys / first layer against the reference's fused model (weights only: runs on CPU)."""
+    import tamtr_amd.backbone as B
+    import tamtr_amd.model as MD
+    fx = golden('fuse')
+    for name in ('plain', 'biased_grouped'):
+        p = f'conv.{name}.'
+        c1, c2, k, s, g, bias = fx[p + 'cfg'].tolist()
+        conv = nn.Conv2d(c1, c2, k, s, k // 2, groups=g, bias=bool(bias))
+        bn = B.batchnorm(c2)
+        with torch.no_grad():
+            conv.weight.copy_(T(fx[p + 'w']))
+            if bias:
+                conv.bias.copy_(T(fx[p + 'b']))
+            for kk in ('weight', 'bias', 'running_mean', 'running_var'):
+                getattr(bn, kk).copy_(T(fx[p + 'bn.' + kk]))
+        f = B.fold_bn(conv, bn)
+        assert_close(f.weight, fx[p + 'fused.w'], 1e-6, 1e-7, name + ' weight')
+        assert_close(f.bias, fx[p + 'fused.b'], 1e-6, 1e-7, name + ' bias')
+        assert not f.weight.requires_grad and f.stride == conv.stride and f.groups == conv.groups
+        x = rnd((2, c1, 7, 7), 9)
+        with torch.no_grad():
+            assert_close(f(x), bn.eval()(conv(x)), 1e-5, 1e-6, name + ' output')
+    rep = B.RepConvN(6, 6, 3, 1)
+    st = fill_state(rep.state_dict(), 41)
+    assert abs(checksum(st) - float(fx['rep.wsum'])) < 1e-6 * abs(float(fx['rep.wsum']))
+    rep.load_state_dict(st)
+    rep.eval()
+    x = T(fx['rep.x'])
+    with torch.no_grad():
+        assert_close(rep(x), fx['rep.y_before'], 1e-5, 1e-6, 'rep before')
+        rep.switch_to_deploy()
+        rep.switch_to_deploy()       # idempotent
+        assert_close(rep.conv.weight, fx['rep.w'], 1e-6, 1e-7, 'rep kernel')
+        assert_close(rep.conv.bias, fx['rep.b'], 1e-6, 1e-7, 'rep bias')
+        assert_close(rep(x), fx['rep.y_after'], 1e-5, 1e-6, 'rep after')
+    assert sorted(rep.state_dict()) == fx['rep.keys'].tolist()
+    # whole model: keys and the stem
+    model = MD.RTDETRDetectionWorldModel(nc=10)
+    model.load_state_dict(fill_state(model.state_dict(), int(fx['model.wseed'])))
+    assert not model.is_fused()
+    model.eval().fuse()
+    assert model.is_fused() and model.fuse() is model
+    keys = sorted(k for k in model.state_dict() if '.VSSBlocks.' not in k)
+    assert keys == fx['model.keys'].tolist()
+    assert sum(isinstance(v, nn.BatchNorm2d) for v in model.modules()) == int(fx['model.n_bn'])
+    check_summary(fx, 'model.w0', model.model[0].conv.weight, 1e-6, 1e-7)
+    assert_close(model.model[0].conv.bias, fx['model.b0'], 1e-6, 1e-7, 'stem bias')
+    assert not any(p.requires_grad for n, p in model.named_parameters() if n.endswith('.conv.bias') and not n.startswith('model.41.'))

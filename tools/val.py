@@ -27,6 +27,7 @@ def main():
     ap.add_argument('--conf', type=float, default=0.001)
     ap.add_argument('--iou', type=float, default=0.7)
     ap.add_argument('--raw', action='store_true', help='use the raw weights instead of the EMA copy')
+    ap.add_argument('--no-fuse', action='store_true', help='keep BatchNorm layers separate (valTAMTR.py fuses, nn/autobackend.py:115)')
     args = ap.parse_args()
 
     import tamtr_amd  # noqa: F401
@@ -44,6 +45,9 @@ def main():
     ck = torch.load(args.weights, map_location=dev)
     model.load_state_dict(ck['model' if args.raw else 'ema'])
     model.set_text_features(tf.encode([v.split('/')[0] for v in names.values()])[None].to(dev))
+    model.eval()
+    if not args.no_fuse:
+        model.fuse()
     res = E.validate(model, (D.preprocess_batch(b, None, dev) for b in loader), imgsz=args.imgsz, conf=args.conf, iou=args.iou,
                      autocast_dtype=torch.bfloat16 if args.dtype == 'bf16' else None)
     print(json.dumps(res))
