@@ -608,7 +608,7 @@ def test_fused_eval_graph_vs_reference_fixture(pkg, golden):
     for b in range(2):
         assert_rows_match(y0[b], fx['model.y_eval'][b], 2e-3, f'unfused eval image {b}')
         assert_rows_match(y1[b], fx['model.y_eval_fused'][b], 2e-3, f'fused eval image {b}')
-        assert_rows_match(y1[b], y0[b], 1e-4, f'fused vs unfused image {b}')
+        assert_rows_match(y1[b], y0[b].cpu(), 1e-4, f'fused vs unfused image {b}')
     with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):   # the bf16 evaluation path runs the folded convs too
         model.autocast_dtype = torch.bfloat16
         yb, _ = model(img, txt_feats=txt)
