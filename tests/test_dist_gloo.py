@@ -75,3 +75,58 @@ def test_shard_batch():
     assert [shard_batch(128, r, 8) for r in (0, 7)] == [(0, 16), (112, 128)]
     with pytest.raises(ValueError):
         shard_batch(10, 0, 4)
+
+
+def _fit_worker(rank, world, port, img_dir, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from test_engine import _ToyDetector
+    from tamtr_amd import data as D
+    from tamtr_amd.dist import GradReducer, init_from_env
+    from tamtr_amd.engine import fit
+    init_from_env('gloo')
+    names = ['a', 'b', 'c', 'd', 'e']
+    ds = D.PromptDetDataset(img_dir, names, imgsz=32, augment=True, batch_size=2)
+    loader = D.build_dataloader(ds, 2, workers=0, shuffle=True, rank=rank)
+    val = D.build_dataloader(D.PromptDetDataset(img_dir, names, imgsz=32, augment=False), 4, workers=0, shuffle=False) if rank == 0 else None
+    tf = D.TextFeatures.synthetic(names + [''], dim=8)
+    torch.manual_seed(0)
+    model = _ToyDetector()
+    start = {k: v.clone() for k, v in model.state_dict().items()}
+    seen = []
+
+    def prepare(batch, training):
+        if training:
+            seen.extend(batch['im_file'])
+        return D.preprocess_batch(batch, tf if training else None, 'cpu')
+    red = GradReducer(model.named_parameters(), bucket_bytes=1 << 10)
+    hist = fit(model, loader, prepare, epochs=2, val_loader=val, lr0=1e-2, warmup_iters=0, imgsz=32, reducer=red, rank=rank, world=world,
+               save_dir=os.path.join(out, 'run') if rank == 0 else None)
+    torch.save({'state': model.state_dict(), 'start': start, 'seen': seen, 'hist': hist}, os.path.join(out, f'rank{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_fit_shards_images_and_keeps_ranks_in_step(tmp_path):
+    """engine.fit over data.build_dataloader(rank=...) with the gradient reducer: every epoch each rank trains on its own half of
+    the images, the weights stay identical across ranks, only rank 0 validates and writes checkpoints."""
+    import numpy as np
+    from PIL import Image
+    g = np.random.default_rng(3)
+    (tmp_path / 'images').mkdir(), (tmp_path / 'labels').mkdir()
+    for i in range(8):
+        Image.fromarray(g.integers(0, 255, (40, 48, 3), dtype=np.uint8)).save(tmp_path / 'images' / f'{i}.png')
+        (tmp_path / 'labels' / f'{i}.txt').write_text(f'{i % 5} 0.5 0.5 0.3 0.3\n')
+    mp.spawn(_fit_worker, args=(2, _free_port(), str(tmp_path / 'images'), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'rank0.pt'), torch.load(tmp_path / 'rank1.pt')
+    for k, v in r0['state'].items():
+        if 'running_' in k or 'num_batches' in k:
+            continue                                    # BatchNorm statistics are per rank (no SyncBN), as in the reference
+        assert torch.equal(v, r1['state'][k]), k
+    assert any(not torch.equal(r0['state'][k], r0['start'][k]) for k in ('head.weight', 'conv.weight'))
+    for e in range(2):                                  # 8 images, 2 ranks, batch 2 -> 2 steps per rank and epoch
+        a, b = set(r0['seen'][4 * e:4 * e + 4]), set(r1['seen'][4 * e:4 * e + 4])
+        assert len(a) == 4 and len(b) == 4 and not (a & b)
+    assert r0['hist'][-1]['steps'] == 4 and 'mAP50' in r0['hist'][-1] and 'mAP50' not in r1['hist'][-1]
+    assert (tmp_path / 'run' / 'last.pt').exists()
