@@ -333,7 +333,8 @@ def fit(model, train_loader, prepare, epochs, val_loader=None, lr0=1e-4, lrf=1.0
                 reducer.finish()
             torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], max_norm=0.1)
             opt.step()
-            opt.zero_grad(set_to_none=True)
+            if reducer is None:      # (the reducer's gradients are views of its flat buckets, zeroed by prepare())
+                opt.zero_grad(set_to_none=True)
             if ema is not None:
                 ema.update(model)
             mean_items = items.detach() if mean_items is None else (mean_items * i + items.detach()) / (i + 1)   # no host sync
