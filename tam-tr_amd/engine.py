@@ -84,6 +84,20 @@ class ModelEMA:
         for p in self.ema.parameters():
             p.requires_grad_(False)
         self.enabled = True
+        self._pairs = None      # (key, ema tensors, model tensors): walking two 1 200-entry state_dicts costs ~10 ms of host time per step
+
+    def _tensors(self, model):
+        first = next(model.parameters())
+        key = (id(model), first.data_ptr(), len(model._modules))
+        if self._pairs is None or self._pairs[0] != key:
+            msd = model.state_dict()
+            dst, src = [], []
+            for k, v in self.ema.state_dict().items():
+                if v.dtype.is_floating_point:
+                    dst.append(v)
+                    src.append(msd[k].detach())
+            self._pairs = (key, dst, src)
+        return self._pairs[1], self._pairs[2]
 
     @torch.no_grad()
     def update(self, model):
@@ -91,12 +105,7 @@ class ModelEMA:
             return
         self.updates += 1
         d = self.decay(self.updates)
-        msd = model.state_dict()
-        dst, src = [], []
-        for k, v in self.ema.state_dict().items():
-            if v.dtype.is_floating_point:
-                dst.append(v)
-                src.append(msd[k].detach())
+        dst, src = self._tensors(model)        # (parameters and buffers are updated in place, so the aliases stay valid)
         torch._foreach_mul_(dst, d)            # v = d * v + (1 - d) * m, a few multi-tensor kernels instead of 2 per tensor
         torch._foreach_add_(dst, src, alpha=1 - d)
 
@@ -320,9 +329,16 @@ def fit(model, train_loader, prepare, epochs, val_loader=None, lr0=1e-4, lrf=1.0
             train_loader.sampler.set_epoch(epoch)
         if close_mosaic and epoch == epochs - close_mosaic and hasattr(train_loader.dataset, 'close_mosaic'):
             train_loader.dataset.close_mosaic()
-        t0, mean_items = time.time(), None
+        t0, mean_items, waited, i = time.time(), None, 0.0, -1
         opt.zero_grad(set_to_none=True)
-        for i, batch in enumerate(train_loader):
+        batches = iter(train_loader)
+        while True:
+            t1 = time.perf_counter()
+            batch = next(batches, None)
+            waited += time.perf_counter() - t1        # host time blocked on the loader (0 when the workers keep ahead)
+            if batch is None:
+                break
+            i += 1
             warmup(opt, i + nb * epoch, warmup_iters, lf(epoch), warmup_bias_lr, warmup_momentum, momentum)
             batch = prepare(batch, True)
             if reducer is not None:
@@ -341,7 +357,7 @@ def fit(model, train_loader, prepare, epochs, val_loader=None, lr0=1e-4, lrf=1.0
             steps += 1
             if max_steps is not None and steps >= max_steps:
                 break
-        rec = {'epoch': epoch, 'steps': steps, 'seconds': time.time() - t0, 'lr': [g['lr'] for g in opt.param_groups],
+        rec = {'epoch': epoch, 'steps': steps, 'seconds': time.time() - t0, 'loader_wait': waited, 'lr': [g['lr'] for g in opt.param_groups],
                'loss_items': mean_items.float().cpu().tolist() if mean_items is not None else []}
         sched.step()
         if rank == 0:

@@ -57,6 +57,10 @@ def main():
     from tamtr_amd import data as D, dist as tdist, engine as E
     from tamtr_amd.model import RTDETRDetectionWorldModel
     rank, local, world = tdist.init_from_env()
+    try:       # host side = kernel launches + a few tiny CPU ops: a thread pool sized for the whole host only adds wake-up latency
+        torch.set_num_threads(min(8, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        torch.set_num_threads(8)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     tmp = None
