@@ -18,7 +18,7 @@ candidate filter, flips, RandomLoadText's draw sequence, Format, collate.  NOT p
 cv2 is absent from the image: `resize_linear_u8`, `warp_affine_u8`, `hsv_jitter_u8` run in libtamtr_host.so (C, include/tamtr_host.h;
 per-image cost is what bounds the loader) and restate OpenCV's published 8-bit algorithms (fixed-point bilinear
 resize, 1/32-pixel affine remap, integer RGB->HSV / float HSV->RGB); tests hold them bit-exact to a numpy twin
-(oracle/imgproc_np.py) and to closed forms.  The CLIP text encoder is out of scope: prompts are looked up in a table of precomputed embeddings.
+(oracle/imgproc_np.py), to closed forms, and within rounding of torch's float sampling and colorsys.  The CLIP text encoder is out of scope: prompts are looked up in a table of precomputed embeddings.
 Albumentations (absent from the reference's requirements -> a no-op there) and CopyPaste (needs segments) are not built.
 """
 import glob
