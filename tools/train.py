@@ -61,6 +61,7 @@ def main():
         torch.set_num_threads(min(8, len(os.sched_getaffinity(0))))
     except AttributeError:
         torch.set_num_threads(8)
+    local = local % max(torch.cuda.device_count(), 1)      # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     tmp = None
