@@ -277,6 +277,20 @@ int tamtr_bncl_act_fwd(const void* x, const float* gamma, const float* beta, flo
 int tamtr_bncl_act_bwd(const void* gy, const void* x, const float* gamma, const float* beta, const float* mean_rstd, void* gx,
                        float* ggamma, float* gbeta, float* partials, long long N, int C, int act, int dtype, void* stream);
 
+/* ---- data path: the pixel half of the training transforms on the device.
+ *      Replaces, for a whole batch and in this order: cv2.warpAffine(img, M[:2], dsize, borderValue=114) of RandomPerspective
+ *      (ultralytics/data/augment.py:415-420), the BGR2HSV -> LUT -> HSV2BGR chain of RandomHSV (:590-609), RandomFlip's
+ *      np.flipud / np.fliplr (:656-660), Format._format_img (:920-926) and preprocess_batch's img.float() / 255
+ *      (models/yolo/detect/train.py:56).  Same arithmetic as libtamtr_host.so (include/tamtr_host.h), bit for bit.
+ *      src        u8  [B, SH, SW, 3]  decoded + stretched RGB images (before any transform)
+ *      inv_affine f64 [B, 6]          destination -> source map  m0 m1 b1 / m3 m4 b2  (inverse of the transform's 2x3 matrix)
+ *      luts       u8  [B, 3, 256]     hue (< 180), saturation, value look-up tables of RandomHSV
+ *      flags      i32 [B]             bit 0: flipped up-down, bit 1: flipped left-right, bit 2: no HSV step (luts ignored)
+ *      out        f32 [B, 3, H, W]    pixel * float(1 / 255.0), which is how torch evaluates `img.float() / 255` on the device
+ */
+int tamtr_img_augment_u8(const uint8_t* src, const double* inv_affine, const uint8_t* luts, const int32_t* flags, float* out, int B,
+                         int SH, int SW, int H, int W, int border, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,9 @@ What the reference does on this path and where (all host-side numpy / PIL / torc
 
 Built MI355X-side as plain host code feeding the sync-free step: samples stay numpy until `Format`, the batch keeps its
 labels on the host (model.loss uploads them through the pinned ring) and only `img` / `txt_feats` go to the device.
+With `device_augment=True` the workers only decode, stretch and draw the random parameters; the pixel work of the affine warp,
+HSV jitter, flips and the uint8 -> float conversion runs on the GPU after the upload (tamtr_img_augment_u8, one kernel per batch,
+bit-identical to the host kernels), which halves the per-image host time.
 
 Pinned against the reference's own functions (tests/golden/data.npz): label parsing, box conversions, the affine box path and
 candidate filter, flips, RandomLoadText's draw sequence, Format, collate.  NOT pinned - the reference calls OpenCV for these and
@@ -152,10 +155,25 @@ def warp_affine_u8(src, M, dw, dh, border=114):
     return out
 
 
+def invert_affine(M):
+    """The six doubles both warps evaluate: destination -> source map (m0 m1 b1 / m3 m4 b2) of the 2x3 source -> destination M."""
+    M = np.asarray(M, np.float64)
+    det = M[0, 0] * M[1, 1] - M[0, 1] * M[1, 0]
+    det = 1.0 / det if det != 0 else 0.0
+    m0, m1, m3, m4 = M[1, 1] * det, -M[0, 1] * det, -M[1, 0] * det, M[0, 0] * det
+    return np.array([m0, m1, -m0 * M[0, 2] - m1 * M[1, 2], m3, m4, -m3 * M[0, 2] - m4 * M[1, 2]], np.float64)
+
+
+def hsv_luts(gains):
+    """[3, 256] uint8 hue / saturation / value tables of RandomHSV for one draw of gains."""
+    x = np.arange(0, 256, dtype=np.float64)
+    return np.stack([((x * gains[0]) % 180).astype(np.uint8), np.clip(x * gains[1], 0, 255).astype(np.uint8),
+                     np.clip(x * gains[2], 0, 255).astype(np.uint8)])
+
+
 def hsv_jitter_u8(img, gains):
     """Per-channel gain look-up tables on the HSV planes (hue wraps at 180, saturation / value clip at 255), RGB in, RGB out."""
-    x = np.arange(0, 256, dtype=np.float64)
-    luts = [np.ascontiguousarray(t.astype(np.uint8)) for t in ((x * gains[0]) % 180, np.clip(x * gains[1], 0, 255), np.clip(x * gains[2], 0, 255))]
+    luts = hsv_luts(gains)
     out = _u8_image(img).copy()
     if out.shape[2] != 3:
         raise TypeError('hsv_jitter_u8 needs 3 channels')
@@ -178,6 +196,7 @@ class Sample:
     resized_shape: tuple = (0, 0)
     ratio_pad: tuple = None
     mosaic_border: tuple = None
+    defer: dict = None        # device_augment: the pixel work recorded instead of done (inverse affine, HSV tables, flips, output size)
 
     def to_xyxy(self):
         if self.fmt == 'xywh':
@@ -282,7 +301,9 @@ class RandomAffine:
         smp.mosaic_border = None
         size = (w + border[1] * 2, h + border[0] * 2)
         M, s = self.matrix(w, h, size)
-        if border[0] != 0 or border[1] != 0 or (M != np.eye(3)).any():
+        if smp.defer is not None:
+            smp.defer.update(inv=invert_affine(M[:2]), size=(size[1], size[0]))
+        elif border[0] != 0 or border[1] != 0 or (M != np.eye(3)).any():
             smp.img = warp_affine_u8(smp.img, M[:2], size[0], size[1], 114)
         old = smp.boxes
         smp.boxes = affine_boxes(old, M)
@@ -290,7 +311,7 @@ class RandomAffine:
         for k in range(4):
             old[:, k] *= s
         smp.select(box_candidates(old.T, smp.boxes.T, area_thr=0.10))
-        smp.resized_shape = smp.img.shape[:2]
+        smp.resized_shape = (size[1], size[0]) if smp.defer is not None else smp.img.shape[:2]
         return smp
 
 
@@ -353,7 +374,12 @@ class RandomHSV:
 
     def __call__(self, smp):
         if any(self.gains):
-            smp.img = hsv_jitter_u8(smp.img, np.random.uniform(-1, 1, 3) * self.gains + 1)
+            gains = np.random.uniform(-1, 1, 3) * self.gains + 1
+            if smp.defer is not None:
+                smp.defer['luts'] = hsv_luts(gains)
+                smp.defer['flags'] &= ~4
+            else:
+                smp.img = hsv_jitter_u8(smp.img, gains)
         return smp
 
 
@@ -364,10 +390,13 @@ class RandomFlip:
 
     def __call__(self, smp):
         smp.to_xywh()
-        h, w = smp.img.shape[:2]
+        h, w = smp.defer['size'] if smp.defer is not None else smp.img.shape[:2]
         extent = 1 if smp.normalized else (w if self.axis else h)
         if random.random() < self.p:
-            smp.img = np.flip(smp.img, self.axis)
+            if smp.defer is not None:
+                smp.defer['flags'] ^= 2 if self.axis else 1
+            else:
+                smp.img = np.flip(smp.img, self.axis)
             k = 0 if self.axis else 1
             smp.boxes[:, k] = extent - smp.boxes[:, k]
         smp.img = np.ascontiguousarray(smp.img)
@@ -412,14 +441,20 @@ class Format:
     """Sample -> dict of tensors for `collate`: img uint8 [3, h, w] RGB, cls [n, 1], bboxes [n, 4] xywh normalised, batch_idx [n]."""
 
     def __call__(self, smp):
-        h, w = smp.img.shape[:2]
+        h, w = smp.defer['size'] if smp.defer is not None else smp.img.shape[:2]
         smp.to_xywh().denormalize(w, h).normalize(w, h)
         n = len(smp.boxes)
         out = {'im_file': smp.im_file, 'ori_shape': smp.ori_shape, 'resized_shape': smp.resized_shape}
         if smp.ratio_pad is not None:
             out['ratio_pad'] = smp.ratio_pad
         out['texts'] = smp.texts
-        out['img'] = torch.from_numpy(np.ascontiguousarray(smp.img.transpose(2, 0, 1)))
+        if smp.defer is not None:      # the untransformed picture travels; ops.img_augment finishes it on the device
+            d = smp.defer
+            out['src'] = torch.from_numpy(np.ascontiguousarray(smp.img))
+            out['aug_inv'], out['aug_luts'] = torch.from_numpy(d['inv']), torch.from_numpy(np.ascontiguousarray(d['luts']))
+            out['aug_flags'] = torch.tensor(d['flags'], dtype=torch.int32)
+        else:
+            out['img'] = torch.from_numpy(np.ascontiguousarray(smp.img.transpose(2, 0, 1)))
         out['cls'] = torch.from_numpy(smp.cls) if n else torch.zeros(n)
         out['bboxes'] = torch.from_numpy(smp.boxes) if n else torch.zeros((n, 4))
         out['batch_idx'] = torch.zeros(n)
@@ -429,7 +464,9 @@ class Format:
 def collate(samples):
     """Stack images, concatenate labels with the image index written into batch_idx, keep everything else as tuples."""
     batch = {k: [s[k] for s in samples] for k in samples[0]}
-    batch['img'] = torch.stack(batch['img'], 0)
+    for k in ('img', 'src', 'aug_inv', 'aug_luts', 'aug_flags'):
+        if k in batch:
+            batch[k] = torch.stack(batch[k], 0)
     batch['batch_idx'] = torch.cat([b + i for i, b in enumerate(batch['batch_idx'])], 0)
     for k in ('bboxes', 'cls'):
         batch[k] = torch.cat(batch[k], 0)
@@ -445,8 +482,9 @@ class PromptDetDataset(torch.utils.data.Dataset):
     """Images stretched to imgsz x imgsz with YOLO labels and the class-name prompts (`a/b` = synonyms).  augment=True runs the
     training transforms, otherwise the sample is only formatted (the reference's RTDETRDataset, models/rtdetrworld/val.py:15-58)."""
 
-    def __init__(self, img_path, names, imgsz=640, augment=False, hyp=None, batch_size=16, log=None):
+    def __init__(self, img_path, names, imgsz=640, augment=False, hyp=None, batch_size=16, log=None, device_augment=False):
         self.imgsz, self.augment = imgsz, augment
+        self.device_augment = bool(device_augment and augment)
         self.names = dict(enumerate(names)) if isinstance(names, (list, tuple)) else dict(names)
         self.prompts = [v.split('/') for _, v in self.names.items()]
         self.labels = scan_labels(list_images(img_path), len(self.names), log)
@@ -461,6 +499,8 @@ class PromptDetDataset(torch.utils.data.Dataset):
         if not self.augment:
             return [Format()]
         h = self.hyp
+        if self.device_augment and (h['mosaic'] or h['mixup']):
+            raise ValueError('device_augment needs one source image per sample: mosaic and mixup must be 0 (the reference\'s defaults)')
         pre = [Mosaic4(self, self.imgsz, h['mosaic']),
                RandomAffine(h['degrees'], h['translate'], h['scale'], h['shear'], h['perspective'])]
 
@@ -498,8 +538,11 @@ class PromptDetDataset(torch.utils.data.Dataset):
         lb = self.labels[i]
         im, hw0 = self.load_image(i)
         rs = im.shape[:2]
-        return Sample(im, lb['cls'].copy(), lb['bboxes'].copy(), 'xywh', True, [list(p) for p in self.prompts], lb['im_file'], hw0, rs,
-                      (rs[0] / hw0[0], rs[1] / hw0[1]))
+        smp = Sample(im, lb['cls'].copy(), lb['bboxes'].copy(), 'xywh', True, [list(p) for p in self.prompts], lb['im_file'], hw0, rs,
+                     (rs[0] / hw0[0], rs[1] / hw0[1]))
+        if self.device_augment:     # workers only decode, stretch and draw; tamtr_img_augment_u8 does the pixels after the upload
+            smp.defer = {'flags': 4, 'luts': np.zeros((3, 256), np.uint8), 'inv': invert_affine(np.eye(3)[:2]), 'size': rs}
+        return smp
 
     def __getitem__(self, i):
         smp = self.load_sample(i)
@@ -564,7 +607,12 @@ def preprocess_batch(batch, text_features, device):
     """img -> device float in [0, 1]; sampled prompts -> txt_feats [B, T, d] (training batches only: a validation batch carries the
     synonym lists and the model uses the features set in advance); labels stay on the host for the sync-free loss."""
     out = dict(batch)
-    out['img'] = batch['img'].to(device, non_blocking=True).float() / 255
+    if 'src' in batch:      # device_augment: finish the transforms' pixel work on the GPU (csrc/imgaug.hip)
+        from . import ops
+        a = [out.pop(k).to(device, non_blocking=True) for k in ('src', 'aug_inv', 'aug_luts', 'aug_flags')]
+        out['img'] = ops.img_augment(*a, out_hw=tuple(batch['resized_shape'][0]))
+    else:
+        out['img'] = batch['img'].to(device, non_blocking=True).float() / 255
     if text_features is None or not all(isinstance(t, str) for t in batch['texts'][0]):
         return out
     texts = list(chain(*batch['texts']))

@@ -654,6 +654,23 @@ def lsap_assign(cost, gt_groups):
     return out[0], out[1], out[2]
 
 
+def img_augment(src, inv_affine, luts, flags, out_hw, border=114):
+    """The pixel half of the training transforms for a whole batch (affine warp -> HSV look-up -> flips -> CHW float / 255;
+    ultralytics/data/augment.py:415-420,590-609,636-666,920-926).  src u8 [B, SH, SW, 3], inv_affine f64 [B, 6]
+    (destination -> source), luts u8 [B, 3, 256], flags i32 [B] (bit 0 up-down, bit 1 left-right) -> f32 [B, 3, H, W].
+    Bit-identical to the host kernels of libtamtr_host.so followed by `img.float() / 255` on the device."""
+    require_gpu(src, inv_affine, luts, flags)
+    B, SH, SW, ch = src.shape
+    H, W = out_hw
+    if (ch != 3 or src.dtype != torch.uint8 or inv_affine.dtype != torch.float64 or luts.dtype != torch.uint8 or flags.dtype != torch.int32
+            or tuple(inv_affine.shape) != (B, 6) or tuple(luts.shape) != (B, 3, 256) or tuple(flags.shape) != (B,)):
+        raise _lib.TamtrHipError('img_augment: expected src u8 [B,SH,SW,3], inv_affine f64 [B,6], luts u8 [B,3,256], flags i32 [B]')
+    src, inv_affine, luts, flags = _c(src), _c(inv_affine), _c(luts), _c(flags)
+    out = torch.empty(B, 3, H, W, device=src.device, dtype=torch.float32)
+    call('tamtr_img_augment_u8', ptr(src), ptr(inv_affine), ptr(luts), ptr(flags), ptr(out), B, SH, SW, H, W, int(border), stream_ptr())
+    return out
+
+
 class _CPAM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -445,3 +445,61 @@ def test_ln_gate_full_size_row_statistics(ops):
     xz[..., D:] = 20.0   # SiLU(20) = 20 (to 2e-9): the gate becomes a known constant
     out = ops.ln_gate(x, xz, torch.ones(D, device='cuda'), torch.zeros(D, device='cuda'), 1e-5).float() / 20.0
     assert float(out.mean(-1).abs().max()) < 2e-2 and float((out.var(-1, unbiased=False) - 1).abs().max()) < 3e-2
+
+
+def test_img_augment_matches_host_kernels_bit_for_bit(ops, tmp_path):
+    """tamtr_img_augment_u8 (affine warp -> HSV tables -> flips -> CHW float / 255 on the device) against the host kernels of
+    libtamtr_host.so / their numpy twin followed by torch's own `.float() / 255` on the device: identical bits, for crops,
+    zooms, rotations, every flip combination, the no-HSV flag, and through the dataset with device_augment on and off."""
+    import random
+    from PIL import Image
+    from oracle import imgproc_np as NP
+    from tamtr_amd import data as D
+    g = np.random.default_rng(12)
+    B, SH, SW, H, W = 8, 70, 90, 48, 64
+    src = g.integers(0, 256, (B, SH, SW, 3), dtype=np.uint8)
+    mats = [np.array([[1, 0, 0], [0, 1, 0]], np.float32), np.array([[1, 0, -13], [0, 1, -11]], np.float32),
+            np.array([[0.61, 0.07, 4.3], [-0.05, 0.66, 2.9]], np.float32), np.array([[1.9, 0, -50.2], [0, 1.9, -30.7]], np.float32),
+            np.array([[0.8, 0.6, 10], [-0.6, 0.8, 30]], np.float32), np.array([[0.11, 0, 20], [0, 0.11, 20]], np.float32),
+            np.array([[1, 0, 0.5], [0, 1, 0.25]], np.float32), np.array([[-1, 0, 63], [0, -1, 47]], np.float32)]
+    gains = [np.array([1 + 0.015 * g.uniform(-1, 1), 1 + 0.7 * g.uniform(-1, 1), 1 + 0.4 * g.uniform(-1, 1)]) for _ in range(B)]
+    luts = np.stack([D.hsv_luts(gn) for gn in gains])
+    flags = np.arange(B, dtype=np.int32)              # 0..7: all flip combinations, 4..7 with the HSV step off
+    inv = np.stack([D.invert_affine(m) for m in mats])
+    got = ops.img_augment(torch.from_numpy(src).cuda(), torch.from_numpy(inv).cuda(), torch.from_numpy(luts).cuda(),
+                          torch.from_numpy(flags).cuda(), (H, W))
+    want = []
+    for b in range(B):
+        pic = D.warp_affine_u8(src[b], mats[b], W, H, 114)
+        assert np.array_equal(pic, NP.warp_affine_u8(src[b], mats[b], W, H, 114))
+        if not flags[b] & 4:
+            pic = NP.hsv_lut_u8(pic, *luts[b])
+        if flags[b] & 1:
+            pic = pic[::-1]
+        if flags[b] & 2:
+            pic = pic[:, ::-1]
+        want.append(np.ascontiguousarray(pic.transpose(2, 0, 1)))
+    want = torch.from_numpy(np.stack(want)).cuda()
+    u8 = (got * 255).round().to(torch.uint8)
+    for b in range(B):
+        assert torch.equal(u8[b], want[b]), f'image {b}: {(u8[b] != want[b]).float().mean().item():.4f} of the pixels differ'
+    assert torch.equal(got, want.float() / 255)
+    # through the dataset: same seeds, pixel work on the host vs on the device
+    (tmp_path / 'images').mkdir(), (tmp_path / 'labels').mkdir()
+    for i in range(4):
+        Image.fromarray(g.integers(0, 255, (60 + 7 * i, 100 - 9 * i, 3), dtype=np.uint8)).save(tmp_path / 'images' / f'{i}.png')
+        (tmp_path / 'labels' / f'{i}.txt').write_text(f'{i} 0.5 0.5 0.4 0.4\n')
+    names = ['a', 'b', 'c', 'd']
+    tf = D.TextFeatures.synthetic(names + [''], dim=8)
+    batches = []
+    for dev_aug in (False, True):
+        ds = D.PromptDetDataset(str(tmp_path / 'images'), names, imgsz=64, augment=True, hyp={'degrees': 8.0, 'flipud': 0.5},
+                                batch_size=4, device_augment=dev_aug)
+        random.seed(3), np.random.seed(3)
+        batches.append(D.preprocess_batch(D.collate([ds[i] for i in range(4)]), tf, 'cuda'))
+    a, b = batches
+    assert b['img'].shape == (4, 3, 64, 64) and torch.equal(a['img'], b['img']) and 'src' not in b
+    assert torch.equal(a['bboxes'], b['bboxes']) and torch.equal(a['txt_feats'], b['txt_feats'])
+    with pytest.raises(Exception):
+        ops.img_augment(torch.zeros(1, 4, 4, 3), torch.zeros(1, 6, dtype=torch.float64), torch.zeros(1, 3, 256, dtype=torch.uint8),
+                        torch.zeros(1, dtype=torch.int32), (4, 4))

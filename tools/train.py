@@ -48,6 +48,7 @@ def main():
     ap.add_argument('--lr0', type=float, default=1e-4)
     ap.add_argument('--close-mosaic', type=int, default=0)
     ap.add_argument('--mosaic', type=float, default=0.0)
+    ap.add_argument('--device-augment', action='store_true', help='affine warp / HSV / flips / float conversion on the GPU (needs --mosaic 0)')
     ap.add_argument('--max-steps', type=int)
     ap.add_argument('--weights', help='state_dict checkpoint (last.pt / best.pt of an earlier run) to start from')
     ap.add_argument('--save-dir', default='runs/train/TAMTR')
@@ -79,7 +80,8 @@ def main():
     if not args.text_feats and rank == 0:
         print('no --text-feats: random prompt embeddings (loop exercise only)', file=sys.stderr)
 
-    train = D.PromptDetDataset(spec['train'], names, args.imgsz, augment=True, hyp={'mosaic': args.mosaic}, batch_size=args.batch)
+    train = D.PromptDetDataset(spec['train'], names, args.imgsz, augment=True, hyp={'mosaic': args.mosaic}, batch_size=args.batch,
+                               device_augment=args.device_augment)
     tl = D.build_dataloader(train, args.batch, args.workers, shuffle=True, rank=rank if world > 1 else -1)
     vl = None
     if rank == 0 and 'val' in spec:
