@@ -570,6 +570,17 @@ def build_dataloader(dataset, batch, workers=4, shuffle=True, rank=-1):
                                        generator=gen, persistent_workers=nw > 0)
 
 
+def reset_workers(loader):
+    """Make the loader's next epoch start from fresh worker processes (the reference's `train_loader.reset()`,
+    engine/trainer.py:319-321, data/build.py:44-50): persistent workers hold a pickled copy of the dataset, so a change made to
+    `loader.dataset` in the main process (close_mosaic) would otherwise never reach them."""
+    it = getattr(loader, '_iterator', None)
+    if it is not None:
+        if hasattr(it, '_shutdown_workers'):
+            it._shutdown_workers()
+        loader._iterator = None
+
+
 # ------------------------------------------------------------------------------------------------ prompts -> text features
 class TextFeatures:
     """Prompt -> embedding table standing in for the frozen CLIP ViT-B/32 text tower (computed offline; the encoder is out of

@@ -6,8 +6,11 @@ SUM over ranks of the per-rank gradients.  Here: an explicit bucketed gradient r
   * parameters that never receive a gradient (the 30 `model.{16,24,32,36,40}.attn.*` tensors) are excluded up
     front, which is what makes plain DDP fail on iteration 2 in the reference;
   * gradients live in a few large flat buckets (views), one all-reduce per bucket, launched from a post-accumulate hook
-    as soon as the bucket's last gradient of this backward pass is written, so the collectives overlap the rest of the
-    backward; xGMI is point-to-point (7 links per GPU), so few large buckets (default 32 MiB) beat many small ones;
+    once the bucket's last gradient of this backward pass is written AND every earlier bucket has been launched, so the
+    collectives overlap the rest of the backward and every rank issues them in the same (bucket index) order whatever
+    its data did - a rank whose batch has no GT boxes never produces a gradient for `denoising_class_embed`, and
+    collectives are matched by issue order; xGMI is point-to-point (7 links per GPU), so few large buckets (default
+    32 MiB) beat many small ones;
   * no collective anywhere on the data path of the forward (per-rank BatchNorm statistics, like the reference).
 """
 import os
@@ -43,13 +46,20 @@ def shard_batch(global_batch, rank, world):
 class GradReducer:
     """Bucketed, overlapped all-reduce (SUM or MEAN) of the gradients of `params` that are known to receive one."""
 
-    def __init__(self, named_params, bucket_bytes=32 << 20, op='sum', grad_dtype=None, skip=lambda name: False):
+    def __init__(self, named_params, bucket_bytes=32 << 20, op='sum', grad_dtype=None, skip=lambda name: False,
+                 late=lambda name: False):
+        """grad_dtype: dtype of the buckets on the wire (torch.bfloat16 halves the 168.5 MB of fp32 gradients per step;
+        the optimizer still sees fp32 gradients).  skip(name): parameters that never get a gradient.  late(name):
+        parameters that may get none on some steps (`denoising_class_embed` when a rank's batch has no boxes) - they go
+        into the last bucket, so that a missing hook delays only that bucket's launch to finish()."""
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.op = op
         self.buckets = []   # dicts: flat, params, pending, handle
         self._hooks = []
+        self._next = 0      # index of the first bucket not yet handed to the collective (launch order == bucket order)
         params = [(n, p) for n, p in named_params if p.requires_grad and not skip(n)]
         params.reverse()  # roughly the order gradients become ready in backward
+        params = [x for x in params if not late(x[0])] + [x for x in params if late(x[0])]
         cur, cur_bytes = [], 0
         groups = []
         for n, p in params:
@@ -81,31 +91,45 @@ class GradReducer:
         def hook(param):
             if param.grad is not view:  # dtype differs from the bucket (e.g. bf16 buckets) or grad was re-created
                 view.copy_(param.grad)
-                if view.dtype == param.dtype:
-                    param.grad = view
+                param.grad = view if view.dtype == param.dtype else None  # finish() hands back the reduced gradient
             bucket['pending'] -= 1
-            if bucket['pending'] == 0 and self.world > 1:
-                bucket['handle'] = dist.all_reduce(bucket['flat'], op=dist.ReduceOp.SUM, async_op=True)
+            if bucket['pending'] == 0:
+                self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        """Launch, in index order, every complete bucket that directly follows the launched prefix.  A complete bucket
+        behind an incomplete one waits (for that one's last hook, or for finish()): the issue order is rank-independent."""
+        while self._next < len(self.buckets) and self.buckets[self._next]['pending'] == 0:
+            b = self.buckets[self._next]
+            if self.world > 1:
+                b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
+            self._next += 1
 
     def prepare(self):
         """Call before backward: arm the per-bucket counters and zero the flat buffers."""
+        self._next = 0
         for b in self.buckets:
             b['pending'] = len(b['params'])
             b['handle'] = None
             b['flat'].zero_()
+            for (_, p), v in zip(b['params'], b['views']):
+                if v.dtype != p.dtype:
+                    p.grad = None  # last step's reduced copy: autograd must not accumulate onto it
 
     def finish(self):
-        """Call after backward: wait for the collectives (a bucket whose params did not all fire is reduced now)."""
+        """Call after backward: launch what is left in index order (a bucket with a parameter that got no gradient on this
+        rank stays zero-filled for it, and holds back the buckets behind it until here), then wait for all of them."""
+        for b in self.buckets[self._next:]:
+            b['pending'] = 0
+        self._launch_ready()
         for b in self.buckets:
             if self.world > 1:
-                if b['handle'] is None:
-                    b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
                 b['handle'].wait()
                 if self.op == 'mean':
                     b['flat'].div_(self.world)
             for (_, p), v in zip(b['params'], b['views']):
-                if p.grad is not v and v.dtype != p.dtype:
+                if v.dtype != p.dtype:
                     p.grad = v.to(p.dtype)
 
     def remove(self):

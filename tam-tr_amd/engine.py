@@ -307,7 +307,7 @@ def fitness(metrics):
 
 def fit(model, train_loader, prepare, epochs, val_loader=None, lr0=1e-4, lrf=1.0, momentum=0.9, weight_decay=1e-4, optimizer='AdamW',
         warmup_iters=2000, warmup_bias_lr=0.1, warmup_momentum=0.8, close_mosaic=0, imgsz=640, reducer=None, rank=0, world=1,
-        save_dir=None, max_steps=None, log=None):
+        save_dir=None, max_steps=None, log=None, resume=None):
     """Train `model` for `epochs` passes over train_loader; defaults are the reference's shipped hyper-parameters
     (cfg/default.yaml:23,84-90; this fork sets nbs = batch, so there is no gradient accumulation and weight decay is unscaled, and
     reads warmup_epochs as an iteration count: trainer.py:263-265,294).
@@ -315,20 +315,34 @@ def fit(model, train_loader, prepare, epochs, val_loader=None, lr0=1e-4, lrf=1.0
     prepare(batch, training) -> batch on the device (data.preprocess_batch with the prompt table bound).  reducer: dist.GradReducer for
     world > 1 - gradients are SUMMED over ranks, which is the reference's mean-reduce of a loss pre-multiplied by world_size
     (trainer.py:346-347).  Rank 0 validates the EMA weights after every epoch and keeps last.pt / best.pt under save_dir.
-    Returns the per-epoch records."""
+    resume: a checkpoint dict written by an earlier fit() ({'epoch', 'model', 'ema', 'updates', 'optimizer'}; the caller has loaded
+    'model'): EMA weights and update count, optimizer state and the epoch counter continue from it (trainer.py:560-583), so the
+    warm-up does not start over.  Returns the per-epoch records."""
     nb = len(train_loader)
     opt = build_optimizer(model, name=optimizer, lr=lr0, momentum=momentum, decay=weight_decay,
                           iterations=math.ceil(len(train_loader.dataset) / max(train_loader.batch_size or 1, 1)) * epochs)
     lf = linear_lr(epochs, lrf)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lf)
     ema = ModelEMA(model) if rank == 0 else None
-    history, best, steps = [], None, 0
-    for epoch in range(epochs):
+    history, best, steps, start = [], None, 0, 0
+    if resume is not None:
+        start = int(resume.get('epoch', -1)) + 1
+        if 'optimizer' in resume:
+            opt.load_state_dict(resume['optimizer'])
+        if ema is not None and 'ema' in resume:
+            ema.ema.load_state_dict(resume['ema'])
+            ema.updates = int(resume.get('updates', 0))
+        best = resume.get('metrics', {}).get('fitness')
+        for _ in range(start):
+            sched.step()
+    for epoch in range(start, epochs):
         model.train()
         if hasattr(train_loader.sampler, 'set_epoch'):
             train_loader.sampler.set_epoch(epoch)
         if close_mosaic and epoch == epochs - close_mosaic and hasattr(train_loader.dataset, 'close_mosaic'):
             train_loader.dataset.close_mosaic()
+            from .data import reset_workers
+            reset_workers(train_loader)     # persistent workers keep their own copy of the dataset
         t0, mean_items, waited, i = time.time(), None, 0.0, -1
         opt.zero_grad(set_to_none=True)
         batches = iter(train_loader)

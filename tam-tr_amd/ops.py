@@ -261,23 +261,21 @@ def linear_bf16(x, weight, bias=None):
 
 
 # ------------------------------------------------------------------------------------------------ a-7 self-attention
-_mask_cache = {}
+_mask_cache = []   # [(mask tensor, its _version, packed words)]: the entry keeps the mask alive, so its address cannot be reused
 
 
 def pack_mask(mask):
-    """bool [Q,Q] (True = blocked) -> int32 bit words [Q, ceil(Q/32)]; cached per mask tensor (reused by all layers)."""
-    key = (mask.data_ptr(), mask._version, tuple(mask.shape), str(mask.device))
-    hit = _mask_cache.get(key)
-    if hit is not None:
-        return hit
+    """bool [Q,Q] (True = blocked) -> int32 bit words [Q, ceil(Q/32)]; cached per mask tensor (reused by all layers).
+    The hit test is object identity + version: an address/shape key could match a NEW mask allocated in a freed one's block."""
+    if _mask_cache and _mask_cache[0][0] is mask and _mask_cache[0][1] == mask._version:
+        return _mask_cache[0][2]
     Q = mask.shape[1]
     W = (Q + 31) // 32
     m = torch.zeros(mask.shape[0], W * 32, dtype=torch.int64, device=mask.device)
     m[:, :Q] = mask.to(torch.int64)
     words = (m.view(mask.shape[0], W, 32) << torch.arange(32, device=mask.device)).sum(-1)
     words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()
-    _mask_cache.clear()
-    _mask_cache[key] = words
+    _mask_cache[:] = [(mask, mask._version, words)]
     return words
 
 

@@ -186,3 +186,21 @@ def test_fused_eval_graph_matches_reference(golden):
     check_summary(fx, 'model.w0', model.model[0].conv.weight, 1e-6, 1e-7)
     assert_close(model.model[0].conv.bias, fx['model.b0'], 1e-6, 1e-7, 'stem bias')
     assert not any(p.requires_grad for n, p in model.named_parameters() if n.endswith('.conv.bias') and not n.startswith('model.41.'))
+
+
+def test_pack_mask_cache_is_keyed_on_the_tensor_not_its_address():
+    """a freed mask's block can be handed to a new mask of the same shape; the packed words must follow the tensor."""
+    from tamtr_amd import ops
+    from tamtr_amd.loss import _dn_attn_mask
+
+    def bits(m):
+        Q = m.shape[1]
+        w = ops.pack_mask(m).to(torch.int64) & 0xFFFFFFFF
+        return torch.stack([(w[:, j // 32] >> (j % 32)) & 1 for j in range(Q)], 1).bool()
+    for mx, ng in ((30, 3), (45, 2), (90, 1), (30, 3)):     # all give n_dn = 180
+        m = _dn_attn_mask(180, 100, mx, ng, 'cpu').clone()  # fresh storage each time (may reuse the previous one's block)
+        assert torch.equal(bits(m), m)
+        assert ops.pack_mask(m) is ops.pack_mask(m)         # reused while it is the same tensor ...
+        m[0, 1] = ~m[0, 1]
+        assert torch.equal(bits(m), m)                      # ... and rebuilt after an in-place edit
+        del m

@@ -50,8 +50,10 @@ def main():
     ap.add_argument('--mosaic', type=float, default=0.0)
     ap.add_argument('--device-augment', action='store_true', help='affine warp / HSV / flips / float conversion on the GPU (needs --mosaic 0)')
     ap.add_argument('--max-steps', type=int)
-    ap.add_argument('--weights', help='state_dict checkpoint (last.pt / best.pt of an earlier run) to start from')
+    ap.add_argument('--weights', help='last.pt / best.pt of an earlier run: weights, EMA, optimizer state and epoch are restored')
     ap.add_argument('--save-dir', default='runs/train/TAMTR')
+    ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--grad-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire (N > 1)')
     args = ap.parse_args()
 
     import tamtr_amd  # noqa: F401  (raises if the HIP library is missing)
@@ -89,12 +91,16 @@ def main():
 
     torch.manual_seed(0)
     model = RTDETRDetectionWorldModel(nc=len(names)).to(dev).train()
-    if args.weights:
-        model.load_state_dict(torch.load(args.weights, map_location=dev)['model'])
+    resume = None
+    if args.weights:   # a checkpoint written by engine.fit: {'epoch', 'model', 'ema', 'updates', 'optimizer', 'metrics'} (state_dicts only;
+        resume = torch.load(args.weights, map_location=dev)   # a reference .pt pickles modules: export its state_dict first)
+        model.load_state_dict(resume['model'])
+    torch.manual_seed(args.seed + 1 + rank)    # per-rank streams for DropPath / denoising noise (reference: seed + 1 + RANK)
     model.autocast_dtype = torch.bfloat16 if args.dtype == 'bf16' else None
     model.names = names
     model.set_text_features(tf.encode([v.split('/')[0] for v in names.values()])[None].to(dev))     # validation vocabulary
-    reducer = tdist.GradReducer(model.named_parameters(), skip=lambda n: '.attn.' in n) if world > 1 else None
+    reducer = tdist.GradReducer(model.named_parameters(), skip=lambda n: '.attn.' in n, late=lambda n: 'denoising_class_embed' in n,
+                                grad_dtype=torch.bfloat16 if args.grad_dtype == 'bf16' else None) if world > 1 else None
 
     def prepare(batch, training):
         return D.preprocess_batch(batch, tf if training else None, dev)
@@ -102,7 +108,7 @@ def main():
     def log(rec):
         print(json.dumps({k: (round(v, 5) if isinstance(v, float) else v) for k, v in rec.items()}), flush=True)
     E.fit(model, tl, prepare, args.epochs, val_loader=vl, lr0=args.lr0, close_mosaic=args.close_mosaic, imgsz=args.imgsz, reducer=reducer,
-          rank=rank, world=world, save_dir=args.save_dir if rank == 0 else None, max_steps=args.max_steps, log=log)
+          rank=rank, world=world, save_dir=args.save_dir if rank == 0 else None, max_steps=args.max_steps, log=log, resume=resume)
     if tmp is not None:
         tmp.cleanup()
 

@@ -46,6 +46,7 @@ def main():
     model.load_state_dict(ck['model' if args.raw else 'ema'])
     model.set_text_features(tf.encode([v.split('/')[0] for v in names.values()])[None].to(dev))
     model.eval()
+    model.autocast_dtype = torch.bfloat16 if args.dtype == 'bf16' else None    # predict() opens its own autocast region from this
     if not args.no_fuse:
         model.fuse()
     res = E.validate(model, (D.preprocess_batch(b, None, dev) for b in loader), imgsz=args.imgsz, conf=args.conf, iou=args.iou,
