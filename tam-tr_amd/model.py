@@ -53,6 +53,9 @@ def build_graph(spec, ch=3, nc=10):
         elif name == 'ManbaWorldDecoder':
             a = [nc if v == 'nc' else v for v in args]
             m, c2 = ManbaWorldDecoder(a[0], [chans[j] for j in f], *a[1:]), None
+        elif name == 'Detect':      # the yolo head rows `[[..], 1, Detect, [nc]]` (tasks.py:923-924): args = [nc], ch from `f`
+            from .detect import Detect
+            m, c2 = Detect(nc if args[0] == 'nc' else args[0], [chans[j] for j in f]), None
         else:
             raise ValueError(name)
         m.i, m.f, m.type = i, f, name

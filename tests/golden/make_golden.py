@@ -843,6 +843,32 @@ def gen_fuse():
     save('fuse', d)
 
 
+def gen_detect():
+    """Boundary class `Detect` (nn/modules/head.py:22-82): train-mode maps, eval output, bias_init, for nc 10 and two channel sets."""
+    from ultralytics.nn.modules.head import Detect
+    d = {}
+    for tag, nc, ch, sizes in (('A', 10, (32, 64, 128), ((2, 8, 8), (2, 4, 4), (2, 2, 2))), ('B', 3, (16, 48), ((1, 6, 10), (1, 3, 5)))):
+        m = set_bn(Detect(nc, ch))
+        d[f'{tag}.wsum'] = load_filled(m, seed=21)
+        m.stride = torch.tensor([8., 16., 32.][:len(ch)])
+        xs = [rnd((b, c, h, w), 40 + i) for i, (c, (b, h, w)) in enumerate(zip(ch, sizes))]
+        m.train()
+        out = m([x.clone() for x in xs])
+        for i, o in enumerate(out):
+            d[f'{tag}.train{i}'] = o
+        d[f'{tag}.bn_mean'] = m.cv2[0][0].bn.running_mean
+        m.eval()
+        y, raw = m([x.clone() for x in xs])
+        d[f'{tag}.y'] = y
+        d[f'{tag}.raw0'] = raw[0]
+        m.bias_init()
+        d[f'{tag}.bias_box'] = m.cv2[1][-1].bias
+        d[f'{tag}.bias_cls'] = m.cv3[1][-1].bias
+        d[f'{tag}.cfg'] = np.asarray([nc, len(ch), m.no, m.reg_max])
+        d[f'{tag}.keys'] = np.asarray(sorted(m.state_dict()))
+    save('detect', d)
+
+
 def gen_e2e():
     for wseed in range(71, 91):
         if _gen_e2e(wseed):
@@ -853,6 +879,6 @@ def gen_e2e():
 if __name__ == '__main__':
     _import_reference()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['gate', 'msdeform', 'contrastive', 'decoder', 'cdn', 'loss', 'vss', 'head', 'e2e', 'metrics', 'data', 'fuse']
+    which = sys.argv[1:] or ['gate', 'msdeform', 'contrastive', 'decoder', 'cdn', 'loss', 'vss', 'head', 'e2e', 'metrics', 'data', 'fuse', 'detect']
     for w in which:
         globals()['gen_' + w]()

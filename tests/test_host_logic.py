@@ -204,3 +204,39 @@ def test_pack_mask_cache_is_keyed_on_the_tensor_not_its_address():
         m[0, 1] = ~m[0, 1]
         assert torch.equal(bits(m), m)                      # ... and rebuilt after an in-place edit
         del m
+
+
+@pytest.mark.parametrize('tag,ch,sizes', [('A', (32, 64, 128), ((2, 8, 8), (2, 4, 4), (2, 2, 2))), ('B', (16, 48), ((1, 6, 10), (1, 3, 5)))])
+def test_detect_head_api_vs_reference_fixture(golden, tag, ch, sizes):
+    """Boundary class `Detect(nc, ch)` (north_star 'yolo Detect head API', nn/modules/head.py:22-82) against the reference's own
+    module: state_dict keys, train-mode maps (with the BatchNorm side effect), eval output (y, raw maps), export output, bias_init."""
+    from tamtr_amd.detect import Detect
+    fx = golden('detect')
+    nc, nl, no, reg_max = (int(v) for v in fx[f'{tag}.cfg'])
+    m = Detect(nc, ch)
+    assert (m.nc, m.nl, m.no, m.reg_max) == (nc, nl, no, reg_max) and sorted(m.state_dict()) == fx[f'{tag}.keys'].tolist()
+    st = fill_state(m.state_dict(), 21)
+    assert abs(checksum(st) - float(fx[f'{tag}.wsum'])) <= 1e-6 * abs(float(fx[f'{tag}.wsum']))
+    m.load_state_dict(st)
+    assert not m.dfl.conv.weight.requires_grad
+    m.stride = torch.tensor([8., 16., 32.][:nl])
+    xs = [rnd((b, c, h, w), 40 + i) for i, (c, (b, h, w)) in enumerate(zip(ch, sizes))]
+    m.train()
+    fed = [x.clone() for x in xs]
+    out = m(fed)
+    assert out is fed                                        # the reference rewrites the caller's list in place
+    for i, o in enumerate(out):
+        assert_close(o, fx[f'{tag}.train{i}'], 1e-4, 1e-5, f'train map {i}')
+    assert_close(m.cv2[0][0].bn.running_mean, fx[f'{tag}.bn_mean'], 1e-5, 1e-6, 'running_mean')
+    m.eval()
+    y, raw = m([x.clone() for x in xs])
+    assert y.shape == (sizes[0][0], 4 + nc, sum(h * w for _, h, w in sizes))
+    assert_close(y, fx[f'{tag}.y'], 1e-4, 1e-4, 'eval y')
+    assert_close(raw[0], fx[f'{tag}.raw0'], 1e-4, 1e-5, 'eval raw map')
+    m.export = True
+    assert torch.equal(m([x.clone() for x in xs]), y)
+    m.bias_init()
+    assert_close(m.cv2[1][-1].bias, fx[f'{tag}.bias_box'], 0, 0)
+    assert_close(m.cv3[1][-1].bias, fx[f'{tag}.bias_cls'], 1e-6, 1e-6)
+    with pytest.raises(ValueError):
+        m([xs[0]] * (nl + 1))
