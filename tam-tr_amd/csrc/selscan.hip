@@ -333,302 +333,371 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
   }
 }
 
-// In-kernel phase timing (build with -DSCAN_STAMP through tools/build_scan_variant.sh; tools/scan_stamps.py reads the sums that
-// wave 0 of workgroup (0, 0) leaves in the first floats of gu): s_memtime deltas accumulated per phase.
-#ifdef SCAN_STAMP
-#define STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
-#define STAMP(i) { unsigned long long st_now; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory"); st_acc[i] += st_now - st_last; st_last = st_now; }
-#else
-#define STAMP_DECL
-#define STAMP(i)
-#endif
+// ------------------------------------------------------------------------------------------------ backward
+// One pass per (row, chunk) over all 16 states.  The first version walked the states in groups of 4 (register tile of dB/dC =
+// 2 x 4 x ITEMS) and therefore repeated the row prologue (dt projection, softplus, u / gy loads) four times and carried the
+// per-row partial du / d(delta) sums between the groups through HBM (33 GB of traffic per level-0 launch, 16.5 ms, waves
+// parked half of their life in the prologue's load waits).  Here:
+//   * the dB/dC tile of ALL states stays in registers (2 x 16 x ITEMS = 128 VGPRs) across the BWD_RPW rows of a wave, the loop
+//     over the states is unrolled with scheduling fences between the states so that only one state's temporaries are live
+//     (~230 VGPRs: still two waves per SIMD);
+//   * sum_n gh_n B_n is accumulated once per step (S) and turned into du and the B-part of d(delta) after the states, instead of
+//     four FMAs per (state, step);
+//   * the next row's u / gy / parameters (A, D, bias, chunk-entry states: one VGPR, lane n holds entry n) are requested while the
+//     current row computes, so no load is waited for at its point of use;
+//   * the cross-lane scans use DPP-fused v_fmac / v_mul (inline asm: hipcc keeps a v_mov_b32_dpp in front of every float mul/fma),
+//     the prefix scan of h and the suffix scan of dL/dh interleaved so that no DPP hazard nop is needed between the levels;
+//   * the 16 per-state dA sums (and the rank-R d(Wdt) sums) of a row are reduced over the wave together: a reduce-scatter
+//     (16 -> 8 -> 4 values per lane while the lane groups halve) instead of 16 separate 6-level reductions.
+// per-row LDS accumulators, ACC floats per row: [0, 16) dA | [16, 16 + R) d(Wdt) | [62] dD, [63] d(bias)
+constexpr int ACC = 64;
 
-#ifndef SCAN_BWD_PREFETCH
-#define SCAN_BWD_PREFETCH 0  // measured: 18.1 vs 17.6 ms at level 0 with it on (256 VGPRs + scratch); kept for the record
-#endif
-// global streams of one backward row for one chunk: u, gy, and (from the second state group on) the partial du / d(delta) sums
-template <bool VEC>
-__device__ __forceinline__ void bwd_fetch_row(const float* __restrict__ u, const float* __restrict__ gy, const float* __restrict__ gu,
-                                              const float* __restrict__ gdelta, int bk, int K, int k, int Dk, int d, int L, int t, bool rev,
-                                              int xmode, bool first, float (&uu)[ITEMS], float (&g)[ITEMS], float (&pdu)[ITEMS],
-                                              float (&pddt)[ITEMS]) {
-  const size_t row = (size_t)(bk / K) * K * Dk + (size_t)k * Dk + d;
-  const size_t prow = ((size_t)(bk / K) * 2 + (k & 1)) * Dk + d;
-  load4<VEC>(xmode ? u + prow * L : u + row * L, t, L, uu, 0.f, rev);
-  load4<VEC>((xmode & 2) ? gy + prow * L : gy + row * L, t, L, g, 0.f, rev);
-  if (!first) {
-    load4<VEC>(gu + row * L, t, L, pdu, 0.f, rev);
-    load4<VEC>(gdelta + row * L, t, L, pddt, 0.f, rev);
+// (pA, pB): inclusive PREFIX scan over the 64 lanes of the affine maps h -> A*h + B (row_shr 1,2,4,8, row_bcast 15 / 31);
+// (sA, sB): the four in-row levels (row_shl 1,2,4,8) of the inclusive SUFFIX scan.  One statement: inside it every DPP read is
+// at least two instructions behind the write of its source (the gfx9 VALU-write -> DPP-read hazard), the s_nop at both ends
+// covers the compiler's instructions around it (which it cannot see into).
+__device__ __forceinline__ void fused_scans(float& pA, float& pB, float& sA, float& sB) {
+#define P_LVL(c) "v_fmac_f32_dpp %1, %1, %0 " c "\n\tv_mul_f32_dpp %0, %0, %0 " c "\n\t"
+#define S_LVL(c) "v_fmac_f32_dpp %3, %3, %2 " c "\n\tv_mul_f32_dpp %2, %2, %2 " c "\n\t"
+  asm volatile("s_nop 1\n\t"
+               P_LVL("row_shr:1 row_mask:0xf bank_mask:0xf") S_LVL("row_shl:1 row_mask:0xf bank_mask:0xf")
+               P_LVL("row_shr:2 row_mask:0xf bank_mask:0xf") S_LVL("row_shl:2 row_mask:0xf bank_mask:0xf")
+               P_LVL("row_shr:4 row_mask:0xf bank_mask:0xf") S_LVL("row_shl:4 row_mask:0xf bank_mask:0xf")
+               P_LVL("row_shr:8 row_mask:0xf bank_mask:0xf") S_LVL("row_shl:8 row_mask:0xf bank_mask:0xf")
+               P_LVL("row_bcast:15 row_mask:0xa bank_mask:0xf") "s_nop 0\n\t"
+               P_LVL("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
+               : "+v"(pA), "+v"(pB), "+v"(sA), "+v"(sB));
+#undef P_LVL
+#undef S_LVL
+}
+
+// Sums over the 64 lanes of two sets of 16 per-lane values at once: a reduce-scatter - every step halves both the number of
+// values a lane carries and the group of lanes that share them - instead of 32 separate 6-level reductions:
+//   lane bit 5: v_permlane32_swap of (value j, value j+8), the lower half keeps j, the upper half j+8          16 -> 8
+//   lane bit 4: v_permlane16_swap of (j, j+4), even 16-lane rows keep j, odd rows j+4                          8 -> 4
+//   lane bit 3 / bit 2: two DPP adds with complementary bank masks per kept value (row_shl / row_shr by 8 / 4)  4 -> 2 -> 1
+//   lane bits 1, 0: butterfly over the quad.
+// On return lane l holds in x[0] / y[0] the total of value (l >> 2) & 15 of its set (the four lanes of a quad agree).
+__device__ __forceinline__ float f_of(unsigned v) { return __builtin_bit_cast(float, v); }
+__device__ __forceinline__ unsigned u_of(float v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ void reduce16x2(float (&x)[16], float (&y)[16]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const auto rx = __builtin_amdgcn_permlane32_swap(u_of(x[j]), u_of(x[j + 8]), false, false);
+    const auto ry = __builtin_amdgcn_permlane32_swap(u_of(y[j]), u_of(y[j + 8]), false, false);
+    x[j] = f_of(rx[0]) + f_of(rx[1]);
+    y[j] = f_of(ry[0]) + f_of(ry[1]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const auto rx = __builtin_amdgcn_permlane16_swap(u_of(x[j]), u_of(x[j + 4]), false, false);
+    const auto ry = __builtin_amdgcn_permlane16_swap(u_of(y[j]), u_of(y[j + 4]), false, false);
+    x[j] = f_of(rx[0]) + f_of(rx[1]);
+    y[j] = f_of(ry[0]) + f_of(ry[1]);
+  }
+  // every DPP read below is at least two instructions behind the write of its source register
+#define DA(d, s, c) "v_add_f32_dpp %" #d ", %" #s ", %" #s " " c "\n\t"
+  asm volatile("s_nop 1\n\t"
+               DA(0, 0, "row_shl:8 row_mask:0xf bank_mask:0x3") DA(4, 4, "row_shl:8 row_mask:0xf bank_mask:0x3")
+               DA(1, 1, "row_shl:8 row_mask:0xf bank_mask:0x3") DA(5, 5, "row_shl:8 row_mask:0xf bank_mask:0x3")
+               DA(0, 2, "row_shr:8 row_mask:0xf bank_mask:0xc") DA(4, 6, "row_shr:8 row_mask:0xf bank_mask:0xc")
+               DA(1, 3, "row_shr:8 row_mask:0xf bank_mask:0xc") DA(5, 7, "row_shr:8 row_mask:0xf bank_mask:0xc")
+               DA(0, 0, "row_shl:4 row_mask:0xf bank_mask:0x5") DA(4, 4, "row_shl:4 row_mask:0xf bank_mask:0x5")
+               DA(0, 1, "row_shr:4 row_mask:0xf bank_mask:0xa") DA(4, 5, "row_shr:4 row_mask:0xf bank_mask:0xa")
+               "s_nop 0\n\t"
+               DA(0, 0, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") DA(4, 4, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+               "s_nop 0\n\t"
+               DA(0, 0, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf") DA(4, 4, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+               "s_nop 1"
+               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+#undef DA
+}
+
+// v[lane n] = s (n < 16; the lane select is an inline constant: a second SGPR would exceed the constant bus of a gfx9 VALU op)
+template <int N>
+__device__ __forceinline__ void write_lane_c(float& v, float s) { asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(N)); }
+__device__ __forceinline__ void write_lane(float& v, float s, int n) {  // n is a constant after unrolling: the switch folds
+  switch (n) {
+#define WL(N) case N: write_lane_c<N>(v, s); break;
+    WL(0) WL(1) WL(2) WL(3) WL(4) WL(5) WL(6) WL(7) WL(8) WL(9) WL(10) WL(11) WL(12) WL(13) WL(14) WL(15)
+#undef WL
   }
 }
 
+// the same for one set (the DPP levels wait out their hazards with nops instead of a second set's instructions)
+__device__ __forceinline__ void reduce16(float (&x)[16]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const auto rx = __builtin_amdgcn_permlane32_swap(u_of(x[j]), u_of(x[j + 8]), false, false);
+    x[j] = f_of(rx[0]) + f_of(rx[1]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const auto rx = __builtin_amdgcn_permlane16_swap(u_of(x[j]), u_of(x[j + 4]), false, false);
+    x[j] = f_of(rx[0]) + f_of(rx[1]);
+  }
+#define DA(d, s, c) "v_add_f32_dpp %" #d ", %" #s ", %" #s " " c "\n\t"
+  asm volatile("s_nop 1\n\t"
+               DA(0, 0, "row_shl:8 row_mask:0xf bank_mask:0x3") DA(1, 1, "row_shl:8 row_mask:0xf bank_mask:0x3")
+               DA(0, 2, "row_shr:8 row_mask:0xf bank_mask:0xc") DA(1, 3, "row_shr:8 row_mask:0xf bank_mask:0xc")
+               "s_nop 0\n\t"
+               DA(0, 0, "row_shl:4 row_mask:0xf bank_mask:0x5") DA(0, 1, "row_shr:4 row_mask:0xf bank_mask:0xa")
+               "s_nop 1\n\t"
+               DA(0, 0, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+               "s_nop 1\n\t"
+               DA(0, 0, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+               "s_nop 1"
+               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+#undef DA
+}
+
+// u, gy of one row for one chunk
+template <bool VEC>
+__device__ __forceinline__ void bwd_fetch_row(const float* __restrict__ u, const float* __restrict__ gy, int b, int K, int k, int Dk,
+                                              int d, int L, int t, bool rev, int xmode, float (&uu)[ITEMS], float (&g)[ITEMS]) {
+  const size_t row = ((size_t)b * K + k) * Dk + d;
+  const size_t prow = ((size_t)b * 2 + (k & 1)) * Dk + d;
+  load4<VEC>(xmode ? u + prow * L : u + row * L, t, L, uu, 0.f, rev);
+  load4<VEC>((xmode & 2) ? gy + prow * L : gy + row * L, t, L, g, 0.f, rev);
+}
+// the row's small operands in ONE register: lane n < 16: A[kd][n]; lane 16: D[kd]; lane 17: delta bias; lanes 32..47: the
+// state entering chunk c (zero for c == 0).  Read back per state with v_readlane (wave-uniform operands of the VALU ops).
+__device__ __forceinline__ float bwd_fetch_param(const float* __restrict__ Am, const float* __restrict__ Dv, const float* __restrict__ dbias,
+                                                 const float* __restrict__ hstate, int kd, size_t row, int nchunk, int c, int lane) {
+  const float* p = Am + (size_t)kd * NS + (lane & (NS - 1));
+  if (lane == 16) p = Dv + kd;
+  if (lane == 17) p = dbias + kd;
+  if (lane >= 32 && lane < 48 && c > 0) p = hstate + (row * nchunk + (c - 1)) * NS + (lane - 32);
+  const float v = *p;
+  return (lane >= 32 && c == 0) ? 0.f : v;
+}
+
 // Backward: BWD_WAVES waves x BWD_RPW rows each = BWD_ROWS rows of one (b, k) group per workgroup.
-template <bool VEC, int STG>
-__global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_bwd_kernel(
+template <bool VEC>
+__global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
     const float* __restrict__ gy, const float* __restrict__ u, const float* __restrict__ delta, const float* __restrict__ Am,
     const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ Dv, const float* __restrict__ dbias,
     const float* __restrict__ hstate, float* __restrict__ gu, float* __restrict__ gdelta, float* __restrict__ gA,
     float* __restrict__ wsB, float* __restrict__ wsC, float* __restrict__ gD, float* __restrict__ gdbias, int K, int Dk, int L,
     int nchunk, size_t slab_elems, int xmode, const float* __restrict__ dtr, const float* __restrict__ Wdt, float* __restrict__ gWdt,
-    int R, int h0_staged) {
-  __shared__ float sB[NS][CHUNK];
-  __shared__ float sC[NS][CHUNK];
-  // the dB/dC fold tile aliases the B/C tiles: they are dead once the chunk's rows are done (keeps LDS at 2 workgroups per CU)
-  float(*s_dB)[CHUNK] = sB;
-  float(*s_dC)[CHUNK] = sC;
-  __shared__ float s_A[BWD_WAVES][BWD_RPW][NS], s_carry[BWD_WAVES][BWD_RPW][NS], s_dA[BWD_WAVES][BWD_RPW][NS];
-  __shared__ float s_dD[BWD_WAVES][BWD_RPW], s_db[BWD_WAVES][BWD_RPW];
-  __shared__ float s_rc[BWD_WAVES][BWD_RPW][2];  // D and delta bias of the wave's rows (as scalar loads they missed the scalar cache: ~1 us per row)
-  extern __shared__ float s_dyn[];  // fused dt projection: [R][CHUNK] factors | [BWD_ROWS][RMAX] Wdt rows | [BWD_ROWS][RMAX] gWdt sums
-  float(*s_dtr)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(s_dyn);
-  float* s_W = s_dyn + (size_t)R * CHUNK;
-  float* s_gW = s_W + BWD_ROWS * RMAX;
-  // states entering the chunk, [BWD_ROWS][NS] (wave-private rows; fetched while the tiles are staged).  Only when the
-  // launcher found room for it next to the rank-R tiles: 2 workgroups per CU matter more (rank 32 runs without it)
-  float* s_h0 = h0_staged ? s_dyn + (dtr ? (size_t)R * CHUNK + 2 * BWD_ROWS * RMAX : 0) : nullptr;
+    int R) {
+  // one dynamic LDS array: B tile | C tile (the dB/dC fold tile aliases them) | rank-R dt factors | Wdt rows | per-row sums
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float(*sB)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(smem);
+  float(*sC)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(smem + NS * CHUNK);
+  float(*s_dtr)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(smem + 2 * NS * CHUNK);
+  float* s_W = smem + 2 * NS * CHUNK + (size_t)R * CHUNK;  // [BWD_ROWS][RMAX]
+  float* s_acc = s_W + BWD_ROWS * RMAX;                    // [BWD_ROWS][ACC]    dA | d(Wdt) | dD, d(bias) sums
+  float* s_carry = s_acc + BWD_ROWS * ACC;                 // [BWD_ROWS][NS]     a_t * dL/dh_t entering from the next chunk
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-  const int bk = blockIdx.y, k = bk % K;
+  const int bk = blockIdx.y, k = bk % K, b = bk / K;
   const float* Bp = Bm + (size_t)bk * NS * L;
   const float* Cp = Cm + (size_t)bk * NS * L;
   float* slabB = wsB + (size_t)blockIdx.x * slab_elems + (size_t)bk * NS * L;
   float* slabC = wsC + (size_t)blockIdx.x * slab_elems + (size_t)bk * NS * L;
   const int d0 = blockIdx.x * BWD_ROWS + wave * BWD_RPW;
   const bool rev = xmode && k >= 2;
-  // ds_bpermute byte addresses of the first lane of the next / next-but-one 16-lane row (suffix scan, cross-row levels)
   const int rowi = lane >> 4;
-  const int addr1 = rowi + 1 < 4 ? (rowi + 1) * 64 : -1;
+  const int addr1 = rowi + 1 < 4 ? (rowi + 1) * 64 : -1;   // (suffix scan: which 16-lane rows follow this one)
   const int addr2 = rowi + 2 < 4 ? (rowi + 2) * 64 : -1;
   for (int r = 0; r < BWD_RPW; ++r) {
+    const int wr = wave * BWD_RPW + r;
     const int kd = k * Dk + min(d0 + r, Dk - 1);
-    if (lane < NS) { s_A[wave][r][lane] = Am[(size_t)kd * NS + lane]; s_carry[wave][r][lane] = 0.f; s_dA[wave][r][lane] = 0.f; }
-    if (lane == 0) { s_dD[wave][r] = 0.f; s_db[wave][r] = 0.f; s_rc[wave][r][0] = Dv[kd]; s_rc[wave][r][1] = dbias[kd]; }
-    if (dtr && lane < R) { s_W[(wave * BWD_RPW + r) * RMAX + lane] = Wdt[(size_t)kd * R + lane]; s_gW[(wave * BWD_RPW + r) * RMAX + lane] = 0.f; }
+    if (lane < NS) s_carry[wr * NS + lane] = 0.f;
+    s_acc[wr * ACC + lane] = 0.f;
+    if (dtr && lane < RMAX) s_W[wr * RMAX + lane] = lane < R ? Wdt[(size_t)kd * R + lane] : 0.f;
   }
   const float* Rp = dtr ? dtr + (size_t)bk * R * L : nullptr;
+  const int nrow = min(BWD_RPW, Dk - d0);  // rows this wave really has (<= 0: none)
 
-  STAMP_DECL
   for (int c = nchunk - 1; c >= 0; --c) {
     __syncthreads();  // previous chunk's tiles fully consumed / flushed
-    STAMP(0)  // 0: waiting at the chunk-top barrier
-    // chunk-entry states of this wave's rows: 16 consecutive floats per row, requested now and consumed after the staging
-    // barrier (read per state as wave-uniform scalars they cost ~8 % of the kernel in s_waitcnt on HBM-missing s_loads)
-    if (h0_staged) {
+    const int t = c * CHUNK + lane * ITEMS;
+    // first row's streams: requested before the staging, consumed after it
+    float n_uu[ITEMS], n_g[ITEMS], n_par = 0.f;
 #pragma unroll
-      for (int rr = lane >> 4; rr < BWD_RPW; rr += WAVE / NS) {
-        const int d = min(d0 + rr, Dk - 1);
-        const size_t row = (size_t)(bk / K) * K * Dk + (size_t)k * Dk + d;
-        s_h0[((wave * BWD_RPW) + rr) * NS + (lane & (NS - 1))] = c > 0 ? hstate[(row * nchunk + (c - 1)) * NS + (lane & (NS - 1))] : 0.f;
-      }
+    for (int i = 0; i < ITEMS; ++i) n_uu[i] = n_g[i] = 0.f;
+    if (nrow > 0) {
+      bwd_fetch_row<VEC>(u, gy, b, K, k, Dk, d0, L, t, rev, xmode, n_uu, n_g);
+      n_par = bwd_fetch_param(Am, Dv, dbias, hstate, k * Dk + d0, ((size_t)b * K + k) * Dk + d0, nchunk, c, lane);
     }
     stage_bc<BWD_WAVES * WAVE>(Bp, Cp, c * CHUNK, L, sB, sC, VEC, rev);
     if (dtr) stage_dtr<BWD_WAVES * WAVE>(Rp, R, c * CHUNK, L, s_dtr, VEC, rev);
     __syncthreads();
-    STAMP(1)  // 1: staging of the B/C/dt tiles + barrier
-    const int t = c * CHUNK + lane * ITEMS;
-    // The 16 states are walked in groups of STG: the dB/dC register tile is [STG][ITEMS] x 2 instead of [16][ITEMS] x 2 and
-    // only STG states are in flight, which is what lets two waves share a SIMD (<= 256 VGPR, no AGPR shuttling, no scratch).
-    // The per-row d(delta)/du partial sums travel between groups through the gu / gdelta output buffers (same lane, same
-    // address: program order is enough); the row's own inputs (u, gy, delta) are simply re-read / re-projected per group.
-#pragma unroll 1
-    for (int sg = 0; sg < NS / STG; ++sg) {
-      const int n0 = sg * STG;
-      const bool first = sg == 0, last = sg == NS / STG - 1;
-      float accB[STG][ITEMS], accC[STG][ITEMS];  // this wave's rows' dB/dC for the chunk and state group, summed in registers
+    float accB[NS][ITEMS], accC[NS][ITEMS];  // this wave's rows' dB/dC for the chunk, summed in registers
 #pragma unroll
-      for (int j = 0; j < STG; ++j)
+    for (int n = 0; n < NS; ++n)
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) { accB[j][i] = 0.f; accC[j][i] = 0.f; }
+      for (int i = 0; i < ITEMS; ++i) { accB[n][i] = 0.f; accC[n][i] = 0.f; }
 
-#if SCAN_BWD_PREFETCH
-      // software pipeline over the rows: the streams of row r+1 (u, gy, partial sums) are requested before row r's arithmetic
-      // starts; in-kernel stamps put the exposed wait for these loads at ~25 % of the kernel without it
-      float n_uu[ITEMS], n_g[ITEMS], n_du[ITEMS], n_ddt[ITEMS];
-#pragma unroll
-      for (int i = 0; i < ITEMS; ++i) n_du[i] = n_ddt[i] = 0.f;
-      if (d0 < Dk) bwd_fetch_row<VEC>(u, gy, gu, gdelta, bk, K, k, Dk, d0, L, t, rev, xmode, first, n_uu, n_g, n_du, n_ddt);
-#endif
 #pragma unroll 1
-      for (int r = 0; r < BWD_RPW; ++r) {
-        const int d = d0 + r;
-        if (d < Dk) {  // wave-uniform
-          const int kd = k * Dk + d;
-          const size_t row = (size_t)(bk / K) * K * Dk + kd;
-          const float Dd = s_rc[wave][r][0], bias = s_rc[wave][r][1];
-          const float* An = s_A[wave][r];
-          float* carry = s_carry[wave][r];
-          float uu[ITEMS], dl[ITEMS], dt[ITEMS], g[ITEMS], ddt[ITEMS], du[ITEMS], dtu[ITEMS];
-#if SCAN_BWD_PREFETCH
+    for (int r = 0; r < nrow; ++r) {
+      const int d = d0 + r, wr = wave * BWD_RPW + r;
+      const int kd = k * Dk + d;
+      const size_t row = ((size_t)b * K + k) * Dk + d;
+      float uu[ITEMS], g[ITEMS], dt[ITEMS], dtu[ITEMS], S[ITEMS], ddtA[ITEMS];
+      const float par = n_par;
 #pragma unroll
-          for (int i = 0; i < ITEMS; ++i) { uu[i] = n_uu[i]; g[i] = n_g[i]; du[i] = n_du[i]; ddt[i] = n_ddt[i]; }
-          if (r + 1 < BWD_RPW && d + 1 < Dk) bwd_fetch_row<VEC>(u, gy, gu, gdelta, bk, K, k, Dk, d + 1, L, t, rev, xmode, first, n_uu, n_g, n_du, n_ddt);
-#else
-          const float* up = xmode ? u + (((size_t)(bk / K) * 2 + (k & 1)) * Dk + d) * L : u + row * L;
-          load4<VEC>(up, t, L, uu, 0.f, rev);
-#endif
-          const float* Wr = s_W + (wave * BWD_RPW + r) * RMAX;
-          if (dtr) {
-            dl[0] = dl[1] = dl[2] = dl[3] = 0.f;
-            dtproj_row(Wr, s_dtr, R, lane, dl);
-          } else {
-            load4<VEC>(delta + row * L, t, L, dl, 0.f, rev);
-          }
-#if SCAN_BWD_PREFETCH
-          if (first) {
+      for (int i = 0; i < ITEMS; ++i) { uu[i] = n_uu[i]; g[i] = n_g[i]; S[i] = 0.f; ddtA[i] = 0.f; }
+      if (r + 1 < nrow) {  // next row's streams
+        bwd_fetch_row<VEC>(u, gy, b, K, k, Dk, d + 1, L, t, rev, xmode, n_uu, n_g);
+        n_par = bwd_fetch_param(Am, Dv, dbias, hstate, kd + 1, row + 1, nchunk, c, lane);
+      }
+      const float Dd = rdlane(par, 16), bias = rdlane(par, 17);
+      {
+        float dl[ITEMS];
+        if (dtr) {
+          dl[0] = dl[1] = dl[2] = dl[3] = 0.f;
+          dtproj_row(s_W + wr * RMAX, s_dtr, R, lane, dl);
+        } else {
+          load4<VEC>(delta + row * L, t, L, dl, 0.f, rev);
+        }
 #pragma unroll
-            for (int i = 0; i < ITEMS; ++i) { ddt[i] = 0.f; du[i] = Dd * g[i]; }
-          }
-#else
-          load4<VEC>((xmode & 2) ? gy + (((size_t)(bk / K) * 2 + (k & 1)) * Dk + d) * L : gy + row * L, t, L, g, 0.f, rev);
-          if (first) {
-#pragma unroll
-            for (int i = 0; i < ITEMS; ++i) { ddt[i] = 0.f; du[i] = Dd * g[i]; }
-          } else {  // partial sums left by the previous state group
-            load4<VEC>(gu + row * L, t, L, du, 0.f, rev);
-            load4<VEC>(gdelta + row * L, t, L, ddt, 0.f, rev);
-          }
-#endif
-#ifdef SCAN_STAMP
-#if !SCAN_BWD_PREFETCH
-          __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): make the global-load wait visible as its own phase
-#endif
-          STAMP(7)  // 7: dt projection (LDS) issued before + wait for the row's global loads
-#endif
-#pragma unroll
-          for (int i = 0; i < ITEMS; ++i) {
-            dt[i] = (t + i < L) ? softplus_f(dl[i] + bias) : 0.f;
-            dtu[i] = dt[i] * uu[i];
-          }
-          STAMP(2)  // 2: row prologue: loads of u, gy, partial sums; dt projection; softplus
-          const float* hs = h0_staged ? s_h0 + (wave * BWD_RPW + r) * NS + n0 : hstate + (row * nchunk + (c > 0 ? c - 1 : 0)) * NS + n0;
-#pragma unroll
-          for (int j = 0; j < STG; ++j) {
-            const int n = n0 + j;
-            const float4 b4 = *reinterpret_cast<const float4*>(&sB[n][lane * ITEMS]);
-            const float4 c4 = *reinterpret_cast<const float4*>(&sC[n][lane * ITEMS]);
-            const float bb[ITEMS] = {b4.x, b4.y, b4.z, b4.w}, cc[ITEMS] = {c4.x, c4.y, c4.z, c4.w};
-            float a[ITEMS], hh[ITEMS], bu[ITEMS], cg[ITEMS];
-            const float An_n = An[n];
-            const float A2 = An_n * LOG2E;
-            // ---- recompute h inside the chunk (same arithmetic as the forward)
-            float A = 1.f, Bv = 0.f;
-#pragma unroll
-            for (int i = 0; i < ITEMS; ++i) {
-#ifndef SCAN_ABL_NO_EXP
-              a[i] = __builtin_amdgcn_exp2f(dt[i] * A2);
-#else
-              a[i] = fmaf(dt[i], A2, 1.f);
-#endif
-              bu[i] = dtu[i] * bb[i];
-              cg[i] = cc[i] * g[i];
-              Bv = fmaf(a[i], Bv, bu[i]);
-              A *= a[i];
-            }
-            wave_scan_prefix(A, Bv);
-            const float EA = prev_lane(1.f, A), EB = prev_lane(0.f, Bv);
-            const float h0 = (c == 0) ? 0.f : hs[j];
-            const float hin = fmaf(EA, h0, EB);  // h_{t-1} of this lane's first step
-            float hp = hin;
-#pragma unroll
-            for (int i = 0; i < ITEMS; ++i) { hp = fmaf(a[i], hp, bu[i]); hh[i] = hp; }
-            // ---- dL/dh suffix scan:  gh_i = cc_i*g_i + a_{i+1} * gh_{i+1}
-            // a of the next lane's first step; the chunk's last step takes `carry` (= a*gh of the next chunk) with factor 1
-            float al[ITEMS];
-#pragma unroll
-            for (int i = 0; i < ITEMS - 1; ++i) al[i] = a[i + 1];
-            al[ITEMS - 1] = next_lane(1.f, a[0]);
-            float SA = 1.f, SB = 0.f;
-#pragma unroll
-            for (int i = ITEMS - 1; i >= 0; --i) { SB = fmaf(al[i], SB, cg[i]); SA *= al[i]; }
-            wave_scan_suffix(SA, SB, addr1, addr2);
-            const float XA = next_lane(1.f, SA), XB = next_lane(0.f, SB);
-            float gh = fmaf(XA, carry[n], XB);  // gh of the step right after this lane's last one (already times its a)
-            float dA_n = 0.f;
-#pragma unroll
-            for (int i = ITEMS - 1; i >= 0; --i) {
-              gh = fmaf(al[i], gh, cg[i]);  // dL/dh_t
-              const float hprev = (i == 0) ? hin : hh[i - 1];
-              const float da = gh * hprev * a[i];  // dL/d(dt*A) through a = exp(dt*A)
-              dA_n = fmaf(da, dt[i], dA_n);
-              ddt[i] = fmaf(da, An_n, ddt[i]);
-              ddt[i] = fmaf(gh * uu[i], bb[i], ddt[i]);
-              du[i] = fmaf(gh * dt[i], bb[i], du[i]);
-              accB[j][i] = fmaf(gh, dtu[i], accB[j][i]);
-              accC[j][i] = fmaf(g[i], hh[i], accC[j][i]);
-            }
-            if (lane == 0) carry[n] = a[0] * gh;  // a_t * gh_t of this chunk's first step, for the previous chunk
-#ifndef SCAN_ABL_NO_DA
-            dA_n = wave_sum_dpp(dA_n);
-            if (lane == WAVE - 1) s_dA[wave][r][n] += dA_n;
-#else
-            if (dA_n == 123.456f) s_dA[wave][r][n] += dA_n;
-#endif
-          }
-          STAMP(3)  // 3: the STG states of the row
-          if (!last) {
-#ifndef SCAN_ABL_NO_STORE
-            store4<VEC>(gu + row * L, t, L, du, rev);
-            store4<VEC>(gdelta + row * L, t, L, ddt, rev);
-#else
-            if (du[0] == 123.456f && ddt[1] == 654.321f) store4<VEC>(gu + row * L, t, L, du, rev);
-#endif
-          } else {
-            float gd[ITEMS];
-            float dD = 0.f, dbs = 0.f;
-#pragma unroll
-            for (int i = 0; i < ITEMS; ++i) {
-              gd[i] = (t + i < L) ? ddt[i] * sigmoid_f(dl[i] + bias) : 0.f;
-              dbs += gd[i];
-              dD = fmaf(g[i], uu[i], dD);
-            }
-            dD = wave_sum_dpp(dD);
-            dbs = wave_sum_dpp(dbs);
-            if (lane == WAVE - 1) { s_dD[wave][r] += dD; s_db[wave][r] += dbs; }
-#ifdef SCAN_ABL_NO_GW
-            if (false)
-#endif
-            if (dtr) {  // gWdt[kd, q] += sum_t gdelta_t * dtr[q, t]
-              float* gWr = s_gW + (wave * BWD_RPW + r) * RMAX;
-              for (int q = 0; q < R; ++q) {
-                const float4 f = *reinterpret_cast<const float4*>(&s_dtr[q][lane * ITEMS]);
-                const float p = wave_sum_dpp(fmaf(gd[0], f.x, fmaf(gd[1], f.y, fmaf(gd[2], f.z, gd[3] * f.w))));
-                if (lane == WAVE - 1) gWr[q] += p;
-              }
-            }
-            store4<VEC>(gu + row * L, t, L, du, rev);  // gu is always [B, K*Dk, L]; the host folds direction pairs in xmode
-            store4<VEC>(gdelta + row * L, t, L, gd, rev);
-          }
+        for (int i = 0; i < ITEMS; ++i) {
+          dt[i] = (t + i < L) ? softplus_f(dl[i] + bias) : 0.f;  // steps beyond L: the identity map, and no gradient
+          dtu[i] = dt[i] * uu[i];
         }
       }
-#ifdef SCAN_ABL_NO_FOLD
-      if (accB[0][0] == 123.456f || accC[STG - 1][ITEMS - 1] == 123.456f) s_dD[wave][0] += accB[1][1] + accC[2][2];
-      continue;
-#endif
-      STAMP(4)  // 4: row epilogue (stores; last group: gate of d(delta), dD, gW sums) - accumulated with the loop tail
-      // ---- fold the BWD_WAVES register tiles of this state group into the LDS tile, one wave at a time (plain LDS traffic, no
-      // atomics).  The tile aliases the B/C tiles: rows [n0, n0 + STG) of both are dead once every wave is past this group.
-      __syncthreads();
-#pragma unroll 1
-      for (int w = 0; w < BWD_WAVES; ++w) {
-        if (wave == w) {
+      float dAv[NS];
+      // a_t * dL/dh_t entering from the next chunk, lane n holds state n's; the new one is assembled lane by lane (v_writelane).
+      // No branch inside the loop over the states: with the unrolled states in ONE basic block the scheduling fences bound every
+      // state's live ranges (across blocks LLVM sinks the accumulator updates to the end of the row and spills their operands).
+      const float cry = s_carry[wr * NS + (lane & (NS - 1))];
+      float ncry = 0.f;
 #pragma unroll
-          for (int j = 0; j < STG; ++j) {
-            float4* pb = reinterpret_cast<float4*>(&s_dB[n0 + j][lane * ITEMS]);
-            float4* pc = reinterpret_cast<float4*>(&s_dC[n0 + j][lane * ITEMS]);
-            float4 vb = make_float4(accB[j][0], accB[j][1], accB[j][2], accB[j][3]);
-            float4 vc = make_float4(accC[j][0], accC[j][1], accC[j][2], accC[j][3]);
-            if (w > 0) {
-              const float4 ob = *pb, oc = *pc;
-              vb.x += ob.x; vb.y += ob.y; vb.z += ob.z; vb.w += ob.w;
-              vc.x += oc.x; vc.y += oc.y; vc.z += oc.z; vc.w += oc.w;
-            }
-            *pb = vb;
-            *pc = vc;
-          }
+      for (int n = 0; n < NS; ++n) {
+        const float4 b4 = *reinterpret_cast<const float4*>(&sB[n][lane * ITEMS]);
+        const float4 c4 = *reinterpret_cast<const float4*>(&sC[n][lane * ITEMS]);
+        const float bb[ITEMS] = {b4.x, b4.y, b4.z, b4.w}, cc[ITEMS] = {c4.x, c4.y, c4.z, c4.w};
+        float a[ITEMS], hh[ITEMS], bu[ITEMS], cg[ITEMS];
+        const float An_n = rdlane(par, n), h0 = rdlane(par, 32 + n);
+        const float A2 = An_n * LOG2E;
+        // ---- h inside the chunk (same arithmetic as the forward) and the in-lane part of the dL/dh recurrence
+        //      gh_i = cc_i g_i + a_{i+1} gh_{i+1}
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+          a[i] = __builtin_amdgcn_exp2f(dt[i] * A2);
+          bu[i] = dtu[i] * bb[i];
+          cg[i] = cc[i] * g[i];
         }
-        __syncthreads();
+        float A = a[0], Bv = bu[0];
+#pragma unroll
+        for (int i = 1; i < ITEMS; ++i) { Bv = fmaf(a[i], Bv, bu[i]); A *= a[i]; }
+        // a of the next lane's first step; the chunk's last step takes `carry` (= a * gh of the next chunk) with factor 1
+        const float alast = next_lane(1.f, a[0]);
+        float SA = alast, SB = cg[ITEMS - 1];
+#pragma unroll
+        for (int i = ITEMS - 2; i >= 0; --i) { SB = fmaf(a[i + 1], SB, cg[i]); SA *= a[i + 1]; }
+        fused_scans(A, Bv, SA, SB);
+        {  // cross-row levels of the suffix scan: the three row totals (lanes 16, 32, 48) as scalars, composed and selected by row
+          const float a1 = rdlane(SA, 16), b1 = rdlane(SB, 16), a2 = rdlane(SA, 32), b2 = rdlane(SB, 32), a3 = rdlane(SA, 48), b3 = rdlane(SB, 48);
+          const float a23 = a2 * a3, b23 = fmaf(a2, b3, b2);
+          const float a123 = a1 * a23, b123 = fmaf(a1, b23, b1);
+          const float pa = rowi == 0 ? a123 : rowi == 1 ? a23 : rowi == 2 ? a3 : 1.f;
+          const float pb = rowi == 0 ? b123 : rowi == 1 ? b23 : rowi == 2 ? b3 : 0.f;
+          SB = fmaf(SA, pb, SB);
+          SA *= pa;
+        }
+        const float EA = prev_lane(1.f, A), EB = prev_lane(0.f, Bv);
+        const float hin = fmaf(EA, h0, EB);  // h_{t-1} of this lane's first step
+        hh[0] = fmaf(a[0], hin, bu[0]);
+#pragma unroll
+        for (int i = 1; i < ITEMS; ++i) hh[i] = fmaf(a[i], hh[i - 1], bu[i]);
+        const float XA = next_lane(1.f, SA), XB = next_lane(0.f, SB);
+        float gh = fmaf(XA, rdlane(cry, n), XB);  // gh of the step right after this lane's last one (already times its a)
+        float dA_n = 0.f;
+#pragma unroll
+        for (int i = ITEMS - 1; i >= 0; --i) {
+          gh = fmaf(i == ITEMS - 1 ? alast : a[i + 1], gh, cg[i]);  // dL/dh_t
+          const float da = gh * (i == 0 ? hin : hh[i - 1]) * a[i];   // dL/d(dt*A) through a = exp(dt*A)
+          dA_n = fmaf(da, dt[i], dA_n);
+          ddtA[i] = fmaf(da, An_n, ddtA[i]);
+          S[i] = fmaf(gh, bb[i], S[i]);
+          accB[n][i] = fmaf(gh, dtu[i], accB[n][i]);
+          accC[n][i] = fmaf(g[i], hh[i], accC[n][i]);
+        }
+        // a_t * gh_t of this chunk's first step (lane 0), for the previous chunk
+        write_lane(ncry, rdlane(a[0] * gh, 0), n);
+        dAv[n] = dA_n;
+        // the state's updates happen HERE (the asm makes the accumulators opaque at this point), and nothing crosses the fence:
+        // one state's temporaries at a time (register budget: 2 waves per SIMD)
+        asm volatile("" : "+v"(accB[n][0]), "+v"(accB[n][1]), "+v"(accB[n][2]), "+v"(accB[n][3]), "+v"(accC[n][0]), "+v"(accC[n][1]),
+                          "+v"(accC[n][2]), "+v"(accC[n][3]));
+        asm volatile("" : "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(ddtA[0]), "+v"(ddtA[1]), "+v"(ddtA[2]), "+v"(ddtA[3]),
+                          "+v"(dAv[n]), "+v"(ncry));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (lane < NS) s_carry[wr * NS + lane] = ncry;
+      // ---- after the states: du = D gy + dt S;  d(dt) = sum_n da_n A_n + u S;  d(delta) = d(dt) * sigmoid(delta + bias)
+      float du[ITEMS], gd[ITEMS], dD = 0.f, dbs = 0.f;
+#pragma unroll
+      for (int i = 0; i < ITEMS; ++i) {
+        du[i] = fmaf(dt[i], S[i], Dd * g[i]);
+        const float ddt = fmaf(uu[i], S[i], ddtA[i]);
+        // sigmoid(x) = 1 - exp(-softplus(x)); for x < -10 (dt = e^x < 4.6e-5) the difference cancels and sigmoid(x) = dt to 5e-5
+        const float sg = dt[i] < 4.6e-5f ? dt[i] : 1.f - __builtin_amdgcn_exp2f(-dt[i] * LOG2E);
+        gd[i] = ddt * sg;  // dt = 0 beyond L, hence gd = 0 there
+        dbs += gd[i];
+        dD = fmaf(g[i], uu[i], dD);
+      }
+      store4<VEC>(gu + row * L, t, L, du, rev);  // gu is always [B, K*Dk, L]; the host folds direction pairs in xmode
+      store4<VEC>(gdelta + row * L, t, L, gd, rev);
+      // ---- per-row sums over the chunk's steps: dD and d(bias) by plain wave sums; the 16 dA_n and the rank-R d(Wdt) factors
+      // (gWdt[kd, q] += sum_t gdelta_t * dtr[q, t]) by reduce-scatter, 16 values per set
+      float* acc = s_acc + wr * ACC;
+      const int slot = (lane >> 2) & 15;
+      const bool writer = (lane & 3) == 0;
+      dD = wave_sum_dpp(dD);
+      dbs = wave_sum_dpp(dbs);
+      if (lane == WAVE - 1) { acc[62] += dD; acc[63] += dbs; }
+      if (dtr) {
+        float m[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float4 f = *reinterpret_cast<const float4*>(&s_dtr[min(j, R - 1)][lane * ITEMS]);
+          m[j] = j < R ? fmaf(gd[0], f.x, fmaf(gd[1], f.y, fmaf(gd[2], f.z, gd[3] * f.w))) : 0.f;
+        }
+        reduce16x2(dAv, m);
+        if (writer) { acc[slot] += dAv[0]; acc[16 + slot] += m[0]; }
+        if (R > 16) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const float4 f = *reinterpret_cast<const float4*>(&s_dtr[min(16 + j, R - 1)][lane * ITEMS]);
+            m[j] = 16 + j < R ? fmaf(gd[0], f.x, fmaf(gd[1], f.y, fmaf(gd[2], f.z, gd[3] * f.w))) : 0.f;
+          }
+          reduce16(m);
+          if (writer) acc[32 + slot] += m[0];
+        }
+      } else {
+        reduce16(dAv);
+        if (writer) acc[slot] += dAv[0];
       }
     }
-    STAMP(5)  // 5: folds of the register tiles (barriers included)
+    // ---- fold the BWD_WAVES register tiles into the LDS tile, one wave at a time (plain LDS traffic, no atomics).  The tile
+    // aliases the B/C tiles, which are dead once every wave is past its rows.
+    float(*s_dB)[CHUNK] = sB;
+    float(*s_dC)[CHUNK] = sC;
+    __syncthreads();
+#pragma unroll 1
+    for (int w = 0; w < BWD_WAVES; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+          float4* pb = reinterpret_cast<float4*>(&s_dB[n][lane * ITEMS]);
+          float4* pc = reinterpret_cast<float4*>(&s_dC[n][lane * ITEMS]);
+          float4 vb = make_float4(accB[n][0], accB[n][1], accB[n][2], accB[n][3]);
+          float4 vc = make_float4(accC[n][0], accC[n][1], accC[n][2], accC[n][3]);
+          if (w > 0) {
+            const float4 ob = *pb, oc = *pc;
+            vb.x += ob.x; vb.y += ob.y; vb.z += ob.z; vb.w += ob.w;
+            vc.x += oc.x; vc.y += oc.y; vc.z += oc.z; vc.w += oc.w;
+          }
+          *pb = vb;
+          *pc = vc;
+        }
+      }
+      __syncthreads();
+    }
     // ---- plain, coalesced stores of this workgroup's partial dB/dC tile into its slab
     if (VEC) {
       for (int i = threadIdx.x; i < NS * CHUNK / 4; i += BWD_WAVES * WAVE) {
@@ -648,21 +717,15 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, (STG <= 4 ? 2 : 1)) void selscan_b
         if (tg < L) { slabB[(size_t)n * L + pos] = s_dB[n][i % CHUNK]; slabC[(size_t)n * L + pos] = s_dC[n][i % CHUNK]; }
       }
     }
-    STAMP(6)  // 6: slab stores
   }
-#ifdef SCAN_STAMP
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-    for (int i = 0; i < 8; ++i) gu[i] = (float)(st_acc[i] >> 6);  // units of 64 ticks
-  }
-#endif
-#pragma unroll
   for (int r = 0; r < BWD_RPW; ++r) {
-    const int d = d0 + r;
+    const int d = d0 + r, wr = wave * BWD_RPW + r;
     if (d < Dk) {
       const int kd = k * Dk + d;
-      if (lane < NS) atomicAdd(gA + (size_t)kd * NS + lane, s_dA[wave][r][lane]);  // summed over the batch only: no contention
-      if (lane == 0) { atomicAdd(gD + kd, s_dD[wave][r]); atomicAdd(gdbias + kd, s_db[wave][r]); }
-      if (dtr && lane < R) atomicAdd(gWdt + (size_t)kd * R + lane, s_gW[(wave * BWD_RPW + r) * RMAX + lane]);
+      const float* acc = s_acc + wr * ACC;
+      if (lane < NS) atomicAdd(gA + (size_t)kd * NS + lane, acc[lane]);  // summed over the batch only: no contention
+      if (lane == 0) { atomicAdd(gD + kd, acc[62]); atomicAdd(gdbias + kd, acc[63]); }
+      if (dtr && lane < R) atomicAdd(gWdt + (size_t)kd * R + lane, acc[16 + lane]);
     }
   }
 }
@@ -823,15 +886,11 @@ static int scan_bwd_launch(const float* gy, const float* u, const float* delta, 
   float* wsC = ws + (size_t)nslab * slab;
   dim3 grid(nslab, B * K);
   hipStream_t s = (hipStream_t)stream;
-  size_t dyn = dtr ? ((size_t)R * CHUNK + 2 * BWD_ROWS * RMAX) * sizeof(float) : 0;
-  // static LDS of the kernel: B/C tiles + per-row state (A, carry, dA, dD, db); two workgroups per CU need <= 80 KB each
-  const size_t stat = (size_t)(2 * NS * CHUNK + 3 * BWD_ROWS * NS + 2 * BWD_ROWS) * sizeof(float);
-  const size_t h0_bytes = (size_t)BWD_ROWS * NS * sizeof(float);
-  const int h0_staged = stat + dyn + h0_bytes <= 80 * 1024;
-  if (h0_staged) dyn += h0_bytes;
-#define LAUNCH_BWD(VEC)                                                                                                              \
-  hipLaunchKernelGGL((selscan_bwd_kernel<VEC, SCAN_BWD_STG>), grid, dim3(BWD_WAVES * WAVE), dyn, s, gy, u, delta, A, Bm, Cm, D, dbias, \
-                     hstate, gu, gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab, xmode, dtr, Wdt, gWdt, R, h0_staged)
+  // B/C tiles | rank-R dt factors | Wdt rows | per-row sums | carry: 78 KB at rank 32, two workgroups per CU
+  const size_t dyn = ((size_t)2 * NS * CHUNK + (size_t)R * CHUNK + (size_t)BWD_ROWS * (RMAX + ACC + NS)) * sizeof(float);
+#define LAUNCH_BWD(VEC)                                                                                                         \
+  hipLaunchKernelGGL((selscan_bwd_kernel<VEC>), grid, dim3(BWD_WAVES * WAVE), dyn, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu, \
+                     gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab, xmode, dtr, Wdt, gWdt, R)
   if (L % 4 == 0) LAUNCH_BWD(true); else LAUNCH_BWD(false);
 #undef LAUNCH_BWD
   if (dtr && L % 4) {
