@@ -6,19 +6,24 @@
 //     dt = softplus(delta + dbias);  h_t = exp(dt_t A_n) h_{t-1} + dt_t B_{n,t} u_t;  y_t = sum_n C_{n,t} h_{n,t} + D u_t
 //
 // Mapping (wave64): ONE WAVE PER ROW (b, k*Dk+d); lanes run along TIME, 4 consecutive steps per lane, so a wave eats
-// a CHUNK of 256 steps per iteration with perfectly coalesced 16-B/lane loads of u, delta (and gy) and stores of y.
+// a CHUNK of 256 steps per iteration with perfectly coalesced 16-B/lane loads of u (and gy) and stores of y.
 // Inside a chunk the linear recurrence is an associative scan on affine maps h -> a*h + b: 3 sequential steps inside
-// the lane, then a 6-level scan across the 64 lanes done with DPP row shifts / row broadcasts (VALU-rate cross-lane
-// moves, no LDS round trip), then the carry h_n (wave-uniform) of the previous chunk is folded in.  The 16 states are
-// looped; the y dot product stays inside the lane.  Chunk-boundary states are written out for the backward pass, which
-// walks the chunks in reverse, recomputes h inside the chunk and runs the mirrored (suffix) scan for dL/dh.
+// the lane, then a 6-level scan across the 64 lanes with DPP row shifts / row broadcasts (VALU-rate cross-lane moves, no
+// LDS round trip), then the carry h_n (wave-uniform) of the previous chunk is folded in.  The 16 states are looped; the
+// y dot product stays inside the lane.  Chunk-boundary states are written out for the backward pass, which walks the
+// chunks in reverse, recomputes h inside the chunk and runs the mirrored (suffix) scan for dL/dh.
 // B/C (and dB/dC) are shared by the Dk rows of a (b, k) group: a workgroup holds rows of ONE group and stages the chunk's
-// B/C tiles once in LDS.  In the backward every wave walks BWD_RPW rows per chunk (per group of STG states) and sums their
-// dB/dC contributions in REGISTERS; the waves then fold their register tiles into one LDS tile in turns, and the workgroup plain-stores it to
-// its slab of a workspace that a second kernel sums.  What was measured on the way (MI355X, level 0 = 16x1024 rows x
-// 25600 steps): float atomics straight into gB/gC ran at the contended-atomic rate (79 ms); an LDS tile fed by
-// ds_add_f32 from 8 waves was no better (81 ms, 64 of them in the LDS atomics); shuffles through ds_bpermute made both
-// passes instruction-bound (~2000 instructions per wave-chunk, 500 of them in log1pf/expf range handling).
+// B/C tiles once in LDS.
+//
+// What the instruction stream looks like matters as much as its length here (both kernels are VALU-issue bound, one
+// instruction per ~4 cycles per wave):
+//   * no load sits under a branch: hipcc waits vmcnt(0) at the end of every conditional block that holds a load, which
+//     turned the "prefetches" of the first version into synchronous round trips (in-kernel stamps: 22 % of the backward in
+//     the row prologue, 10 % in the tile staging).  Addresses are clamped and results selected instead;
+//   * hipcc never folds a DPP move into a float multiply or fma (it does for adds), so the scans are inline asm with
+//     v_fmac_f32_dpp / v_mul_f32_dpp, two independent chains interleaved so that no DPP hazard nop is needed;
+//   * per-row scalars (A, D, bias, chunk-entry / carried states) travel in ONE VGPR each (lane n holds entry n) and are
+//     read per state with v_readlane, new carries are assembled with v_writelane: no LDS round trips, no branches.
 #include "common.h"
 
 namespace {
@@ -27,61 +32,73 @@ constexpr int NS = 16;         // d_state
 constexpr int ITEMS = 4;       // time steps per lane
 constexpr int CHUNK = WAVE * ITEMS;
 constexpr int FWD_ROWS = 8;    // waves (= rows of one (b,k) group) per workgroup, forward
+constexpr int FWD_RPW = 4;     // rows per wave and chunk, forward (they share the staged tiles)
 constexpr int BWD_WAVES = 4;   // waves per workgroup, backward
-constexpr int BWD_RPW = 8;     // rows handled one after the other by each wave per chunk
-constexpr int BWD_ROWS = BWD_WAVES * BWD_RPW;  // rows of one (b,k) group per workgroup = one dB/dC slab
-constexpr float LOG2E = 1.4426950408889634f;
-// Backward kernel: states per group (STG; register tile of dB/dC = 2 x STG x ITEMS).  Measured on MI355X with
-// tools/bench_kernels.py scan at the three MEH levels (backward ms at level 0 / 1 / 2 = dt rank 8 / 16 / 32):
-//   STG 4, 2 waves/SIMD (207 VGPR)      18.8 / 10.5 / 7.3        STG 8 (256 VGPR + 256 B scratch)   23.1 / 12.0 / 7.6
-//   STG 2 (149 VGPR)                    26.4 / 14.5 / 10.0       STG 16, 1 wave/SIMD (501 VGPR+AGPR, 636 v_accvgpr moves)  - / - / 8.7
-// (STG 16 is the single-group kernel of the first version: 39.5 ms per training step over the three levels, now 36.6.)
-// Small groups repeat the row's delta projection (R FMAs x 4 per group); large ones spill the tile to AGPRs / scratch.
-#ifndef SCAN_BWD_STG
-#define SCAN_BWD_STG 4
+#ifndef SCAN_BWD_RPW
+#define SCAN_BWD_RPW 8
 #endif
+constexpr int BWD_RPW = SCAN_BWD_RPW;  // rows handled one after the other by each wave per chunk
+constexpr int BWD_ROWS = BWD_WAVES * BWD_RPW;  // rows of one (b,k) group per workgroup = one dB/dC slab
+constexpr int RMAX = 32;       // largest dt rank built (d_model 512 / 16)
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
 
 // softplus with torch's threshold (20); log(1+e^x) through the hardware exp2/log2 (abs err ~1e-7, the e^x branch keeps
 // the relative accuracy for very negative x where 1 + e^x rounds to 1)
 __device__ __forceinline__ float softplus_f(float x) {
   const float e = __builtin_amdgcn_exp2f(x * LOG2E);
-  const float sp = __builtin_amdgcn_logf(1.f + e) * 0.6931471805599453f;
+  const float sp = __builtin_amdgcn_logf(1.f + e) * LN2;
   return x > 20.f ? x : (x < -10.f ? e : sp);
 }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __builtin_amdgcn_exp2f(-x * LOG2E)); }
 
 // scan step t lives at memory position t (rev = false) or L-1-t (rev = true: the two reversed scan directions of the
-// cross-scan read and write the SAME buffers as the forward ones, back to front - still 16-B coalesced, descending)
-template <bool VEC>
-__device__ __forceinline__ void load4(const float* __restrict__ p, int t, int L, float (&o)[ITEMS], float fill, bool rev = false) {
-  if (VEC) {
-    if (t < L) {  // L % 4 == 0 and t % 4 == 0: all-or-nothing
-      if (!rev) {
-        const float4 v = *reinterpret_cast<const float4*>(p + t);
-        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-      } else {
-        const float4 v = *reinterpret_cast<const float4*>(p + (L - 4 - t));
-        o[0] = v.w; o[1] = v.z; o[2] = v.y; o[3] = v.x;
-      }
-    } else {
-      o[0] = o[1] = o[2] = o[3] = fill;
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) o[i] = (t + i < L) ? p[rev ? L - 1 - t - i : t + i] : fill;
-  }
+// cross-scan read and write the SAME buffers as the forward ones, back to front - still 16-B coalesced, descending).
+// Row streams go through raw buffer loads / stores with the row as the buffer (base = the row's wave-uniform pointer,
+// num_records = 4 L): a lane past the end of the row gets zeros / stores nothing by the hardware's range check, so neither
+// a branch nor a select surrounds the memory instruction - hipcc can then count them (a store under `if (t < L)` makes it wait
+// vmcnt(0) for the loads issued before it).  Two halves, so that a request can be issued a whole row before its use:
+// `load4_issue` only loads, `load4_take` puts the four values into step order where they are consumed.
+struct Raw4 { float v[ITEMS]; };
+constexpr unsigned OOB = 0x7ffffff0u;  // byte offset no row reaches: the access is dropped by the range check
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float* rowp, int L) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rowp), 0, L * 4, 0x00020000);
 }
 template <bool VEC>
-__device__ __forceinline__ void store4(float* __restrict__ p, int t, int L, const float (&v)[ITEMS], bool rev = false) {
-  if (VEC) {
-    if (t < L) {
-      if (!rev) *reinterpret_cast<float4*>(p + t) = make_float4(v[0], v[1], v[2], v[3]);
-      else *reinterpret_cast<float4*>(p + (L - 4 - t)) = make_float4(v[3], v[2], v[1], v[0]);
-    }
+__device__ __forceinline__ Raw4 load4_issue(const float* __restrict__ rowp, int t, int L, bool rev) {
+  const __amdgpu_buffer_rsrc_t rs = row_rsrc(rowp, L);
+  Raw4 r;
+  if (VEC) {  // L % 4 == 0 and t % 4 == 0: all-or-nothing
+    // (the builtin's 128-bit result type is whatever this clang gives it: moved by memcpy, not converted - a conversion to a
+    // 4 x u32 vector type compiled to a ONE-dword load splat over the four elements)
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, t < L ? (rev ? L - 4 - t : t) * 4 : OOB, 0, 0);
+    static_assert(sizeof(v) == sizeof(r.v), "128-bit buffer load");
+    __builtin_memcpy(r.v, &v, sizeof(r.v));
   } else {
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i)
-      if (t + i < L) p[rev ? L - 1 - t - i : t + i] = v[i];
+      r.v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t + i < L ? (rev ? L - 1 - t - i : t + i) * 4 : OOB, 0, 0));
+  }
+  return r;
+}
+template <bool VEC>
+__device__ __forceinline__ void load4_take(const Raw4& r, float (&o)[ITEMS], bool rev) {
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) o[i] = VEC ? (rev ? r.v[ITEMS - 1 - i] : r.v[i]) : r.v[i];
+}
+template <bool VEC>
+__device__ __forceinline__ void store4(float* __restrict__ rowp, int t, int L, const float (&v)[ITEMS], bool rev) {
+  const __amdgpu_buffer_rsrc_t rs = row_rsrc(rowp, L);
+  if (VEC) {
+    float o[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) o[i] = rev ? v[ITEMS - 1 - i] : v[i];
+    decltype(__builtin_amdgcn_raw_buffer_load_b128(rs, 0, 0, 0)) w;
+    __builtin_memcpy(&w, o, sizeof(o));
+    __builtin_amdgcn_raw_buffer_store_b128(w, rs, t < L ? (rev ? L - 4 - t : t) * 4 : OOB, 0, 0);
+  } else {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rs, t + i < L ? (rev ? L - 1 - t - i : t + i) * 4 : OOB, 0, 0);
   }
 }
 
@@ -91,116 +108,149 @@ __device__ __forceinline__ float dpp(float old, float src) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL,
                                                                ROWMASK, 0xf, false));
 }
-#define SCAN_STEP(CTRL, RM)                                              \
-  {                                                                      \
-    const float pa = dpp<CTRL, RM>(1.f, A), pb = dpp<CTRL, RM>(0.f, Bv); \
-    Bv = fmaf(A, pb, Bv);                                                \
-    A *= pa;                                                             \
-  }
-// inclusive prefix scan over the 64 lanes of the affine maps h -> A*h + B (earlier map applied first):
-// row_shr 1,2,4,8 inside the 16-lane rows, then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3
-__device__ __forceinline__ void wave_scan_prefix(float& A, float& Bv) {
-  SCAN_STEP(0x111, 0xf) SCAN_STEP(0x112, 0xf) SCAN_STEP(0x114, 0xf) SCAN_STEP(0x118, 0xf)
-  SCAN_STEP(0x142, 0xa) SCAN_STEP(0x143, 0xc)
-}
 // value of the previous lane (lane 0 keeps `old`): wave_shr:1
 __device__ __forceinline__ float prev_lane(float old, float v) { return dpp<0x138, 0xf>(old, v); }
 // value of the next lane (lane 63 keeps `old`): wave_shl:1
 __device__ __forceinline__ float next_lane(float old, float v) { return dpp<0x130, 0xf>(old, v); }
-
-// inclusive suffix scan g -> A*g + B (later map applied first): row_shl 1,2,4,8 inside the rows; the two cross-row
-// levels fetch the composite held by the FIRST lane of row r+1 / r+2 with ds_bpermute (there is no "broadcast to the
-// previous row" DPP mode).  addr1/addr2: byte addresses of those lanes, or -1 when the row does not exist.
-#ifndef SCAN_SUFFIX_READLANE
-#define SCAN_SUFFIX_READLANE 1
-#endif
 __device__ __forceinline__ float rdlane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
-__device__ __forceinline__ void wave_scan_suffix(float& A, float& Bv, int addr1, int addr2) {
-  SCAN_STEP(0x101, 0xf) SCAN_STEP(0x102, 0xf) SCAN_STEP(0x104, 0xf) SCAN_STEP(0x108, 0xf)
-#ifdef SCAN_ABL_NO_BPERMUTE
-  return;
-#endif
-#if SCAN_SUFFIX_READLANE
-  // cross-row levels without LDS: only the three row totals T1, T2, T3 (held by lanes 16, 32, 48) matter; they are read into
-  // scalars, composed (wave-uniform) and selected by row.  (ds_bpermute put two dependent LDS round trips into every state.)
-  const float a1 = rdlane(A, 16), b1 = rdlane(Bv, 16), a2 = rdlane(A, 32), b2 = rdlane(Bv, 32), a3 = rdlane(A, 48), b3 = rdlane(Bv, 48);
-  const float a23 = a2 * a3, b23 = fmaf(a2, b3, b2);          // T2 o T3
-  const float a123 = a1 * a23, b123 = fmaf(a1, b23, b1);      // T1 o T2 o T3
-  const int row = addr1 < 0 ? 3 : (addr2 < 0 ? 2 : (addr1 == 128 ? 1 : 0));
-  const float pa = row == 0 ? a123 : row == 1 ? a23 : row == 2 ? a3 : 1.f;
-  const float pb = row == 0 ? b123 : row == 1 ? b23 : row == 2 ? b3 : 0.f;
-  Bv = fmaf(A, pb, Bv);
-  A *= pa;
-#else
+// v[lane n] = s (n < 16; the lane select is an inline constant: a second SGPR would exceed the constant bus of a gfx9 VALU op)
+template <int N>
+__device__ __forceinline__ void write_lane_c(float& v, float s) { asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(N)); }
+__device__ __forceinline__ void write_lane(float& v, float s, int n) {  // n is a constant after unrolling: the switch folds
+  switch (n) {
+#define WL(N) case N: write_lane_c<N>(v, s); break;
+    WL(0) WL(1) WL(2) WL(3) WL(4) WL(5) WL(6) WL(7) WL(8) WL(9) WL(10) WL(11) WL(12) WL(13) WL(14) WL(15)
+#undef WL
+  }
+}
+
+// sum over the 64 lanes, valid in lane 63 (row_shr 1,2,4,8 + row_bcast 15,31; hipcc folds these DPP moves into the adds)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp<0x111, 0xf>(0.f, v); v += dpp<0x112, 0xf>(0.f, v); v += dpp<0x114, 0xf>(0.f, v); v += dpp<0x118, 0xf>(0.f, v);
+  v += dpp<0x142, 0xa>(0.f, v); v += dpp<0x143, 0xc>(0.f, v);
+  return v;
+}
+
+// ---- fused DPP scan steps.  (A, B) <- one level of the inclusive scan of the affine maps h -> A*h + B:
+//      B += A * B[src lane];  A *= A[src lane];  lanes without a source keep their values (DPP write disable).
+// Inside a statement every DPP read is at least two instructions behind the write of its source register (the gfx9
+// VALU-write -> DPP-read hazard); the s_nop at both ends covers the compiler's instructions around the statement, which it
+// cannot see into.
+#define LVL(b, a, c) "v_fmac_f32_dpp %" #b ", %" #b ", %" #a " " c "\n\tv_mul_f32_dpp %" #a ", %" #a ", %" #a " " c "\n\t"
+#define FULL "row_mask:0xf bank_mask:0xf"
+// two independent inclusive PREFIX scans over the 64 lanes (earlier map applied first): row_shr 1,2,4,8, row_bcast 15 / 31
+__device__ __forceinline__ void prefix_scan_x2(float& A0, float& B0, float& A1, float& B1) {
+  asm volatile("s_nop 1\n\t"
+               LVL(1, 0, "row_shr:1 " FULL) LVL(3, 2, "row_shr:1 " FULL) LVL(1, 0, "row_shr:2 " FULL) LVL(3, 2, "row_shr:2 " FULL)
+               LVL(1, 0, "row_shr:4 " FULL) LVL(3, 2, "row_shr:4 " FULL) LVL(1, 0, "row_shr:8 " FULL) LVL(3, 2, "row_shr:8 " FULL)
+               LVL(1, 0, "row_bcast:15 row_mask:0xa bank_mask:0xf") LVL(3, 2, "row_bcast:15 row_mask:0xa bank_mask:0xf")
+               LVL(1, 0, "row_bcast:31 row_mask:0xc bank_mask:0xf") LVL(3, 2, "row_bcast:31 row_mask:0xc bank_mask:0xf")
+               "s_nop 1"
+               : "+v"(A0), "+v"(B0), "+v"(A1), "+v"(B1));
+}
+// (pA, pB): inclusive PREFIX scan over the wave; (sA, sB): the four in-row levels (row_shl 1,2,4,8) of the inclusive SUFFIX scan
+// (later map applied first) - its two cross-row levels have no DPP mode and are done by the caller
+__device__ __forceinline__ void prefix_and_row_suffix_scan(float& pA, float& pB, float& sA, float& sB) {
+  asm volatile("s_nop 1\n\t"
+               LVL(1, 0, "row_shr:1 " FULL) LVL(3, 2, "row_shl:1 " FULL) LVL(1, 0, "row_shr:2 " FULL) LVL(3, 2, "row_shl:2 " FULL)
+               LVL(1, 0, "row_shr:4 " FULL) LVL(3, 2, "row_shl:4 " FULL) LVL(1, 0, "row_shr:8 " FULL) LVL(3, 2, "row_shl:8 " FULL)
+               LVL(1, 0, "row_bcast:15 row_mask:0xa bank_mask:0xf") "s_nop 0\n\t"
+               LVL(1, 0, "row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
+               : "+v"(pA), "+v"(pB), "+v"(sA), "+v"(sB));
+}
+#undef LVL
+#undef FULL
+
+// ---- sums over the 64 lanes of two sets of 16 per-lane values at once: a reduce-scatter - every step halves both the number
+// of values a lane carries and the group of lanes that share them - instead of 32 separate 6-level reductions:
+//   lane bit 5: v_permlane32_swap of (value j, value j+8), the lower half keeps j, the upper half j+8          16 -> 8
+//   lane bit 4: v_permlane16_swap of (j, j+4), even 16-lane rows keep j, odd rows j+4                          8 -> 4
+//   lane bit 3 / bit 2: two DPP adds with complementary bank masks per kept value (row_shl / row_shr by 8 / 4)  4 -> 2 -> 1
+//   lane bits 1, 0: butterfly over the quad.
+// On return lane l holds in x[0] / y[0] the total of value (l >> 2) & 15 of its set (the four lanes of a quad agree).
+__device__ __forceinline__ float f_of(unsigned v) { return __builtin_bit_cast(float, v); }
+__device__ __forceinline__ unsigned u_of(float v) { return __builtin_bit_cast(unsigned, v); }
+#define DA(d, s, c) "v_add_f32_dpp %" #d ", %" #s ", %" #s " " c "\n\t"
+// first step for one pair of values: the lower half-wave ends up with a + (a from lane + 32), the upper with b + (b from lane - 32)
+__device__ __forceinline__ float pair_sum32(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(u_of(a), u_of(b), false, false);
+  return f_of(r[0]) + f_of(r[1]);
+}
+// the remaining steps on x[j] = pair_sum32(value j, value j + 8), j < 8 (callers do the first step as the values appear,
+// so that at most 8 + 8 registers are alive)
+__device__ __forceinline__ void reduce8x2(float (&x)[8], float (&y)[8]) {
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int ad = s ? addr2 : addr1;
-    float pa = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(ad, __builtin_bit_cast(int, A)));
-    float pb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(ad, __builtin_bit_cast(int, Bv)));
-    if (ad < 0) { pa = 1.f; pb = 0.f; }
-    Bv = fmaf(A, pb, Bv);
-    A *= pa;
+  for (int j = 0; j < 4; ++j) {
+    const auto rx = __builtin_amdgcn_permlane16_swap(u_of(x[j]), u_of(x[j + 4]), false, false);
+    const auto ry = __builtin_amdgcn_permlane16_swap(u_of(y[j]), u_of(y[j + 4]), false, false);
+    x[j] = f_of(rx[0]) + f_of(rx[1]);
+    y[j] = f_of(ry[0]) + f_of(ry[1]);
   }
-#endif
+  asm volatile("s_nop 1\n\t"
+               DA(0, 0, "row_shl:8 row_mask:0xf bank_mask:0x3") DA(4, 4, "row_shl:8 row_mask:0xf bank_mask:0x3")
+               DA(1, 1, "row_shl:8 row_mask:0xf bank_mask:0x3") DA(5, 5, "row_shl:8 row_mask:0xf bank_mask:0x3")
+               DA(0, 2, "row_shr:8 row_mask:0xf bank_mask:0xc") DA(4, 6, "row_shr:8 row_mask:0xf bank_mask:0xc")
+               DA(1, 3, "row_shr:8 row_mask:0xf bank_mask:0xc") DA(5, 7, "row_shr:8 row_mask:0xf bank_mask:0xc")
+               DA(0, 0, "row_shl:4 row_mask:0xf bank_mask:0x5") DA(4, 4, "row_shl:4 row_mask:0xf bank_mask:0x5")
+               DA(0, 1, "row_shr:4 row_mask:0xf bank_mask:0xa") DA(4, 5, "row_shr:4 row_mask:0xf bank_mask:0xa")
+               "s_nop 0\n\t"
+               DA(0, 0, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") DA(4, 4, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+               "s_nop 0\n\t"
+               DA(0, 0, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf") DA(4, 4, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+               "s_nop 1"
+               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
 }
+#undef DA
 
-// cooperative load of the chunk's B and C tiles ([NS][CHUNK] each) into LDS, zero beyond L
-template <int THREADS>
-__device__ __forceinline__ void stage_bc(const float* __restrict__ Bp, const float* __restrict__ Cp, int t0, int L,
-                                         float (*sB)[CHUNK], float (*sC)[CHUNK], bool vec, bool rev) {
-  if (vec) {
-    for (int i = threadIdx.x; i < NS * CHUNK / 4; i += THREADS) {
-      const int n = i / (CHUNK / 4), tt = (i % (CHUNK / 4)) * 4;
-      float4 b = make_float4(0.f, 0.f, 0.f, 0.f), c = b;
-      if (t0 + tt < L) {
-        if (!rev) {
-          b = *reinterpret_cast<const float4*>(Bp + (size_t)n * L + t0 + tt);
-          c = *reinterpret_cast<const float4*>(Cp + (size_t)n * L + t0 + tt);
-        } else {
-          const float4 rb = *reinterpret_cast<const float4*>(Bp + (size_t)n * L + (L - 4 - t0 - tt));
-          const float4 rc = *reinterpret_cast<const float4*>(Cp + (size_t)n * L + (L - 4 - t0 - tt));
-          b = make_float4(rb.w, rb.z, rb.y, rb.x);
-          c = make_float4(rc.w, rc.z, rc.y, rc.x);
-        }
-      }
-      *reinterpret_cast<float4*>(&sB[n][tt]) = b;
-      *reinterpret_cast<float4*>(&sC[n][tt]) = c;
+// ---- cooperative load of `rows` time-indexed rows ([rows][L] in global memory) of the chunk starting at step t0 into LDS
+// ([rows][CHUNK], step order, zero beyond L).  PER float4s per thread are requested together and only then written: the
+// loads' latency is paid once per call, not once per float4.
+template <int THREADS, int PER>
+__device__ __forceinline__ void stage_rows_vec(const float* __restrict__ P, int rows, int t0, int L, float (*s)[CHUNK], bool rev, int tid) {
+  const int total = rows * (CHUNK / 4);
+  for (int base = 0; base < total; base += THREADS * PER) {
+    float4 v[PER];
+    int dst[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = base + j * THREADS + tid;
+      const int r = min(i, total - 1) / (CHUNK / 4), tt = (i % (CHUNK / 4)) * 4;
+      const bool ok = i < total && t0 + tt < L;
+      v[j] = *reinterpret_cast<const float4*>(P + (ok ? (size_t)r * L + (rev ? L - 4 - t0 - tt : t0 + tt) : 0));
+      if (!ok) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rev) v[j] = make_float4(v[j].w, v[j].z, v[j].y, v[j].x);
+      dst[j] = i < total ? r * CHUNK + tt : -1;
     }
-  } else {
-    for (int i = threadIdx.x; i < NS * CHUNK; i += THREADS) {
-      const int n = i / CHUNK, tt = i % CHUNK;
-      const bool ok = t0 + tt < L;
-      const int pos = rev ? L - 1 - t0 - tt : t0 + tt;
-      sB[n][tt] = ok ? Bp[(size_t)n * L + pos] : 0.f;
-      sC[n][tt] = ok ? Cp[(size_t)n * L + pos] : 0.f;
-    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+      if (dst[j] >= 0) *reinterpret_cast<float4*>(&s[0][0] + dst[j]) = v[j];
   }
 }
-
-constexpr int RMAX = 32;  // largest dt rank built (d_model 512 / 16)
-
-// dt low-rank factors of the chunk: s_dtr[r][tt] = dtr[r][pos(t0 + tt)], zero beyond L
 template <int THREADS>
-__device__ __forceinline__ void stage_dtr(const float* __restrict__ Rp, int R, int t0, int L, float (*s_dtr)[CHUNK], bool vec,
-                                          bool rev) {
-  if (vec) {
-    for (int i = threadIdx.x; i < R * CHUNK / 4; i += THREADS) {
-      const int r = i / (CHUNK / 4), tt = (i % (CHUNK / 4)) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t0 + tt < L) {
-        if (!rev) v = *reinterpret_cast<const float4*>(Rp + (size_t)r * L + t0 + tt);
-        else {
-          const float4 w = *reinterpret_cast<const float4*>(Rp + (size_t)r * L + (L - 4 - t0 - tt));
-          v = make_float4(w.w, w.z, w.y, w.x);
-        }
-      }
-      *reinterpret_cast<float4*>(&s_dtr[r][tt]) = v;
-    }
+__device__ __forceinline__ void stage_rows_scalar(const float* __restrict__ P, int rows, int t0, int L, float (*s)[CHUNK], bool rev, int tid) {
+  for (int i = tid; i < rows * CHUNK; i += THREADS) {  // L % 4 != 0: odd test shapes only
+    const int r = i / CHUNK, tt = i % CHUNK;
+    const bool ok = t0 + tt < L;
+    const float v = P[ok ? (size_t)r * L + (rev ? L - 1 - t0 - tt : t0 + tt) : 0];
+    s[r][tt] = ok ? v : 0.f;
+  }
+}
+template <int THREADS, bool VEC>
+__device__ __forceinline__ void stage_tiles(const float* __restrict__ Bp, const float* __restrict__ Cp, const float* __restrict__ Rp,
+                                            int R, int t0, int L, float (*sB)[CHUNK], float (*sC)[CHUNK], float (*s_dtr)[CHUNK], bool rev) {
+  // the thread index through an opaque copy: everything derived from it (source offsets, LDS addresses) is recomputed per call
+  // instead of being hoisted out of the chunk loop and held - or spilled - across the row loop
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  if (VEC) {
+    constexpr int PER = NS * (CHUNK / 4) / THREADS;  // 4 (256 threads) or 2 (512)
+    stage_rows_vec<THREADS, PER>(Bp, NS, t0, L, sB, rev, tid);
+    stage_rows_vec<THREADS, PER>(Cp, NS, t0, L, sC, rev, tid);
+    if (Rp) stage_rows_vec<THREADS, PER>(Rp, R, t0, L, s_dtr, rev, tid);
   } else {
-    for (int i = threadIdx.x; i < R * CHUNK; i += THREADS) {
-      const int r = i / CHUNK, tt = i % CHUNK;
-      s_dtr[r][tt] = (t0 + tt < L) ? Rp[(size_t)r * L + (rev ? L - 1 - t0 - tt : t0 + tt)] : 0.f;
-    }
+    stage_rows_scalar<THREADS>(Bp, NS, t0, L, sB, rev, tid);
+    stage_rows_scalar<THREADS>(Cp, NS, t0, L, sC, rev, tid);
+    if (Rp) stage_rows_scalar<THREADS>(Rp, R, t0, L, s_dtr, rev, tid);
   }
 }
 
@@ -228,20 +278,11 @@ __device__ __forceinline__ void dtproj_row(const float* __restrict__ Wrow, const
   }
 }
 
-// sum over the 64 lanes, valid in lane 63 (row_shr 1,2,4,8 + row_bcast 15,31: no LDS round trip)
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  v += dpp<0x111, 0xf>(0.f, v); v += dpp<0x112, 0xf>(0.f, v); v += dpp<0x114, 0xf>(0.f, v); v += dpp<0x118, 0xf>(0.f, v);
-  v += dpp<0x142, 0xa>(0.f, v); v += dpp<0x143, 0xc>(0.f, v);
-  return v;
-}
-
-// Forward: FWD_ROWS waves x FWD_RPW rows each = rows of ONE (b, k) group per workgroup; the chunk's B/C/dt tiles are staged once
-// for all of them.
-#ifndef SCAN_FWD_RPW
-#define SCAN_FWD_RPW 4   // measured fwd ms (level 0 / 1 / 2): 1 row per wave 3.87 / 2.00 / 1.22, 2 rows 3.71 / 1.85 / 1.13, 4 rows 3.67 / 1.78 / 1.03
-#endif
-constexpr int FWD_RPW = SCAN_FWD_RPW;
-template <bool VEC>
+// ------------------------------------------------------------------------------------------------ forward
+// FWD_ROWS waves x FWD_RPW rows each = rows of ONE (b, k) group per workgroup.  Per row and chunk the 16 states are walked in
+// PAIRS: the two prefix scans of a pair are independent and interleave in one fused-DPP statement.  Row constants (A * log2 e,
+// D, bias) and the carried state h live in two LDS words per lane-slot that a row reads into one VGPR each at its start.
+template <bool VEC, bool DTR>  // DTR: fused dt projection (delta formed in-kernel from dtr and Wdt) vs a materialised delta
 __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float* __restrict__ u, const float* __restrict__ delta,
                                                                       const float* __restrict__ Am, const float* __restrict__ Bm,
                                                                       const float* __restrict__ Cm, const float* __restrict__ Dv,
@@ -249,86 +290,104 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
                                                                       float* __restrict__ hstate, int K, int Dk, int L, int nchunk,
                                                                       int xmode, const float* __restrict__ dtr,
                                                                       const float* __restrict__ Wdt, int R) {
-  __shared__ float sB[NS][CHUNK];
-  __shared__ float sC[NS][CHUNK];
-  __shared__ float s_A[FWD_ROWS][FWD_RPW][NS], s_h[FWD_ROWS][FWD_RPW][NS];  // wave-private per-state values (A*log2e, carried h)
-  __shared__ float s_rc[FWD_ROWS][FWD_RPW][2];                               // D and delta bias of the wave's rows
-  extern __shared__ float s_dyn[];  // fused dt projection: [R][CHUNK] factors + [FWD_ROWS * FWD_RPW][RMAX] rows of Wdt
-  float(*s_dtr)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(s_dyn);
-  float* s_W = s_dyn + (size_t)R * CHUNK;
-  const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // B tile | C tile | dt factors | Wdt rows | row constants | carried h
+  float(*sB)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(smem);
+  float(*sC)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(smem + NS * CHUNK);
+  float(*s_dtr)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(smem + 2 * NS * CHUNK);
+  float* s_W = smem + 2 * NS * CHUNK + (size_t)R * CHUNK;  // [FWD_ROWS * FWD_RPW][RMAX]
+  float* s_par = s_W + FWD_ROWS * FWD_RPW * RMAX;          // [FWD_ROWS * FWD_RPW][32]: A * log2(e) | D | bias
+  float* s_h = s_par + FWD_ROWS * FWD_RPW * 32;            // [FWD_ROWS * FWD_RPW][NS]
+  // (wave index as a provably uniform value: row pointers then live in SGPRs and the loads take SGPR base + lane offset)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
   const int d0 = (blockIdx.x * FWD_ROWS + wave) * FWD_RPW;
-  const int bk = blockIdx.y, k = bk % K;
+  const int bk = blockIdx.y, k = bk % K, b = bk / K;
   // cross-scan layout (xmode): u is [B, 2, Dk, L] (k & 1 picks the row-major / column-major copy) and directions k >= 2
   // walk every time-indexed buffer back to front
   const bool rev = xmode && k >= 2;
   const float* Bp = Bm + (size_t)bk * NS * L;
   const float* Cp = Cm + (size_t)bk * NS * L;
-#pragma unroll
+  const float* Rp = DTR ? dtr + (size_t)bk * R * L : nullptr;
   for (int r = 0; r < FWD_RPW; ++r) {
+    const int wr = wave * FWD_RPW + r;
     const int kd = k * Dk + min(d0 + r, Dk - 1);
-    if (lane < NS) { s_A[wave][r][lane] = Am[(size_t)kd * NS + lane] * LOG2E; s_h[wave][r][lane] = 0.f; }
-    if (lane == 0) { s_rc[wave][r][0] = Dv[kd]; s_rc[wave][r][1] = dbias[kd]; }
-    if (dtr && lane < R) s_W[(wave * FWD_RPW + r) * RMAX + lane] = Wdt[(size_t)kd * R + lane];
+    if (lane < 32) s_par[wr * 32 + lane] = lane < NS ? Am[(size_t)kd * NS + lane] * LOG2E : lane == 16 ? Dv[kd] : lane == 17 ? dbias[kd] : 0.f;
+    if (lane < NS) s_h[wr * NS + lane] = 0.f;
+    if (DTR && lane < RMAX) s_W[wr * RMAX + lane] = lane < R ? Wdt[(size_t)kd * R + lane] : 0.f;
   }
-  const float* Rp = dtr ? dtr + (size_t)bk * R * L : nullptr;
+  const int nrow = min(FWD_RPW, Dk - d0);  // rows this wave really has (<= 0: none)
+  // row d's operand rows (d clamped: a row past the end is loaded like the last one and never used)
+  auto urow = [&](int d) { d = min(d, Dk - 1); return xmode ? u + (((size_t)b * 2 + (k & 1)) * Dk + d) * L : u + (((size_t)b * K + k) * Dk + d) * L; };
+  auto drow = [&](int d) { return delta + (((size_t)b * K + k) * Dk + min(d, Dk - 1)) * L; };
 
   for (int c = 0; c < nchunk; ++c) {
-    __syncthreads();  // previous chunk's tile fully consumed
-    stage_bc<FWD_ROWS * WAVE>(Bp, Cp, c * CHUNK, L, sB, sC, VEC, rev);
-    if (dtr) stage_dtr<FWD_ROWS * WAVE>(Rp, R, c * CHUNK, L, s_dtr, VEC, rev);
-    __syncthreads();
+    __syncthreads();  // previous chunk's tiles fully consumed
     const int t = c * CHUNK + lane * ITEMS;
+    // first row's streams: requested before the staging, consumed after it
+    Raw4 n_uu = load4_issue<VEC>(urow(d0), t, L, rev), n_dl = n_uu;
+    if (!DTR) n_dl = load4_issue<VEC>(drow(d0), t, L, rev);
+    stage_tiles<FWD_ROWS * WAVE, VEC>(Bp, Cp, Rp, R, c * CHUNK, L, sB, sC, s_dtr, rev);
+    __syncthreads();
 #pragma unroll 1
-    for (int r = 0; r < FWD_RPW; ++r) {
-      const int d = d0 + r;
-      if (d >= Dk) break;  // wave-uniform
-      const int kd = k * Dk + d;
-      const size_t row = (size_t)(bk / K) * K * Dk + kd;
-      const float* up = xmode ? u + (((size_t)(bk / K) * 2 + (k & 1)) * Dk + d) * L : u + row * L;
-      const float* An = s_A[wave][r];
-      float* h = s_h[wave][r];
-      const float Dd = s_rc[wave][r][0], bias = s_rc[wave][r][1];
+    for (int r = 0; r < nrow; ++r) {
+      const int d = d0 + r, wr = wave * FWD_RPW + r;
+      const size_t row = ((size_t)b * K + k) * Dk + d;
       float uu[ITEMS], dt[ITEMS], dtu[ITEMS], yy[ITEMS];
-      load4<VEC>(up, t, L, uu, 0.f, rev);
-      if (dtr) {  // delta_t = <Wdt[kd, :], dtr[:, t]>: the [B, 4*d_inner, L] delta tensor of the reference is never materialised
-        dt[0] = dt[1] = dt[2] = dt[3] = 0.f;
-        dtproj_row(s_W + (wave * FWD_RPW + r) * RMAX, s_dtr, R, lane, dt);
-      } else {
-        load4<VEC>(delta + row * L, t, L, dt, 0.f, rev);
-      }
+      load4_take<VEC>(n_uu, uu, rev);
+      load4_take<VEC>(n_dl, dt, rev);
+      if (DTR) dt[0] = dt[1] = dt[2] = dt[3] = 0.f;
+      n_uu = load4_issue<VEC>(urow(d + 1), t, L, rev);  // next row's streams, in flight behind this row's arithmetic
+      if (!DTR) n_dl = load4_issue<VEC>(drow(d + 1), t, L, rev);
+      const float par = s_par[wr * 32 + (lane & 31)];
+      const float hc = s_h[wr * NS + (lane & (NS - 1))];  // state entering the chunk, lane n holds state n
+      float nh = 0.f;
+      // delta_t = <Wdt[kd, :], dtr[:, t]>: the [B, 4*d_inner, L] delta tensor of the reference is never materialised
+      if (DTR) dtproj_row(s_W + wr * RMAX, s_dtr, R, lane, dt);
+      const float Dd = rdlane(par, 16), bias = rdlane(par, 17);
 #pragma unroll
       for (int i = 0; i < ITEMS; ++i) {
-        dt[i] = (t + i < L) ? softplus_f(dt[i] + bias) : 0.f;  // steps beyond L become the identity map (a = 1, b = 0)
+        dt[i] = softplus_f((t + i < L) ? dt[i] + bias : -1e30f);  // steps beyond L become the identity map (dt = 0: a = 1, b = 0)
         dtu[i] = dt[i] * uu[i];
         yy[i] = Dd * uu[i];
       }
-#pragma unroll 4
-      for (int n = 0; n < NS; ++n) {
-        const float4 b4 = *reinterpret_cast<const float4*>(&sB[n][lane * ITEMS]);
-        const float4 c4 = *reinterpret_cast<const float4*>(&sC[n][lane * ITEMS]);
-        float bb[ITEMS] = {b4.x, b4.y, b4.z, b4.w}, cc[ITEMS] = {c4.x, c4.y, c4.z, c4.w}, a[ITEMS];
-        const float An_n = An[n];
-        float A = 1.f, Bv = 0.f;
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-          a[i] = __builtin_amdgcn_exp2f(dt[i] * An_n);
-          bb[i] *= dtu[i];
-          Bv = fmaf(a[i], Bv, bb[i]);
-          A *= a[i];
-        }
-        wave_scan_prefix(A, Bv);
-        const float EA = prev_lane(1.f, A), EB = prev_lane(0.f, Bv);
-        float hh = fmaf(EA, h[n], EB);  // state entering this lane's first step
+      for (int n = 0; n < NS; n += 2) {
+        float a[2][ITEMS], bb[2][ITEMS], cc[2][ITEMS], A[2], Bv[2];
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-          hh = fmaf(a[i], hh, bb[i]);
-          yy[i] = fmaf(cc[i], hh, yy[i]);
+        for (int j = 0; j < 2; ++j) {
+          const float4 b4 = *reinterpret_cast<const float4*>(&sB[n + j][lane * ITEMS]);
+          const float4 c4 = *reinterpret_cast<const float4*>(&sC[n + j][lane * ITEMS]);
+          const float A2 = rdlane(par, n + j);
+          bb[j][0] = b4.x; bb[j][1] = b4.y; bb[j][2] = b4.z; bb[j][3] = b4.w;
+          cc[j][0] = c4.x; cc[j][1] = c4.y; cc[j][2] = c4.z; cc[j][3] = c4.w;
+#pragma unroll
+          for (int i = 0; i < ITEMS; ++i) {
+            a[j][i] = __builtin_amdgcn_exp2f(dt[i] * A2);
+            bb[j][i] *= dtu[i];
+          }
+          A[j] = a[j][0];
+          Bv[j] = bb[j][0];
+#pragma unroll
+          for (int i = 1; i < ITEMS; ++i) { Bv[j] = fmaf(a[j][i], Bv[j], bb[j][i]); A[j] *= a[j][i]; }
         }
-        if (lane == WAVE - 1) h[n] = hh;  // state after the chunk
+        prefix_scan_x2(A[0], Bv[0], A[1], Bv[1]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float EA = prev_lane(1.f, A[j]), EB = prev_lane(0.f, Bv[j]);
+          float hh = fmaf(EA, rdlane(hc, n + j), EB);  // state entering this lane's first step
+#pragma unroll
+          for (int i = 0; i < ITEMS; ++i) {
+            hh = fmaf(a[j][i], hh, bb[j][i]);
+            yy[i] = fmaf(cc[j][i], hh, yy[i]);
+          }
+          write_lane(nh, rdlane(hh, WAVE - 1), n + j);  // state after the chunk
+        }
+        asm volatile("" : "+v"(yy[0]), "+v"(yy[1]), "+v"(yy[2]), "+v"(yy[3]), "+v"(nh));
+        __builtin_amdgcn_sched_barrier(0);  // one pair's temporaries at a time
       }
       store4<VEC>(y + row * L, t, L, yy, rev);
-      if (lane < NS) hstate[(row * nchunk + c) * NS + lane] = h[lane];
+      if (lane < NS) s_h[wr * NS + lane] = nh;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, nh), row_rsrc(hstate + (row * nchunk + c) * NS, NS),
+                                            lane < NS ? lane * 4 : OOB, 0, 0);
     }
   }
 }
@@ -336,144 +395,71 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
 // ------------------------------------------------------------------------------------------------ backward
 // One pass per (row, chunk) over all 16 states.  The first version walked the states in groups of 4 (register tile of dB/dC =
 // 2 x 4 x ITEMS) and therefore repeated the row prologue (dt projection, softplus, u / gy loads) four times and carried the
-// per-row partial du / d(delta) sums between the groups through HBM (33 GB of traffic per level-0 launch, 16.5 ms, waves
-// parked half of their life in the prologue's load waits).  Here:
-//   * the dB/dC tile of ALL states stays in registers (2 x 16 x ITEMS = 128 VGPRs) across the BWD_RPW rows of a wave, the loop
-//     over the states is unrolled with scheduling fences between the states so that only one state's temporaries are live
-//     (~230 VGPRs: still two waves per SIMD);
+// per-row partial du / d(delta) sums between the groups through HBM (33 GB of traffic per level-0 launch, 16.5 ms).  Here:
+//   * the dB/dC tile of ALL states stays in registers (2 x 16 x ITEMS = 128 VGPRs) across the BWD_RPW rows of a wave; the loop
+//     over the states is unrolled, in ONE basic block, with scheduling fences between the states so that only one state's
+//     temporaries are live (256 VGPRs, two waves per SIMD).  (With a branch inside the loop LLVM sinks the accumulator updates
+//     to the end of the row and spills their operands: 400 VGPRs of scratch.)
 //   * sum_n gh_n B_n is accumulated once per step (S) and turned into du and the B-part of d(delta) after the states, instead of
 //     four FMAs per (state, step);
-//   * the next row's u / gy / parameters (A, D, bias, chunk-entry states: one VGPR, lane n holds entry n) are requested while the
-//     current row computes, so no load is waited for at its point of use;
-//   * the cross-lane scans use DPP-fused v_fmac / v_mul (inline asm: hipcc keeps a v_mov_b32_dpp in front of every float mul/fma),
-//     the prefix scan of h and the suffix scan of dL/dh interleaved so that no DPP hazard nop is needed between the levels;
-//   * the 16 per-state dA sums (and the rank-R d(Wdt) sums) of a row are reduced over the wave together: a reduce-scatter
-//     (16 -> 8 -> 4 values per lane while the lane groups halve) instead of 16 separate 6-level reductions.
-// per-row LDS accumulators, ACC floats per row: [0, 16) dA | [16, 16 + R) d(Wdt) | [62] dD, [63] d(bias)
+//   * the prefix scan of h and the in-row part of the suffix scan of dL/dh interleave in one fused-DPP statement;
+//   * the 16 per-state dA sums and the rank-R d(Wdt) sums of a row are reduced over the wave together by a reduce-scatter;
+//   * the four waves fold their register tiles into the LDS tile in parallel, each wave a different quarter of the states per round.
+// per-row LDS accumulators, ACC floats per row: [0, 16) dA | [16, 16 + R) d(Wdt) | [48] dD, [49] d(bias)
 constexpr int ACC = 64;
-
-// (pA, pB): inclusive PREFIX scan over the 64 lanes of the affine maps h -> A*h + B (row_shr 1,2,4,8, row_bcast 15 / 31);
-// (sA, sB): the four in-row levels (row_shl 1,2,4,8) of the inclusive SUFFIX scan.  One statement: inside it every DPP read is
-// at least two instructions behind the write of its source (the gfx9 VALU-write -> DPP-read hazard), the s_nop at both ends
-// covers the compiler's instructions around it (which it cannot see into).
-__device__ __forceinline__ void fused_scans(float& pA, float& pB, float& sA, float& sB) {
-#define P_LVL(c) "v_fmac_f32_dpp %1, %1, %0 " c "\n\tv_mul_f32_dpp %0, %0, %0 " c "\n\t"
-#define S_LVL(c) "v_fmac_f32_dpp %3, %3, %2 " c "\n\tv_mul_f32_dpp %2, %2, %2 " c "\n\t"
-  asm volatile("s_nop 1\n\t"
-               P_LVL("row_shr:1 row_mask:0xf bank_mask:0xf") S_LVL("row_shl:1 row_mask:0xf bank_mask:0xf")
-               P_LVL("row_shr:2 row_mask:0xf bank_mask:0xf") S_LVL("row_shl:2 row_mask:0xf bank_mask:0xf")
-               P_LVL("row_shr:4 row_mask:0xf bank_mask:0xf") S_LVL("row_shl:4 row_mask:0xf bank_mask:0xf")
-               P_LVL("row_shr:8 row_mask:0xf bank_mask:0xf") S_LVL("row_shl:8 row_mask:0xf bank_mask:0xf")
-               P_LVL("row_bcast:15 row_mask:0xa bank_mask:0xf") "s_nop 0\n\t"
-               P_LVL("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
-               : "+v"(pA), "+v"(pB), "+v"(sA), "+v"(sB));
-#undef P_LVL
-#undef S_LVL
-}
-
-// Sums over the 64 lanes of two sets of 16 per-lane values at once: a reduce-scatter - every step halves both the number of
-// values a lane carries and the group of lanes that share them - instead of 32 separate 6-level reductions:
-//   lane bit 5: v_permlane32_swap of (value j, value j+8), the lower half keeps j, the upper half j+8          16 -> 8
-//   lane bit 4: v_permlane16_swap of (j, j+4), even 16-lane rows keep j, odd rows j+4                          8 -> 4
-//   lane bit 3 / bit 2: two DPP adds with complementary bank masks per kept value (row_shl / row_shr by 8 / 4)  4 -> 2 -> 1
-//   lane bits 1, 0: butterfly over the quad.
-// On return lane l holds in x[0] / y[0] the total of value (l >> 2) & 15 of its set (the four lanes of a quad agree).
-__device__ __forceinline__ float f_of(unsigned v) { return __builtin_bit_cast(float, v); }
-__device__ __forceinline__ unsigned u_of(float v) { return __builtin_bit_cast(unsigned, v); }
-__device__ __forceinline__ void reduce16x2(float (&x)[16], float (&y)[16]) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const auto rx = __builtin_amdgcn_permlane32_swap(u_of(x[j]), u_of(x[j + 8]), false, false);
-    const auto ry = __builtin_amdgcn_permlane32_swap(u_of(y[j]), u_of(y[j + 8]), false, false);
-    x[j] = f_of(rx[0]) + f_of(rx[1]);
-    y[j] = f_of(ry[0]) + f_of(ry[1]);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const auto rx = __builtin_amdgcn_permlane16_swap(u_of(x[j]), u_of(x[j + 4]), false, false);
-    const auto ry = __builtin_amdgcn_permlane16_swap(u_of(y[j]), u_of(y[j + 4]), false, false);
-    x[j] = f_of(rx[0]) + f_of(rx[1]);
-    y[j] = f_of(ry[0]) + f_of(ry[1]);
-  }
-  // every DPP read below is at least two instructions behind the write of its source register
-#define DA(d, s, c) "v_add_f32_dpp %" #d ", %" #s ", %" #s " " c "\n\t"
-  asm volatile("s_nop 1\n\t"
-               DA(0, 0, "row_shl:8 row_mask:0xf bank_mask:0x3") DA(4, 4, "row_shl:8 row_mask:0xf bank_mask:0x3")
-               DA(1, 1, "row_shl:8 row_mask:0xf bank_mask:0x3") DA(5, 5, "row_shl:8 row_mask:0xf bank_mask:0x3")
-               DA(0, 2, "row_shr:8 row_mask:0xf bank_mask:0xc") DA(4, 6, "row_shr:8 row_mask:0xf bank_mask:0xc")
-               DA(1, 3, "row_shr:8 row_mask:0xf bank_mask:0xc") DA(5, 7, "row_shr:8 row_mask:0xf bank_mask:0xc")
-               DA(0, 0, "row_shl:4 row_mask:0xf bank_mask:0x5") DA(4, 4, "row_shl:4 row_mask:0xf bank_mask:0x5")
-               DA(0, 1, "row_shr:4 row_mask:0xf bank_mask:0xa") DA(4, 5, "row_shr:4 row_mask:0xf bank_mask:0xa")
-               "s_nop 0\n\t"
-               DA(0, 0, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") DA(4, 4, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-               "s_nop 0\n\t"
-               DA(0, 0, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf") DA(4, 4, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-               "s_nop 1"
-               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
-#undef DA
-}
-
-// v[lane n] = s (n < 16; the lane select is an inline constant: a second SGPR would exceed the constant bus of a gfx9 VALU op)
-template <int N>
-__device__ __forceinline__ void write_lane_c(float& v, float s) { asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(N)); }
-__device__ __forceinline__ void write_lane(float& v, float s, int n) {  // n is a constant after unrolling: the switch folds
-  switch (n) {
-#define WL(N) case N: write_lane_c<N>(v, s); break;
-    WL(0) WL(1) WL(2) WL(3) WL(4) WL(5) WL(6) WL(7) WL(8) WL(9) WL(10) WL(11) WL(12) WL(13) WL(14) WL(15)
-#undef WL
-  }
-}
-
-// the same for one set (the DPP levels wait out their hazards with nops instead of a second set's instructions)
-__device__ __forceinline__ void reduce16(float (&x)[16]) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const auto rx = __builtin_amdgcn_permlane32_swap(u_of(x[j]), u_of(x[j + 8]), false, false);
-    x[j] = f_of(rx[0]) + f_of(rx[1]);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const auto rx = __builtin_amdgcn_permlane16_swap(u_of(x[j]), u_of(x[j + 4]), false, false);
-    x[j] = f_of(rx[0]) + f_of(rx[1]);
-  }
-#define DA(d, s, c) "v_add_f32_dpp %" #d ", %" #s ", %" #s " " c "\n\t"
-  asm volatile("s_nop 1\n\t"
-               DA(0, 0, "row_shl:8 row_mask:0xf bank_mask:0x3") DA(1, 1, "row_shl:8 row_mask:0xf bank_mask:0x3")
-               DA(0, 2, "row_shr:8 row_mask:0xf bank_mask:0xc") DA(1, 3, "row_shr:8 row_mask:0xf bank_mask:0xc")
-               "s_nop 0\n\t"
-               DA(0, 0, "row_shl:4 row_mask:0xf bank_mask:0x5") DA(0, 1, "row_shr:4 row_mask:0xf bank_mask:0xa")
-               "s_nop 1\n\t"
-               DA(0, 0, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-               "s_nop 1\n\t"
-               DA(0, 0, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-               "s_nop 1"
-               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
-#undef DA
-}
 
 // u, gy of one row for one chunk
 template <bool VEC>
 __device__ __forceinline__ void bwd_fetch_row(const float* __restrict__ u, const float* __restrict__ gy, int b, int K, int k, int Dk,
-                                              int d, int L, int t, bool rev, int xmode, float (&uu)[ITEMS], float (&g)[ITEMS]) {
+                                              int d, int L, int t, bool rev, int xmode, Raw4& uu, Raw4& g) {
   const size_t row = ((size_t)b * K + k) * Dk + d;
   const size_t prow = ((size_t)b * 2 + (k & 1)) * Dk + d;
-  load4<VEC>(xmode ? u + prow * L : u + row * L, t, L, uu, 0.f, rev);
-  load4<VEC>((xmode & 2) ? gy + prow * L : gy + row * L, t, L, g, 0.f, rev);
+  uu = load4_issue<VEC>(xmode ? u + prow * L : u + row * L, t, L, rev);
+  g = load4_issue<VEC>((xmode & 2) ? gy + prow * L : gy + row * L, t, L, rev);
 }
 // the row's small operands in ONE register: lane n < 16: A[kd][n]; lane 16: D[kd]; lane 17: delta bias; lanes 32..47: the
-// state entering chunk c (zero for c == 0).  Read back per state with v_readlane (wave-uniform operands of the VALU ops).
+// state entering chunk c (c > 0).  Read back per state with v_readlane (wave-uniform operands of the VALU ops).
 __device__ __forceinline__ float bwd_fetch_param(const float* __restrict__ Am, const float* __restrict__ Dv, const float* __restrict__ dbias,
                                                  const float* __restrict__ hstate, int kd, size_t row, int nchunk, int c, int lane) {
   const float* p = Am + (size_t)kd * NS + (lane & (NS - 1));
   if (lane == 16) p = Dv + kd;
   if (lane == 17) p = dbias + kd;
   if (lane >= 32 && lane < 48 && c > 0) p = hstate + (row * nchunk + (c - 1)) * NS + (lane - 32);
-  const float v = *p;
-  return (lane >= 32 && c == 0) ? 0.f : v;
+  return *p;  // (lanes 32..47 hold A again when c == 0: the reader substitutes zero)
 }
 
+// In-kernel phase timing (diagnostic build only: -DSCAN_STAMP through tools/build_scan_variant.sh; tools/scan_stamps.py reads the
+// sums that wave 0 of workgroup (0, 0) leaves in the first floats of gu): s_memtime deltas accumulated per phase.
+#ifdef SCAN_STAMP
+#define STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#define STAMP(i) { unsigned long long st_now; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory"); __builtin_amdgcn_sched_barrier(0); st_acc[i] += st_now - st_last; st_last = st_now; }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#endif
+
+// one wave's share of one fold round: states [4q, 4q + 4) of its register tile into the LDS tile (first round: plain stores).
+// All eight tile reads are issued before the first add: written as read-add-write per state they run as eight LDS round trips.
+#define FOLD_QUARTER(q, add)                                                                                          \
+  {                                                                                                                   \
+    float4 ob[4], oc[4];                                                                                              \
+    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                                \
+      ob[jj] = add ? *reinterpret_cast<const float4*>(&s_dB[4 * q + jj][lane * ITEMS]) : make_float4(0.f, 0.f, 0.f, 0.f); \
+      oc[jj] = add ? *reinterpret_cast<const float4*>(&s_dC[4 * q + jj][lane * ITEMS]) : make_float4(0.f, 0.f, 0.f, 0.f); \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                                \
+      ob[jj].x += accB[4 * q + jj][0]; ob[jj].y += accB[4 * q + jj][1]; ob[jj].z += accB[4 * q + jj][2]; ob[jj].w += accB[4 * q + jj][3]; \
+      oc[jj].x += accC[4 * q + jj][0]; oc[jj].y += accC[4 * q + jj][1]; oc[jj].z += accC[4 * q + jj][2]; oc[jj].w += accC[4 * q + jj][3]; \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                                \
+      *reinterpret_cast<float4*>(&s_dB[4 * q + jj][lane * ITEMS]) = ob[jj];                                           \
+      *reinterpret_cast<float4*>(&s_dC[4 * q + jj][lane * ITEMS]) = oc[jj];                                           \
+    }                                                                                                                 \
+  }
+
 // Backward: BWD_WAVES waves x BWD_RPW rows each = BWD_ROWS rows of one (b, k) group per workgroup.
-template <bool VEC>
+// SETS: 16-value sets of d(Wdt) factors per row (0: materialised delta, no dt projection; 1: rank <= 16; 2: rank <= 32)
+template <bool VEC, int SETS>
 __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
     const float* __restrict__ gy, const float* __restrict__ u, const float* __restrict__ delta, const float* __restrict__ Am,
     const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ Dv, const float* __restrict__ dbias,
@@ -481,7 +467,8 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
     float* __restrict__ wsB, float* __restrict__ wsC, float* __restrict__ gD, float* __restrict__ gdbias, int K, int Dk, int L,
     int nchunk, size_t slab_elems, int xmode, const float* __restrict__ dtr, const float* __restrict__ Wdt, float* __restrict__ gWdt,
     int R) {
-  // one dynamic LDS array: B tile | C tile (the dB/dC fold tile aliases them) | rank-R dt factors | Wdt rows | per-row sums
+  constexpr bool DTR = SETS > 0;
+  // one dynamic LDS array: B tile | C tile (the dB/dC fold tile aliases them) | rank-R dt factors | Wdt rows | per-row sums | carry
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float(*sB)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(smem);
   float(*sC)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(smem + NS * CHUNK);
@@ -489,7 +476,8 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
   float* s_W = smem + 2 * NS * CHUNK + (size_t)R * CHUNK;  // [BWD_ROWS][RMAX]
   float* s_acc = s_W + BWD_ROWS * RMAX;                    // [BWD_ROWS][ACC]    dA | d(Wdt) | dD, d(bias) sums
   float* s_carry = s_acc + BWD_ROWS * ACC;                 // [BWD_ROWS][NS]     a_t * dL/dh_t entering from the next chunk
-  const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane0 = threadIdx.x % WAVE;  // wave: provably uniform
+  int lane = lane0;
   const int bk = blockIdx.y, k = bk % K, b = bk / K;
   const float* Bp = Bm + (size_t)bk * NS * L;
   const float* Cp = Cm + (size_t)bk * NS * L;
@@ -497,33 +485,43 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
   float* slabC = wsC + (size_t)blockIdx.x * slab_elems + (size_t)bk * NS * L;
   const int d0 = blockIdx.x * BWD_ROWS + wave * BWD_RPW;
   const bool rev = xmode && k >= 2;
-  const int rowi = lane >> 4;
-  const int addr1 = rowi + 1 < 4 ? (rowi + 1) * 64 : -1;   // (suffix scan: which 16-lane rows follow this one)
-  const int addr2 = rowi + 2 < 4 ? (rowi + 2) * 64 : -1;
   for (int r = 0; r < BWD_RPW; ++r) {
     const int wr = wave * BWD_RPW + r;
     const int kd = k * Dk + min(d0 + r, Dk - 1);
     if (lane < NS) s_carry[wr * NS + lane] = 0.f;
     s_acc[wr * ACC + lane] = 0.f;
-    if (dtr && lane < RMAX) s_W[wr * RMAX + lane] = lane < R ? Wdt[(size_t)kd * R + lane] : 0.f;
+    if (DTR && lane < RMAX) s_W[wr * RMAX + lane] = lane < R ? Wdt[(size_t)kd * R + lane] : 0.f;
   }
-  const float* Rp = dtr ? dtr + (size_t)bk * R * L : nullptr;
+  const float* Rp = DTR ? dtr + (size_t)bk * R * L : nullptr;
   const int nrow = min(BWD_RPW, Dk - d0);  // rows this wave really has (<= 0: none)
+  const int dlast = Dk - 1;
 
+  STAMP_DECL
+#ifdef SCAN_STAMP
+  const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int c = nchunk - 1; c >= 0; --c) {
     __syncthreads();  // previous chunk's tiles fully consumed / flushed
-    const int t = c * CHUNK + lane * ITEMS;
-    // first row's streams: requested before the staging, consumed after it
-    float n_uu[ITEMS], n_g[ITEMS], n_par = 0.f;
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) n_uu[i] = n_g[i] = 0.f;
-    if (nrow > 0) {
-      bwd_fetch_row<VEC>(u, gy, b, K, k, Dk, d0, L, t, rev, xmode, n_uu, n_g);
-      n_par = bwd_fetch_param(Am, Dv, dbias, hstate, k * Dk + d0, ((size_t)b * K + k) * Dk + d0, nchunk, c, lane);
+    STAMP(0)  // 0: waiting at the chunk-top barrier
+    // (lane through an opaque copy at every level of the loop nest: per-lane addresses and predicates are cheap to rebuild, and
+    // hoisted out of the loops they do not fit next to the 128 accumulators - hipcc then spills them, and scratch reloads share
+    // vmcnt with the prefetches)
+    lane = lane0;
+    asm volatile("" : "+v"(lane));
+    int t = c * CHUNK + lane * ITEMS;
+    // first row's streams: requested before the staging, consumed after it (row index clamped: always issued, never under a branch)
+    Raw4 n_uu, n_g, n_dl;
+    float n_par;
+    {
+      const int dd = min(d0, dlast);
+      bwd_fetch_row<VEC>(u, gy, b, K, k, Dk, dd, L, t, rev, xmode, n_uu, n_g);
+      n_par = bwd_fetch_param(Am, Dv, dbias, hstate, k * Dk + dd, ((size_t)b * K + k) * Dk + dd, nchunk, c, lane);
+      n_dl = n_uu;
+      if (!DTR) n_dl = load4_issue<VEC>(delta + (((size_t)b * K + k) * Dk + dd) * L, t, L, rev);
     }
-    stage_bc<BWD_WAVES * WAVE>(Bp, Cp, c * CHUNK, L, sB, sC, VEC, rev);
-    if (dtr) stage_dtr<BWD_WAVES * WAVE>(Rp, R, c * CHUNK, L, s_dtr, VEC, rev);
+    stage_tiles<BWD_WAVES * WAVE, VEC>(Bp, Cp, Rp, R, c * CHUNK, L, sB, sC, s_dtr, rev);
     __syncthreads();
+    STAMP(1)  // 1: staging of the B/C/dt tiles + barrier
     float accB[NS][ITEMS], accC[NS][ITEMS];  // this wave's rows' dB/dC for the chunk, summed in registers
 #pragma unroll
     for (int n = 0; n < NS; ++n)
@@ -533,45 +531,52 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
 #pragma unroll 1
     for (int r = 0; r < nrow; ++r) {
       const int d = d0 + r, wr = wave * BWD_RPW + r;
-      const int kd = k * Dk + d;
       const size_t row = ((size_t)b * K + k) * Dk + d;
+      lane = lane0;
+      asm volatile("" : "+v"(lane));
+      t = c * CHUNK + lane * ITEMS;
+      const int rowi = lane >> 4;
       float uu[ITEMS], g[ITEMS], dt[ITEMS], dtu[ITEMS], S[ITEMS], ddtA[ITEMS];
       const float par = n_par;
-#pragma unroll
-      for (int i = 0; i < ITEMS; ++i) { uu[i] = n_uu[i]; g[i] = n_g[i]; S[i] = 0.f; ddtA[i] = 0.f; }
-      if (r + 1 < nrow) {  // next row's streams
-        bwd_fetch_row<VEC>(u, gy, b, K, k, Dk, d + 1, L, t, rev, xmode, n_uu, n_g);
-        n_par = bwd_fetch_param(Am, Dv, dbias, hstate, kd + 1, row + 1, nchunk, c, lane);
-      }
-      const float Dd = rdlane(par, 16), bias = rdlane(par, 17);
       {
         float dl[ITEMS];
-        if (dtr) {
-          dl[0] = dl[1] = dl[2] = dl[3] = 0.f;
-          dtproj_row(s_W + wr * RMAX, s_dtr, R, lane, dl);
-        } else {
-          load4<VEC>(delta + row * L, t, L, dl, 0.f, rev);
+        load4_take<VEC>(n_uu, uu, rev);
+        load4_take<VEC>(n_g, g, rev);
+        load4_take<VEC>(n_dl, dl, rev);
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) { S[i] = 0.f; ddtA[i] = 0.f; if (DTR) dl[i] = 0.f; }
+        {  // next row's streams, in flight behind this row's arithmetic
+          const int dn = min(d + 1, dlast);
+          bwd_fetch_row<VEC>(u, gy, b, K, k, Dk, dn, L, t, rev, xmode, n_uu, n_g);
+          n_par = bwd_fetch_param(Am, Dv, dbias, hstate, k * Dk + dn, ((size_t)b * K + k) * Dk + dn, nchunk, c, lane);
+          if (!DTR) n_dl = load4_issue<VEC>(delta + (((size_t)b * K + k) * Dk + dn) * L, t, L, rev);
         }
+        if (DTR) dtproj_row(s_W + wr * RMAX, s_dtr, R, lane, dl);
+        const float bias = rdlane(par, 17);
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
-          dt[i] = (t + i < L) ? softplus_f(dl[i] + bias) : 0.f;  // steps beyond L: the identity map, and no gradient
+          dt[i] = softplus_f((t + i < L) ? dl[i] + bias : -1e30f);  // steps beyond L: dt = 0, the identity map, and no gradient
           dtu[i] = dt[i] * uu[i];
         }
       }
-      float dAv[NS];
-      // a_t * dL/dh_t entering from the next chunk, lane n holds state n's; the new one is assembled lane by lane (v_writelane).
-      // No branch inside the loop over the states: with the unrolled states in ONE basic block the scheduling fences bound every
-      // state's live ranges (across blocks LLVM sinks the accumulator updates to the end of the row and spills their operands).
+      const float Dd = rdlane(par, 16);
+      const float par2 = par * LOG2E;  // lanes < 16: A * log2(e), the exponent scale of exp2; d(dt) below is summed in that scale
+      STAMP(2)  // 2: row prologue: next row's requests, dt projection, softplus
+      float dAv[8];  // dA_n + dA_{n+8} after the first reduction step (pair_sum32)
+      float4 nb4 = *reinterpret_cast<const float4*>(&sB[0][lane * ITEMS]), nc4 = *reinterpret_cast<const float4*>(&sC[0][lane * ITEMS]);
+      // a_t * dL/dh_t entering from the next chunk, lane n holds state n's; the new one is assembled lane by lane (v_writelane)
       const float cry = s_carry[wr * NS + (lane & (NS - 1))];
       float ncry = 0.f;
 #pragma unroll
       for (int n = 0; n < NS; ++n) {
-        const float4 b4 = *reinterpret_cast<const float4*>(&sB[n][lane * ITEMS]);
-        const float4 c4 = *reinterpret_cast<const float4*>(&sC[n][lane * ITEMS]);
+        const float4 b4 = nb4, c4 = nc4;  // requested one state ahead: at two waves per SIMD the LDS latency is not covered otherwise
+        if (n + 1 < NS) {
+          nb4 = *reinterpret_cast<const float4*>(&sB[n + 1][lane * ITEMS]);
+          nc4 = *reinterpret_cast<const float4*>(&sC[n + 1][lane * ITEMS]);
+        }
         const float bb[ITEMS] = {b4.x, b4.y, b4.z, b4.w}, cc[ITEMS] = {c4.x, c4.y, c4.z, c4.w};
         float a[ITEMS], hh[ITEMS], bu[ITEMS], cg[ITEMS];
-        const float An_n = rdlane(par, n), h0 = rdlane(par, 32 + n);
-        const float A2 = An_n * LOG2E;
+        const float A2 = rdlane(par2, n), h0 = c > 0 ? rdlane(par, 32 + n) : 0.f;  // A2 = A[kd][n] * log2(e); chunk 0 starts from h = 0
         // ---- h inside the chunk (same arithmetic as the forward) and the in-lane part of the dL/dh recurrence
         //      gh_i = cc_i g_i + a_{i+1} gh_{i+1}
 #pragma unroll
@@ -588,7 +593,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
         float SA = alast, SB = cg[ITEMS - 1];
 #pragma unroll
         for (int i = ITEMS - 2; i >= 0; --i) { SB = fmaf(a[i + 1], SB, cg[i]); SA *= a[i + 1]; }
-        fused_scans(A, Bv, SA, SB);
+        prefix_and_row_suffix_scan(A, Bv, SA, SB);
         {  // cross-row levels of the suffix scan: the three row totals (lanes 16, 32, 48) as scalars, composed and selected by row
           const float a1 = rdlane(SA, 16), b1 = rdlane(SB, 16), a2 = rdlane(SA, 32), b2 = rdlane(SB, 32), a3 = rdlane(SA, 48), b3 = rdlane(SB, 48);
           const float a23 = a2 * a3, b23 = fmaf(a2, b3, b2);
@@ -611,29 +616,29 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
           gh = fmaf(i == ITEMS - 1 ? alast : a[i + 1], gh, cg[i]);  // dL/dh_t
           const float da = gh * (i == 0 ? hin : hh[i - 1]) * a[i];   // dL/d(dt*A) through a = exp(dt*A)
           dA_n = fmaf(da, dt[i], dA_n);
-          ddtA[i] = fmaf(da, An_n, ddtA[i]);
+          ddtA[i] = fmaf(da, A2, ddtA[i]);   // (x log2(e): undone once per step after the states)
           S[i] = fmaf(gh, bb[i], S[i]);
           accB[n][i] = fmaf(gh, dtu[i], accB[n][i]);
           accC[n][i] = fmaf(g[i], hh[i], accC[n][i]);
         }
         // a_t * gh_t of this chunk's first step (lane 0), for the previous chunk
         write_lane(ncry, rdlane(a[0] * gh, 0), n);
-        dAv[n] = dA_n;
-        // the state's updates happen HERE (the asm makes the accumulators opaque at this point), and nothing crosses the fence:
-        // one state's temporaries at a time (register budget: 2 waves per SIMD)
+        if (n < 8) dAv[n] = dA_n; else dAv[n - 8] = pair_sum32(dAv[n - 8], dA_n);
+        // the state's updates happen HERE (the asm makes the accumulators opaque at this point), and nothing crosses the fence
         asm volatile("" : "+v"(accB[n][0]), "+v"(accB[n][1]), "+v"(accB[n][2]), "+v"(accB[n][3]), "+v"(accC[n][0]), "+v"(accC[n][1]),
                           "+v"(accC[n][2]), "+v"(accC[n][3]));
         asm volatile("" : "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(ddtA[0]), "+v"(ddtA[1]), "+v"(ddtA[2]), "+v"(ddtA[3]),
-                          "+v"(dAv[n]), "+v"(ncry));
+                          "+v"(dAv[n & 7]), "+v"(ncry));
         __builtin_amdgcn_sched_barrier(0);
       }
+      STAMP(3)  // 3: the 16 states
       if (lane < NS) s_carry[wr * NS + lane] = ncry;
       // ---- after the states: du = D gy + dt S;  d(dt) = sum_n da_n A_n + u S;  d(delta) = d(dt) * sigmoid(delta + bias)
       float du[ITEMS], gd[ITEMS], dD = 0.f, dbs = 0.f;
 #pragma unroll
       for (int i = 0; i < ITEMS; ++i) {
         du[i] = fmaf(dt[i], S[i], Dd * g[i]);
-        const float ddt = fmaf(uu[i], S[i], ddtA[i]);
+        const float ddt = fmaf(uu[i], S[i], ddtA[i] * LN2);
         // sigmoid(x) = 1 - exp(-softplus(x)); for x < -10 (dt = e^x < 4.6e-5) the difference cancels and sigmoid(x) = dt to 5e-5
         const float sg = dt[i] < 4.6e-5f ? dt[i] : 1.f - __builtin_amdgcn_exp2f(-dt[i] * LOG2E);
         gd[i] = ddt * sg;  // dt = 0 beyond L, hence gd = 0 there
@@ -642,65 +647,75 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
       }
       store4<VEC>(gu + row * L, t, L, du, rev);  // gu is always [B, K*Dk, L]; the host folds direction pairs in xmode
       store4<VEC>(gdelta + row * L, t, L, gd, rev);
-      // ---- per-row sums over the chunk's steps: dD and d(bias) by plain wave sums; the 16 dA_n and the rank-R d(Wdt) factors
-      // (gWdt[kd, q] += sum_t gdelta_t * dtr[q, t]) by reduce-scatter, 16 values per set
+      // ---- per-row sums over the chunk's steps by reduce-scatter, two sets of 16 values at a time: the 16 dA_n travel with the
+      // first 16 d(Wdt) factors (gWdt[kd, q] += sum_t gdelta_t * dtr[q, t]); at ranks > 16 the other factors with (dD, d(bias))
       float* acc = s_acc + wr * ACC;
       const int slot = (lane >> 2) & 15;
       const bool writer = (lane & 3) == 0;
-      dD = wave_sum_dpp(dD);
-      dbs = wave_sum_dpp(dbs);
-      if (lane == WAVE - 1) { acc[62] += dD; acc[63] += dbs; }
-      if (dtr) {
-        float m[16];
+      auto fac = [&](int q) -> float {  // (branch-free: a factor index past the rank reads row 0 and is replaced by zero)
+        const float4 f = *reinterpret_cast<const float4*>(&s_dtr[q < R ? q : 0][lane * ITEMS]);
+        const float v = fmaf(gd[0], f.x, fmaf(gd[1], f.y, fmaf(gd[2], f.z, gd[3] * f.w)));
+        return q < R ? v : 0.f;
+      };
+      float m[8];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const float4 f = *reinterpret_cast<const float4*>(&s_dtr[min(j, R - 1)][lane * ITEMS]);
-          m[j] = j < R ? fmaf(gd[0], f.x, fmaf(gd[1], f.y, fmaf(gd[2], f.z, gd[3] * f.w))) : 0.f;
+      for (int j = 0; j < 8; ++j) {
+        m[j] = SETS ? pair_sum32(fac(j), fac(j + 8)) : 0.f;
+        if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);  // 8 tile reads in flight at a time (unfenced: all 16, 64 registers)
+      }
+      reduce8x2(dAv, m);
+      if (writer) {
+        const float o0 = acc[slot], o1 = acc[16 + slot];
+        acc[slot] = o0 + dAv[0];
+        acc[16 + slot] = o1 + m[0];
+      }
+      if (SETS == 2) {
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          m[j] = pair_sum32(fac(16 + j), fac(24 + j));
+          e[j] = j == 0 ? pair_sum32(dD, 0.f) : j == 1 ? pair_sum32(dbs, 0.f) : 0.f;
+          if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
         }
-        reduce16x2(dAv, m);
-        if (writer) { acc[slot] += dAv[0]; acc[16 + slot] += m[0]; }
-        if (R > 16) {
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const float4 f = *reinterpret_cast<const float4*>(&s_dtr[min(16 + j, R - 1)][lane * ITEMS]);
-            m[j] = 16 + j < R ? fmaf(gd[0], f.x, fmaf(gd[1], f.y, fmaf(gd[2], f.z, gd[3] * f.w))) : 0.f;
-          }
-          reduce16(m);
-          if (writer) acc[32 + slot] += m[0];
+        reduce8x2(m, e);
+        if (writer) {
+          const float o0 = acc[32 + slot], o1 = acc[48 + slot];
+          acc[32 + slot] = o0 + m[0];
+          acc[48 + slot] = o1 + e[0];
         }
       } else {
-        reduce16(dAv);
-        if (writer) acc[slot] += dAv[0];
+        dD = wave_sum_dpp(dD);
+        dbs = wave_sum_dpp(dbs);
+        if (lane == WAVE - 1) {
+          const float o0 = acc[48], o1 = acc[49];
+          acc[48] = o0 + dD;
+          acc[49] = o1 + dbs;
+        }
       }
+      STAMP(4)  // 4: row epilogue: du / d(delta) stores, per-row sums
     }
-    // ---- fold the BWD_WAVES register tiles into the LDS tile, one wave at a time (plain LDS traffic, no atomics).  The tile
-    // aliases the B/C tiles, which are dead once every wave is past its rows.
+    // ---- fold the BWD_WAVES register tiles into the LDS tile (it aliases the B/C tiles, dead once every wave is past its rows):
+    // four rounds, in round j wave w handles the quarter (w + j) & 3 of the states, so the waves never touch the same rows
     float(*s_dB)[CHUNK] = sB;
     float(*s_dC)[CHUNK] = sC;
+    lane = lane0;
+    asm volatile("" : "+v"(lane));
     __syncthreads();
-#pragma unroll 1
-    for (int w = 0; w < BWD_WAVES; ++w) {
-      if (wave == w) {
 #pragma unroll
-        for (int n = 0; n < NS; ++n) {
-          float4* pb = reinterpret_cast<float4*>(&s_dB[n][lane * ITEMS]);
-          float4* pc = reinterpret_cast<float4*>(&s_dC[n][lane * ITEMS]);
-          float4 vb = make_float4(accB[n][0], accB[n][1], accB[n][2], accB[n][3]);
-          float4 vc = make_float4(accC[n][0], accC[n][1], accC[n][2], accC[n][3]);
-          if (w > 0) {
-            const float4 ob = *pb, oc = *pc;
-            vb.x += ob.x; vb.y += ob.y; vb.z += ob.z; vb.w += ob.w;
-            vc.x += oc.x; vc.y += oc.y; vc.z += oc.z; vc.w += oc.w;
-          }
-          *pb = vb;
-          *pc = vc;
-        }
+    for (int j = 0; j < BWD_WAVES; ++j) {
+      switch ((wave + j) & 3) {  // wave-uniform
+        case 0: if (j == 0) { FOLD_QUARTER(0, false) } else { FOLD_QUARTER(0, true) } break;
+        case 1: if (j == 0) { FOLD_QUARTER(1, false) } else { FOLD_QUARTER(1, true) } break;
+        case 2: if (j == 0) { FOLD_QUARTER(2, false) } else { FOLD_QUARTER(2, true) } break;
+        default: if (j == 0) { FOLD_QUARTER(3, false) } else { FOLD_QUARTER(3, true) } break;
       }
       __syncthreads();
     }
+    STAMP(5)  // 5: fold of the register tiles (barriers included)
     // ---- plain, coalesced stores of this workgroup's partial dB/dC tile into its slab
+    const int tid = wave * WAVE + lane;
     if (VEC) {
-      for (int i = threadIdx.x; i < NS * CHUNK / 4; i += BWD_WAVES * WAVE) {
+      for (int i = tid; i < NS * CHUNK / 4; i += BWD_WAVES * WAVE) {
         const int n = i / (CHUNK / 4), tt = (i % (CHUNK / 4)) * 4, tg = c * CHUNK + tt;
         if (tg < L) {
           float4 vb = *reinterpret_cast<const float4*>(&s_dB[n][tt]), vc = *reinterpret_cast<const float4*>(&s_dC[n][tt]);
@@ -711,21 +726,37 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
         }
       }
     } else {
-      for (int i = threadIdx.x; i < NS * CHUNK; i += BWD_WAVES * WAVE) {
+      for (int i = tid; i < NS * CHUNK; i += BWD_WAVES * WAVE) {
         const int n = i / CHUNK, tg = c * CHUNK + (i % CHUNK);
         const int pos = rev ? L - 1 - tg : tg;
         if (tg < L) { slabB[(size_t)n * L + pos] = s_dB[n][i % CHUNK]; slabC[(size_t)n * L + pos] = s_dC[n][i % CHUNK]; }
       }
     }
+    STAMP(6)  // 6: slab stores
   }
+  lane = lane0;
+#ifdef SCAN_STAMP
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    for (int i = 0; i < 8; ++i) gu[i] = (float)(st_acc[i] >> 6);  // units of 64 ticks
+  }
+  if (threadIdx.x == 0) {  // per workgroup: start / end on the 100 MHz real-time counter, XCC id
+    const unsigned long long wg_t1 = __builtin_amdgcn_s_memrealtime();
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    gu[16 + 4 * wg] = (float)(wg_t0 & 0xffffff);
+    gu[17 + 4 * wg] = (float)(wg_t1 & 0xffffff);
+    gu[18 + 4 * wg] = (float)(xcc & 0xf);
+  }
+#endif
   for (int r = 0; r < BWD_RPW; ++r) {
     const int d = d0 + r, wr = wave * BWD_RPW + r;
     if (d < Dk) {
       const int kd = k * Dk + d;
       const float* acc = s_acc + wr * ACC;
       if (lane < NS) atomicAdd(gA + (size_t)kd * NS + lane, acc[lane]);  // summed over the batch only: no contention
-      if (lane == 0) { atomicAdd(gD + kd, acc[62]); atomicAdd(gdbias + kd, acc[63]); }
-      if (dtr && lane < R) atomicAdd(gWdt + (size_t)kd * R + lane, acc[16 + lane]);
+      if (lane == 0) { atomicAdd(gD + kd, acc[48]); atomicAdd(gdbias + kd, acc[49]); }
+      if (DTR && lane < R) atomicAdd(gWdt + (size_t)kd * R + lane, acc[16 + lane]);
     }
   }
 }
@@ -823,13 +854,14 @@ static int scan_fwd_launch(const float* u, const float* delta, const float* dtr,
   const int nchunk = (L + CHUNK - 1) / CHUNK;
   dim3 grid((Dk + FWD_ROWS * FWD_RPW - 1) / (FWD_ROWS * FWD_RPW), B * K);
   hipStream_t s = (hipStream_t)stream;
-  const size_t dyn = dtr ? ((size_t)R * CHUNK + FWD_ROWS * FWD_RPW * RMAX) * sizeof(float) : 0;
-  if (L % 4 == 0)
-    hipLaunchKernelGGL(selscan_fwd_kernel<true>, grid, dim3(FWD_ROWS * WAVE), dyn, s, u, delta, A, Bm, Cm, D, dbias, y, hstate, K, Dk,
-                       L, nchunk, xmode, dtr, Wdt, R);
-  else
-    hipLaunchKernelGGL(selscan_fwd_kernel<false>, grid, dim3(FWD_ROWS * WAVE), dyn, s, u, delta, A, Bm, Cm, D, dbias, y, hstate, K, Dk,
-                       L, nchunk, xmode, dtr, Wdt, R);
+  if (!dtr) R = 0;
+  const size_t dyn = ((size_t)2 * NS * CHUNK + (size_t)R * CHUNK + (size_t)FWD_ROWS * FWD_RPW * (RMAX + 32 + NS)) * sizeof(float);
+#define LAUNCH_FWD(VEC, DTR)                                                                                                          \
+  hipLaunchKernelGGL((selscan_fwd_kernel<VEC, DTR>), grid, dim3(FWD_ROWS * WAVE), dyn, s, u, delta, A, Bm, Cm, D, dbias, y, hstate, K, Dk, \
+                     L, nchunk, xmode, dtr, Wdt, R)
+  if (L % 4 == 0) { if (dtr) LAUNCH_FWD(true, true); else LAUNCH_FWD(true, false); }
+  else { if (dtr) LAUNCH_FWD(false, true); else LAUNCH_FWD(false, false); }
+#undef LAUNCH_FWD
   return tamtr_launch_status();
 }
 
@@ -886,12 +918,17 @@ static int scan_bwd_launch(const float* gy, const float* u, const float* delta, 
   float* wsC = ws + (size_t)nslab * slab;
   dim3 grid(nslab, B * K);
   hipStream_t s = (hipStream_t)stream;
+  if (!dtr) R = 0;
   // B/C tiles | rank-R dt factors | Wdt rows | per-row sums | carry: 78 KB at rank 32, two workgroups per CU
   const size_t dyn = ((size_t)2 * NS * CHUNK + (size_t)R * CHUNK + (size_t)BWD_ROWS * (RMAX + ACC + NS)) * sizeof(float);
-#define LAUNCH_BWD(VEC)                                                                                                         \
-  hipLaunchKernelGGL((selscan_bwd_kernel<VEC>), grid, dim3(BWD_WAVES * WAVE), dyn, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu, \
+#define LAUNCH_BWD(VEC, SETS)                                                                                                          \
+  hipLaunchKernelGGL((selscan_bwd_kernel<VEC, SETS>), grid, dim3(BWD_WAVES * WAVE), dyn, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu, \
                      gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab, xmode, dtr, Wdt, gWdt, R)
-  if (L % 4 == 0) LAUNCH_BWD(true); else LAUNCH_BWD(false);
+  if (L % 4 == 0) {
+    if (R == 0) LAUNCH_BWD(true, 0); else if (R <= 16) LAUNCH_BWD(true, 1); else LAUNCH_BWD(true, 2);
+  } else {
+    if (R == 0) LAUNCH_BWD(false, 0); else if (R <= 16) LAUNCH_BWD(false, 1); else LAUNCH_BWD(false, 2);
+  }
 #undef LAUNCH_BWD
   if (dtr && L % 4) {
     hipLaunchKernelGGL(dtproj_gdtr_scalar_kernel, dim3((L + 255) / 256, B * K), dim3(256), 0, s, gdelta, Wdt, gdtr, K, Dk, R, L);

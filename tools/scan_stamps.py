@@ -23,9 +23,26 @@ for _ in range(2):
          ptr(gdtr), ptr(gW), ptr(gA), ptr(gB), ptr(gC), ptr(gD), ptr(gb), ptr(ws), B, K, Dk, N, R, L, 1, stream_ptr())
 torch.cuda.synchronize()
 st = gu.flatten()[:8].double().cpu() * 64
-names = ['chunk-top barrier', 'tile staging + barrier', 'softplus etc. after the loads arrived', 'states', 'row epilogue (stores, gW)', 'folds + barriers',
-         'slab stores', 'dt projection + wait for the row loads']
+names = ['chunk-top barrier', 'tile staging + barrier', 'row prologue (next-row requests, dt projection, softplus)', 'the 16 states', 'row epilogue (stores, row sums)',
+         'fold + barriers', 'slab stores', '-']
 tot = float(st[:8].sum())
 print(f'level {lvl}: wave 0 of workgroup (0,0): {tot:.0f} ticks total over {nchunk} chunks')
 for n, v in zip(names, st[:8]):
-    print(f'  {n:<42s} {100 * float(v) / tot:5.1f} %   {float(v) / nchunk:9.0f} ticks per chunk')
+    print(f'  {n:<58s} {100 * float(v) / tot:5.1f} %   {float(v) / nchunk:9.0f} ticks per chunk')
+
+nwg = (Dk // 32) * B * K
+w = gu.flatten()[16:16 + 4 * nwg].view(nwg, 4).double().cpu()
+t0, t1, xcc = w[:, 0], w[:, 1], w[:, 2]
+base = t0.min()
+dur = ((t1 - t0) % 16777216.0) / 100.0   # us (100 MHz, 24-bit window)
+start = (t0 - base) / 100.0
+q = torch.quantile(dur, torch.tensor([0.0, 0.25, 0.5, 0.75, 0.9, 0.99, 1.0], dtype=torch.float64))
+print(f'workgroups {nwg}: all started within {start.max():.0f} us; duration quantiles 0/25/50/75/90/99/100 %: ' + ' / '.join(f'{v:.0f}' for v in q) + ' us')
+print('per XCC: count, median, max duration (us):', [(int((xcc == i).sum()), int(dur[xcc == i].median()), int(dur[xcc == i].max())) for i in range(8)])
+nx = Dk // 32
+idx = torch.arange(nwg)
+kdir, bx = (idx // nx) % K, idx % nx
+print('per direction k median/max:', [(int(dur[kdir == i].median()), int(dur[kdir == i].max())) for i in range(K)])
+print('per row block (blockIdx.x) median/max:', [(int(dur[bx == i].median()), int(dur[bx == i].max())) for i in range(min(nx, 8))])
+slow = torch.nonzero(dur > q[3] * 1.15).flatten()
+print(f'{len(slow)} workgroups 15 % over the 75 % quantile; their XCCs: {sorted(set(int(xcc[i]) for i in slow))}')
