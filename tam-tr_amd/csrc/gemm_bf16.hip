@@ -14,6 +14,7 @@
 // LDS staging with the next tile's loads in flight under the MFMAs, XOR-swizzled 128-B rows (chunk ^ (row & 7)) so
 // ds_read_b128 fragment reads spread over all 16-B slots; two LDS stages, one barrier per K-step.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -518,11 +519,227 @@ __global__ __launch_bounds__(T5, 1) void linear_bf16_n512_k64_kernel(const bf16_
 #endif
 }
 
+// =====================================================================================================================
+// W-STATIONARY variant (K <= 512, N % 256 == 0): the weights never move again after the prologue.
+//
+// What held the full-row kernel above at 27 % of the MFMA roof: every 128-row tile re-streams all of W (512 KB) through
+// LDS-DMA - 80 one-KiB pieces per K-step and CU, each blocking its wave for ~260 cycles in the CU's single vector-memory
+// pipe - and pays a barrier per 64-deep K-step.  Here a wave keeps its 32 output columns x K of W in REGISTERS as ready-made
+// MFMA A-fragments (K/16 fragments x 4 VGPRs = 128 VGPRs at K = 512) for the whole kernel; a workgroup (8 waves) owns 256
+// columns and streams 32-row blocks of X (32 KB at K = 512: 32 one-KiB pieces per block and CU instead of 640 per 128 rows)
+// through a 4-slot LDS ring.  Per block a wave runs ONE dependent chain of K/16 + 1 v_mfma_f32_32x32x16_bf16 on a single 32x32
+// accumulator tile (a single accumulation chain of this instruction runs at the issue rate), each fed by one ds_read_b128
+// of the X block; one barrier per block.  N / 256 workgroups share a row block; they sit on the same XCD (blockIdx -> (xcd, slot)
+// map) so that the second reader of an X block hits that XCD's L2 and HBM sees X once.
+//   * Bias: one more MFMA per block whose A-fragment holds the bias split into two bf16 (hi + lo: 16 mantissa bits) against a
+//     constant B-fragment of two ones - no bias registers, loads or adds in the epilogue.
+//   * Epilogue without LDS: the accumulator (lane = one row, four groups of 4 consecutive columns) is packed with v_cvt_pk_bf16_f32,
+//     v_permlane32_swap joins the two half-waves' pieces into 16 bytes per lane, two stores of 32 rows x 32 bytes.  (Through a
+//     wave-private LDS image the three dependent LDS round trips cost ~1700 cycles per block next to the other waves' fragment reads.)
+//   * Stagger: behind the block's barrier waves 0-3 go straight to the matrix pipe and issue their LDS-DMA pieces (for block b + 3)
+//     after the chain; waves 4-7 issue their pieces first and then run the chain.  The two waves of a SIMD (w, w + 4) thus run
+//     about half a block apart - one on the matrix pipe while the other issues memory operations and converts - and every wave's
+//     stores come last, far behind the DMA burst (issued right behind it they queued in the CU's memory pipe for ~2000 cycles).
+// LDS image of a block: row r (K*2 bytes) | 16-byte chunk c stored at position c ^ (r & 15): conflict-free for the 16-lane groups of
+// ds_read_b128 (32 different rows per wave read); LDS-DMA writes lane-linear, so the XOR is applied to the SOURCE chunk of every lane.
+constexpr int WS_ROWS = 32, WS_SLOTS = 4, WS_T = 512, WS_COLS = 256;
+#ifndef WS_PF
+#define WS_PF 8   // X fragments in flight per wave
+#endif
+
+// 16 bytes per lane from global memory straight into LDS at (wave-uniform byte address lds_dst) + 16 * lane.  Inline asm, not the
+// builtin: hipcc treats the builtin as a store to LDS that any later LDS access may alias and drains it (s_waitcnt vmcnt(0)) in
+// front of the next ds_read / ds_write - which is every block here.  Hidden in asm the transfer is ordered only by the counted
+// s_waitcnt vmcnt(N) + barrier below.  M0 carries the LDS address; it is compiler-reserved, so it is saved and restored inside the
+// statement (s_nop: the SALU-writes-M0 -> LDS-DMA wait state).
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+template <int KK>
+__global__ __launch_bounds__(WS_T, 2) void linear_bf16_wstat_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                                     const float* __restrict__ bias, bf16_t* __restrict__ Y, int M,
+                                                                     int N, int ncol, int n_workers, int n_blocks) {
+  constexpr int RB = KK * 2;                   // bytes per X row
+  constexpr int BLK = WS_ROWS * RB;            // bytes per block
+  constexpr int CPR = RB / 16;                 // 16-byte chunks per row
+  constexpr int RPP = 1024 / RB;               // rows per 1-KiB LDS-DMA piece (1, 2 or 4)
+  constexpr int PPL = BLK / 1024 / 8;          // LDS-DMA pieces per wave and block (4, 2 or 1)
+  constexpr int NKS = KK / 16;                 // MFMAs per block and wave (+ 1 for the bias)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [WS_SLOTS blocks]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int colgrp = slot % ncol, worker = (slot / ncol) * 8 + xcd;
+  const int n0w = colgrp * WS_COLS + wave * 32;  // this wave's 32 output columns
+  const int my_blocks = worker < n_workers ? (n_blocks - worker + n_workers - 1) / n_workers : 0;
+
+  // ---- prologue: this wave's W rows as A-fragments (lane: row n0w + lr, k = 16 ks + 8 lh .. + 8) and the bias fragment
+  // (k = 0: bf16(b), k = 1: bf16(b - bf16(b)), rest zero; lanes of the upper half (k = 8 ..) all zero)
+  s16x8 wf[NKS + 1];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) wf[ks] = *reinterpret_cast<const s16x8*>(W + (size_t)(n0w + lr) * KK + ks * 16 + lh * 8);
+  {
+    const float bv = (bias && lh == 0) ? bias[n0w + lr] : 0.f;
+    const bf16_t hi = f2bf(bv), lo = f2bf(bv - bf2f(hi));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wf[NKS][j] = 0;
+    wf[NKS][0] = (short)hi;
+    wf[NKS][1] = (short)lo;
+  }
+  s16x8 ones;  // B-fragment of the bias MFMA: X "row" with ones at k = 0, 1
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = 0;
+  if (lh == 0) { ones[0] = (short)0x3f80; ones[1] = (short)0x3f80; }
+  // (the compiler waits for these loads where they are first USED: make that here, in front of the first LDS-DMA - its wait is a
+  // vmcnt(0), and placed at the first MFMA it would also drain the three blocks of X requested in between)
+#pragma unroll
+  for (int ks = 0; ks <= NKS; ++ks) asm volatile("" : "+v"(wf[ks]));
+
+  // ---- LDS-DMA: a block is 8 * PPL pieces of 1 KiB; wave w issues pieces w * PPL .. + PPL.  Lane -> (row in piece, position); the
+  // lane fetches the chunk that belongs at its position: pos ^ (row & 15)
+  const int prow = lane / CPR, ppos = lane % CPR;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void*)smem;  // byte address of the ring inside the workgroup's LDS allocation
+  auto issue = [&](int bi) {  // bi: this worker's block index (0 .. my_blocks)
+    const int m0 = (worker + bi * n_workers) * WS_ROWS;
+    const uint32_t dst = lds_base + (uint32_t)((bi % WS_SLOTS) * BLK + wave * PPL * 1024);
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      const int row = (wave * PPL + j) * RPP + prow;
+      const int chunk = ppos ^ (row & 15);
+      const bf16_t* src = X + (size_t)min(m0 + row, M - 1) * KK + chunk * 8;  // rows past M re-read the last row (never stored)
+#ifdef WS_ABL_NO_LOAD
+      if (bi < WS_SLOTS)   // timing-only build: only the first ring-full of blocks is really loaded
+#endif
+      glds16(src, dst + j * 1024);
+    }
+  };
+  const bool late = wave >= 4;
+#pragma unroll
+  for (int i = 0; i < WS_SLOTS - 1; ++i)
+    if (i < my_blocks) issue(i);
+
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  auto pack2 = [](float a, float b) -> uint32_t {  // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
+  };
+#ifdef WS_STAMP
+  unsigned long long sta[6] = {0, 0, 0, 0, 0, 0}, stl;
+#define WSTAMP(i) { unsigned long long n_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n_)::"memory"); __builtin_amdgcn_sched_barrier(0); sta[i] += n_ - stl; stl = n_; }
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stl)::"memory");
+#else
+#define WSTAMP(i)
+#endif
+  for (int bi = 0; bi < my_blocks; ++bi) {
+    // This wave's pieces of block bi have landed once only the operations issued AFTER them are outstanding (vmcnt counts loads,
+    // LDS-DMA and stores together, in issue order).  Per iteration j every wave issues [PPL pieces of block j+3][2 stores of block j]
+    // (waves 4-7: pieces, chain, stores; waves 0-3: chain, pieces, stores); behind the pieces of block bi therefore sit the stores of
+    // the iterations bi-3 .. bi-1 that exist and the pieces of the blocks bi+1, bi+2 that exist.
+    {
+      const int ahead = min(my_blocks - 1 - bi, WS_SLOTS - 2), st = min(bi, 3);
+#define VMW(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+      if (ahead == 2) { if (st == 0) VMW(2 * PPL); else if (st == 1) VMW(2 * PPL + 2); else if (st == 2) VMW(2 * PPL + 4); else VMW(2 * PPL + 6); }
+      else if (ahead == 1) { if (st == 0) VMW(PPL); else if (st == 1) VMW(PPL + 2); else if (st == 2) VMW(PPL + 4); else VMW(PPL + 6); }
+      else VMW(0);
+#undef VMW
+    }
+    WSTAMP(0)
+    __builtin_amdgcn_s_barrier();  // the pieces of block bi are in LDS; everyone is done reading block bi - 1
+    WSTAMP(1)
+    const bool more = bi + WS_SLOTS - 1 < my_blocks;
+    if (late && more) issue(bi + WS_SLOTS - 1);  // into the slot block bi - 1 has just left
+    WSTAMP(2)
+    const unsigned char* xb = smem + (bi % WS_SLOTS) * BLK + lr * RB;
+    int sw = lr & 15;              // swizzle key through an opaque copy: the NKS read offsets are rebuilt per block (one VALU op in the
+    asm volatile("" : "+v"(sw));   // shadow of each MFMA) instead of being hoisted out of the loop into NKS registers - and spilled
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    // fragment reads run PF MFMAs ahead of their use (left to itself hipcc issues each read right in front of its MFMA and every
+    // pair of MFMAs waits out an LDS round trip); the order is pinned with sched_group_barrier
+    constexpr int PF = NKS < WS_PF ? NKS : WS_PF;
+    s16x8 xf[PF];
+#pragma unroll
+    for (int ks = 0; ks < PF; ++ks) xf[ks] = *reinterpret_cast<const s16x8*>(xb + (((ks * 2 + lh) ^ sw) << 4));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[NKS], ones, acc, 0, 0, 0);  // bias
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[ks % PF], acc, 0, 0, 0);
+      if (ks + PF < NKS) xf[ks % PF] = *reinterpret_cast<const s16x8*>(xb + ((((ks + PF) * 2 + lh) ^ sw) << 4));
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);  // DS_READ x PF
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);      // MFMA (bias)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);    // MFMA
+      if (ks + PF < NKS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS_READ
+    }
+    WSTAMP(3)
+    if (!late && more) issue(bi + WS_SLOTS - 1);  // waves 0-3: behind their chain (the matrix pipe is the partner wave's now)
+    WSTAMP(5)
+    // ---- epilogue: D[i][j], i = n = (q & 3) + 8 (q >> 2) + 4 lh, j = m = lr.  Per group g = q >> 2 a lane holds 4 consecutive columns
+    // (8 bytes at column 8 g + 4 lh); v_permlane32_swap hands the lower half-wave both halves of the even groups and the upper one
+    // both halves of the odd groups: 16 contiguous bytes per lane, columns 16 (g >> 1) + 8 lh .. + 8
+    const int m0 = (worker + bi * n_workers) * WS_ROWS;
+    uint32_t pk[8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { pk[2 * g] = pack2(acc[4 * g], acc[4 * g + 1]); pk[2 * g + 1] = pack2(acc[4 * g + 2], acc[4 * g + 3]); }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {  // groups (2p, 2p + 1)
+      const auto r0 = __builtin_amdgcn_permlane32_swap(pk[4 * p], pk[4 * p + 2], false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(pk[4 * p + 1], pk[4 * p + 3], false, false);
+      // lower half: [own even-group half | partner's even-group half]; upper half: [partner's odd-group half | own odd-group half]
+      const uint4 v = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+      const int gm = m0 + lr;
+#ifdef WS_ABL_NO_STORE
+      if (gm < M && v.x == 0x12345678u)
+#else
+      if (gm < M)   // (always two store instructions per block and wave, which the vmcnt counts above rely on)
+#endif
+        *reinterpret_cast<uint4*>(Y + (size_t)gm * N + n0w + 16 * p + 8 * lh) = v;
+    }
+    WSTAMP(4)
+  }
+#ifdef WS_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4)) {  // diagnostic build only: the sums overwrite the head of Y
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(Y) + (wave ? 8 : 0);
+    for (int i = 0; i < 6; ++i) dbg[i] = sta[i];
+    dbg[6] = (unsigned long long)my_blocks;
+  }
+#endif
+#undef WSTAMP
+}
+
 }  // namespace
 
 extern "C" int tamtr_linear_bf16(const void* X, const void* W, const float* bias, void* Y, int M, int N, int K, void* stream) {
   if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return TAMTR_EINVAL;
   if (K % BK || N % BN) return TAMTR_EUNSUP;
+  if ((K == 512 || K == 256 || K == 128) && N % WS_COLS == 0 && 32 % (N / WS_COLS) == 0 && getenv("TAMTR_GEMM_OLD") == nullptr) {
+    // W-stationary: 256 persistent workgroups, N / 256 of them (same XCD) per row block
+    const int ncol = N / WS_COLS, n_workers = (32 / ncol) * 8, n_blocks = (M + WS_ROWS - 1) / WS_ROWS;
+    const size_t lds = (size_t)WS_SLOTS * WS_ROWS * K * 2;
+#define LAUNCH_WS(KK)                                                                                                        \
+  {                                                                                                                          \
+    static bool attr_set = false;                                                                                            \
+    if (!attr_set) {                                                                                                         \
+      (void)hipFuncSetAttribute((const void*)linear_bf16_wstat_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      attr_set = true;                                                                                                       \
+    }                                                                                                                        \
+    hipLaunchKernelGGL(linear_bf16_wstat_kernel<KK>, dim3(256), dim3(WS_T), lds, (hipStream_t)stream, (const bf16_t*)X,      \
+                       (const bf16_t*)W, bias, (bf16_t*)Y, M, N, ncol, n_workers, n_blocks);                                 \
+  }
+    if (K == 512) LAUNCH_WS(512) else if (K == 256) LAUNCH_WS(256) else LAUNCH_WS(128)
+#undef LAUNCH_WS
+    return tamtr_launch_status();
+  }
   if (N % TN == 0 && K % TK == 0) {  // full-row tiles: X read once (the value projection shape)
     const int mbl = (M + TM - 1) / TM, nbl = N / TN;
     if ((long long)mbl * nbl > 0x7fffffffLL) return TAMTR_EUNSUP;

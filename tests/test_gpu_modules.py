@@ -177,7 +177,7 @@ def test_self_attention_kernel(pkg, B, Q, nh, dh, masked):
     assert_close(out16.float(), ref, 2e-2, 2e-2, 'attn bf16')
 
 
-@pytest.mark.parametrize('M,N,K', [(1000, 512, 512), (128 * 16, 128, 64), (77, 256, 192)])
+@pytest.mark.parametrize('M,N,K', [(1000, 512, 512), (128 * 16, 128, 64), (77, 256, 192), (8193, 256, 256), (33, 1024, 128), (4999, 2048, 512)])
 def test_linear_bf16_kernel(pkg, M, N, K):
     """MFMA GEMM: exact products of bf16 inputs, fp32 accumulate -> agrees with an fp32 matmul of the same bf16 values
     to accumulation-order noise; output rounded once to bf16 (2^-9 relative)."""
