@@ -11,9 +11,13 @@ loss, backward, gradient clip 0.1, AdamW(lr 1e-4, wd 1e-4).  Every rank runs bs 
 over ranks with bucketed RCCL all-reduces overlapped with the backward (tam-tr_amd/dist.py).
 
 One JSON line on rank 0.  `roofline`: the MEH value-projection GEMM (tamtr_linear_bf16, the dominant dense contraction of
-the head: 3 launches per step, M = 16*33600, N = K = 512), timed live with events on the launch stream inside the timed
-steps, priced against the dense bf16 MFMA peak.  `cpu_baseline`: the CPU oracle (oracle/, a port - the reference's own
-end-to-end path cannot run on CPU) timed on this box's host cores on a bounded sample (2 images, 1 step).
+the head: M = 16*33600, N = K = 512; value_proj x 3 layers + enc_output forward, and their dX products), timed live with
+events on the launch stream inside the timed steps, priced against the dense bf16 MFMA peak; `traffic` = HBM bytes per launch
+from the PMC passes committed under profiles/ (same kernel, same shape).  `cpu_baseline`: the CPU oracle (oracle/, a port - the
+reference's own end-to-end path cannot run on CPU) on this box's host cores, bounded sample: 2 images, 1 warm-up +
+3 timed fwd+bwd steps.  `config.bf16_vs_fp32`: relative difference of the bf16-mode loss from the fp32-mode loss of the SAME
+model on the SAME batch, measured before the warm-up (the GPU parity suite holds the fp32 mode to the CPU oracle at 1e-3).
+For N > 1 the process group must be RCCL (`nccl`): the line records backend and world size, anything else is refused.
 """
 import argparse
 import json
@@ -79,10 +83,10 @@ def gemm_traffic(args):
     """HBM bytes per launch of the roofline kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
     WRITE_SIZE in separate runs of tools/gemm_only.py, corrected as the MI355X guide prescribes).  Counters cannot be collected
     from inside this process; null when the committed measurement is not for this shape."""
-    path = os.path.join(ROOT, 'profiles', 'r01_gemm_pmc.json')
+    path = os.path.join(ROOT, 'profiles', 'r02_gemm_pmc.json')
     try:
         d = json.load(open(path))
-        if d.get('M') == args.batch * 33600 and args.dtype == 'bf16':
+        if d.get('M') == args.batch * (args.imgsz // 4) ** 2 * 21 // 16 and args.dtype == 'bf16':
             return d['hbm_bytes_per_launch']
     except Exception:
         pass
@@ -106,8 +110,9 @@ def host_cores():
     return max(1, min(n, 32))
 
 
-def cpu_baseline(n_img=2, S=640):
-    """The CPU oracle (port) on this box's host cores: one fwd+bwd of the same graph on n_img images."""
+def cpu_baseline(n_img=2, S=640, repeats=3):
+    """The CPU oracle (port) on this box's host cores: fwd+bwd of the same graph on n_img images; one untimed warm-up step at
+    full size, then `repeats` timed steps (mean and spread reported)."""
     cores = host_cores()
     os.environ['OMP_NUM_THREADS'] = str(cores)  # the C scan twin's OpenMP runtime (loaded lazily below)
     torch.set_num_threads(cores)
@@ -123,19 +128,21 @@ def cpu_baseline(n_img=2, S=640):
     keep = b['batch_idx'] < n_img
     b = {'img': b['img'][:n_img], 'txt_feats': b['txt_feats'][:n_img], 'cls': b['cls'][keep], 'bboxes': b['bboxes'][keep],
          'batch_idx': b['batch_idx'][keep]}
-    tiny = synth_batch(2, 64, 1, 'cpu')
-    torch.manual_seed(0)
-    O.tamtr_loss(st, tiny, True, scan_fn=selscan_c.scan)[0].backward()  # thread-pool / allocator warm-up, untimed
-    print('[bench] cpu_baseline: warm-up done, timing', file=sys.stderr, flush=True)
-    t0 = time.time()
-    torch.manual_seed(0)
-    loss = O.tamtr_loss(st, b, True, scan_fn=selscan_c.scan)[0]
-    t1 = time.time()
-    print(f'[bench] cpu_baseline: forward {t1 - t0:.1f} s', file=sys.stderr, flush=True)
-    loss.backward()
-    dt = time.time() - t0
-    return {'value': n_img / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'{n_img} image(s) 640x640, 1 fwd+bwd step of the fp32 CPU oracle (torch CPU ops + C scan twin), {dt:.1f} s'}
+    times = []
+    for it in range(1 + repeats):
+        for v in st.values():
+            v.grad = None
+        t0 = time.time()
+        torch.manual_seed(0)
+        O.tamtr_loss(st, b, True, scan_fn=selscan_c.scan)[0].backward()
+        dt = time.time() - t0
+        print(f'[bench] cpu_baseline: {"warm-up" if it == 0 else "timed"} step {dt:.1f} s', file=sys.stderr, flush=True)
+        if it:
+            times.append(dt)
+    mean = sum(times) / len(times)
+    return {'value': n_img / mean, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'{n_img} image(s) {S}x{S}, fp32 CPU oracle (torch CPU ops + C scan twin): 1 warm-up + {repeats} timed fwd+bwd steps, '
+                      f'mean {mean:.1f} s (min {min(times):.1f}, max {max(times):.1f})'}
 
 
 def main():
@@ -147,6 +154,7 @@ def main():
     ap.add_argument('--imgsz', type=int, default=640)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--grad-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire (N > 1)')
     args = ap.parse_args()
 
     import tamtr_amd  # noqa: F401  (raises if the HIP library is missing)
@@ -155,6 +163,10 @@ def main():
     rank, local, world = tdist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    backend = torch.distributed.get_backend() if world > 1 else None
+    if world > 1 and backend != 'nccl' and os.environ.get('TAMTR_BENCH_ALLOW_GLOO') != '1':
+        # (a gloo run on one shared GPU is a rehearsal of the code path, not a measurement: set TAMTR_BENCH_ALLOW_GLOO=1 to run it)
+        raise SystemExit(f'--gpus {world} needs the RCCL process group (backend "nccl"), got "{backend}"')
     local = local % max(torch.cuda.device_count(), 1)  # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -166,7 +178,8 @@ def main():
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999), fused=True)
     reducer = None
     if world > 1:
-        reducer = tdist.GradReducer(model.named_parameters(), skip=lambda n: '.attn.' in n)
+        reducer = tdist.GradReducer(model.named_parameters(), skip=lambda n: '.attn.' in n, late=lambda n: 'denoising_class_embed' in n,
+                                    grad_dtype=torch.bfloat16 if args.grad_dtype == 'bf16' else None)
     batch = synth_batch(args.batch, args.imgsz, 1 + rank, dev)
     timer = KernelTimer()
     timer.install()
@@ -193,6 +206,21 @@ def main():
         if rank == 0:
             print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
+    # bf16 mode against fp32 mode on the same weights and batch (forward only, same denoising seed), before anything is trained
+    mode_err = None
+    if args.dtype == 'bf16':
+        saved = {k: v.clone() for k, v in model.state_dict().items()}   # BatchNorm statistics move with a training forward
+        with torch.no_grad():
+            losses = {}
+            for name, dt in (('fp32', None), ('bf16', torch.bfloat16)):
+                model.autocast_dtype = dt
+                torch.manual_seed(1234)
+                losses[name] = float(model(batch)[0])
+                model.load_state_dict(saved)
+        model.autocast_dtype = torch.bfloat16
+        mode_err = {'loss_fp32': losses['fp32'], 'loss_bf16': losses['bf16'], 'rel': abs(losses['bf16'] - losses['fp32']) / abs(losses['fp32'])}
+        del saved
+        torch.manual_seed(0)
     note(f'model built on {world} GPU(s), dtype {args.dtype}; warm-up ({args.warmup} steps; the first one includes MIOpen kernel selection)')
     for i in range(args.warmup):
         t1 = time.perf_counter()
@@ -216,14 +244,18 @@ def main():
         ks = timer.summary()
         peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == 'bf16' else MFMA_F32_PEAK_TFLOPS
         out = {
-            'metric': 'images/sec fwd+bwd @640x640 bs=16/GPU', 'value': world * args.batch * args.steps / dt, 'unit': 'images/sec',
+            'metric': f'images/sec fwd+bwd @{args.imgsz}x{args.imgsz} bs={args.batch}/GPU', 'value': world * args.batch * args.steps / dt, 'unit': 'images/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'TAM-TR (TAMTR.yaml graph, 42.1M params) train step fwd+loss+bwd+AdamW, {args.imgsz}x{args.imgsz}, '
                                    f'bs {args.batch}/GPU, 10 text prompts, 8 GT/img, full BTA-PAN+MEH HIP path',
-                       'global_batch': world * args.batch, 'parallelism': f'dp{world}', 'final_loss': float(loss.detach())},
+                       'global_batch': world * args.batch, 'parallelism': f'dp{world}', 'final_loss': float(loss.detach()),
+                       'bf16_vs_fp32': mode_err, 'dist_backend': backend, 'dist_world_size': world,
+                       'grad_bucket_dtype': (args.grad_dtype if world > 1 else None),
+                       'hbm_GiB_peak': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
             'roofline': None if ks is None else {
-                'bound': 'mfma', 'kernel': 'linear_bf16_n512_k64_kernel (MEH value_proj x3 + enc_output, M=%d N=K=512)' % (args.batch * 33600),
+                'bound': 'mfma', 'kernel': 'linear_bf16_wstat_kernel<512> (MEH value_proj x3 + enc_output and their dX, M=%d N=K=512)'
+                                           % (args.batch * (args.imgsz // 4) ** 2 * 21 // 16),
                 'achieved': ks['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': ks['tflops'] / peak, 'traffic': gemm_traffic(args),
                 'avg_ms': ks['avg_ms'], 'launches': ks['launches']},
         }

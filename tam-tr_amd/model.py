@@ -78,6 +78,7 @@ class _CastGroup(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, *ws):
+        ctx.set_materialize_grads(False)  # a copy nobody differentiates through (the discarded gate's proj_conv) keeps grad None
         outs = [torch.empty_like(w, dtype=torch.bfloat16) for w in ws]
         torch._foreach_copy_(outs, list(ws))
         return tuple(outs)
