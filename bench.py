@@ -17,6 +17,8 @@ from the PMC passes committed under profiles/ (same kernel, same shape).  `cpu_b
 reference's own end-to-end path cannot run on CPU) on this box's host cores, bounded sample: 2 images, 1 warm-up +
 3 timed fwd+bwd steps.  `config.bf16_vs_fp32`: relative difference of the bf16-mode loss from the fp32-mode loss of the SAME
 model on the SAME batch, measured before the warm-up (the GPU parity suite holds the fp32 mode to the CPU oracle at 1e-3).
+`config.static_part`: "hip-graph" when the shape-static part of the step (trunk, VSS blocks, input projection: ~3/4 of the
+launches) is replayed as two HIP graphs (model.capture_static_part), "eager" otherwise (--static-part eager).
 For N > 1 the process group must be RCCL (`nccl`): the line records backend and world size, anything else is refused.
 """
 import argparse
@@ -24,6 +26,8 @@ import json
 import os
 import sys
 import time
+
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')  # before the HIP runtime starts: see tam-tr_amd/graphs.py
 
 import torch
 
@@ -154,6 +158,8 @@ def main():
     ap.add_argument('--imgsz', type=int, default=640)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--static-part', default='graph', choices=['graph', 'eager'],
+                    help='trunk + VSS blocks + input projection replayed as two HIP graphs (forward, backward) or launched kernel by kernel')
     ap.add_argument('--grad-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire (N > 1)')
     args = ap.parse_args()
 
@@ -221,6 +227,17 @@ def main():
         mode_err = {'loss_fp32': losses['fp32'], 'loss_bf16': losses['bf16'], 'rel': abs(losses['bf16'] - losses['fp32']) / abs(losses['fp32'])}
         del saved
         torch.manual_seed(0)
+    static_part = 'eager'
+    if args.static_part == 'graph':
+        try:
+            t1 = time.perf_counter()
+            model.capture_static_part(batch['img'], batch['txt_feats'])
+            static_part = 'hip-graph'
+            note(f'static part captured in {time.perf_counter() - t1:.1f} s (includes MIOpen kernel selection)')
+        except Exception as e:  # noqa: BLE001 - report and run eagerly; the JSON line says which it was
+            model.release_static_part()
+            static_part = f'eager (capture failed: {type(e).__name__}: {e})'[:200]
+            note(static_part)
     note(f'model built on {world} GPU(s), dtype {args.dtype}; warm-up ({args.warmup} steps; the first one includes MIOpen kernel selection)')
     for i in range(args.warmup):
         t1 = time.perf_counter()
@@ -251,7 +268,7 @@ def main():
                                    f'bs {args.batch}/GPU, 10 text prompts, 8 GT/img, full BTA-PAN+MEH HIP path',
                        'global_batch': world * args.batch, 'parallelism': f'dp{world}', 'final_loss': float(loss.detach()),
                        'bf16_vs_fp32': mode_err, 'dist_backend': backend, 'dist_world_size': world,
-                       'grad_bucket_dtype': (args.grad_dtype if world > 1 else None),
+                       'grad_bucket_dtype': (args.grad_dtype if world > 1 else None), 'static_part': static_part,
                        'hbm_GiB_peak': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
             'roofline': None if ks is None else {
                 'bound': 'mfma', 'kernel': 'linear_bf16_wstat_kernel<512> (MEH value_proj x3 + enc_output and their dX, M=%d N=K=512)'

@@ -268,10 +268,11 @@ int tamtr_bn_act_bwd(const void* gy, const void* x, const float* gamma, const fl
                      float* ggamma, float* gbeta, float* partials, int B, int C, int HW, int act, int dtype, void* stream);
 
 /*      Channels-last variant (token-major maps, e.g. the MEH input projection output [B*L, hd] of head.py:1087 run as a GEMM):
- *      x, y, gy, gx (T) [N, C], C contiguous, C % 4 == 0 and 256 % (C / 4) == 0 (C <= 1024).  partials: caller workspace of
- *      C * tamtr_bncl_blocks(N) * 3 floats (forward) / C * tamtr_bncl_blocks(N) * 2 + 2 * C floats (backward).
+ *      x, y, gy, gx (T) [N, C], C contiguous and 16-byte aligned, C <= 1024, C % 4 == 0 and 256 % (C / V) == 0 with V = 8 for
+ *      bf16 maps with C % 8 == 0, else 4.  partials: caller workspace of S = tamtr_bncl_blocks(N, C, dtype) chunks:
+ *      C * S * 3 floats (forward) / C * S * 2 + 2 * C floats (backward).
  */
-int tamtr_bncl_blocks(long long N);
+int tamtr_bncl_blocks(long long N, int C, int dtype);
 int tamtr_bncl_act_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y,
                        float* mean_rstd, float* partials, long long N, int C, float eps, float momentum, int act, int dtype, void* stream);
 int tamtr_bncl_act_bwd(const void* gy, const void* x, const float* gamma, const float* beta, const float* mean_rstd, void* gx,

@@ -5,4 +5,15 @@ Layout: csrc/ = HIP kernels + C ABI (include/tamtr_hip.h); _lib.py = ctypes bind
 modules.py / head.py / backbone.py / model.py / loss.py = the ultralytics-style plugin surface (same class names,
 constructor/forward signatures and state_dict keys as the reference).
 """
+import os
+
+# The trunk runs NHWC (model.py: TAMTR_CHANNELS_LAST); MIOpen takes channels-last tensors as they are only when asked to, and
+# ATen reads this switch on its first convolution.
+if os.environ.get('TAMTR_CHANNELS_LAST', '1') != '0':
+    os.environ.setdefault('PYTORCH_MIOPEN_SUGGEST_NHWC', '1')
+
+# HIP graphs (graphs.py): with the runtime's AQL-packet capture of graph nodes, replays of the recorded backward intermittently
+# produced garbage gradients on ROCm 7.2 (tools/try_graph.py bisect; clean with the switch off).  Read when the HIP runtime starts.
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+
 from ._lib import LIB_PATH, TamtrHipError  # noqa: F401

@@ -53,8 +53,7 @@ class Conv(nn.Module):
         if y.is_cuda and self.bn.training and self.bn.affine and type(self.act) in (nn.SiLU, nn.Identity) \
                 and y.dtype in (torch.bfloat16, torch.float32):
             from . import ops
-            if y.dim() == 4 and not y.is_contiguous() and y.is_contiguous(memory_format=torch.channels_last) and y.shape[1] % 4 == 0 \
-                    and y.shape[1] <= 1024 and 256 % (y.shape[1] // 4) == 0:
+            if y.dim() == 4 and not y.is_contiguous() and y.is_contiguous(memory_format=torch.channels_last) and ops.bn_cl_ok(y.shape[1], y.dtype):
                 B, C, H, W = y.shape  # channels-last map: the [B*H*W, C] kernels, result stays channels-last
                 o = ops.bn_act(y.permute(0, 2, 3, 1).reshape(B * H * W, C), self.bn, isinstance(self.act, nn.SiLU))
                 return o.view(B, H, W, C).permute(0, 3, 1, 2)
@@ -179,6 +178,9 @@ class Upsample(nn.Upsample):
                 return x[..., ::2, ::2]
             if self.scale_factor == 2.0:
                 B, C, H, W = x.shape
+                if not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last):  # stays channels-last
+                    y = x.permute(0, 2, 3, 1)[:, :, None, :, None, :].expand(B, H, 2, W, 2, C).reshape(B, 2 * H, 2 * W, C)
+                    return y.permute(0, 3, 1, 2)
                 return x[:, :, :, None, :, None].expand(B, C, H, 2, W, 2).reshape(B, C, 2 * H, 2 * W)
         return super().forward(x)
 

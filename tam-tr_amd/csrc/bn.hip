@@ -9,7 +9,7 @@
 //   bn_apply     : every workgroup Chan-combines the channel's slices -> batch mean / biased var -> rstd (the first slice also
 //                  publishes them and updates the running stats with the unbiased var), then
 //                  y = act(gamma * (x - mean) * rstd + beta), act = identity | SiLU, 16-B loads and stores
-//   bn_finalize  : the same combination as its own one-wave-per-channel kernel (channels-last variant)
+//   bn_finalize  : the same combination as its own one-workgroup-per-channel kernel (channels-last variant)
 //   bn_bwd_reduce: per-slice sums of dz and dz * xhat, dz = gy * act'(z) with z recomputed from x
 //   bn_bwd_apply : gx = gamma * rstd * (dz - mean(dz) - xhat * mean(dz * xhat)); the slice sums of the channel are re-added
 //                  by every workgroup (<= a few hundred floats), d(gamma) / d(beta) are written by the first slice
@@ -82,43 +82,6 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restric
   }
 }
 
-// one workgroup (one wave) per channel
-__global__ __launch_bounds__(WAVE) void bn_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean_rstd,
-                                                            float* __restrict__ running_mean, float* __restrict__ running_var, int S,
-                                                            float eps, float momentum) {
-  const int c = blockIdx.x, lane = threadIdx.x;
-  // Chan's parallel combination, lane-strided then butterfly (combination is associative)
-  float n = 0.f, mean = 0.f, m2 = 0.f;
-  for (int s = lane; s < S; s += WAVE) {
-    const float* p = part + ((size_t)c * S + s) * 3;
-    const float nb = p[0], mb = p[1], m2b = p[2];
-    const float nt = n + nb, d = mb - mean;
-    mean += d * (nb / nt);
-    m2 += m2b + d * d * (n * nb / nt);
-    n = nt;
-  }
-#pragma unroll
-  for (int o = WAVE / 2; o > 0; o >>= 1) {
-    const float nb = __shfl_xor(n, o, WAVE), mb = __shfl_xor(mean, o, WAVE), m2b = __shfl_xor(m2, o, WAVE);
-    const float nt = n + nb;
-    if (nt > 0.f) {
-      const float d = mb - mean;
-      mean += d * (nb / nt);
-      m2 += m2b + d * d * (n * nb / nt);
-    }
-    n = nt;
-  }
-  if (lane == 0) {
-    const float var = m2 / n;
-    mean_rstd[2 * c] = mean;
-    mean_rstd[2 * c + 1] = rsqrtf(var + eps);
-    if (running_mean) {
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
-    }
-  }
-}
-
 // Chan-combine the S slice partials of channel c inside a workgroup (every apply workgroup redoes it: S <= a few hundred
 // triples, against a 4096-element slice of real work; saves the separate one-wave-per-channel finalize launch)
 __device__ __forceinline__ void combine_slices(const float* __restrict__ part, int c, int S, float* s_tri, float& mean_o, float& m2_o, float& n_o) {
@@ -158,6 +121,25 @@ __device__ __forceinline__ void combine_slices(const float* __restrict__ part, i
     n = nt;
   }
   mean_o = mean; m2_o = m2; n_o = n;
+}
+
+// one workgroup per channel (channels-last variant: S can be ~1000 chunks)
+__global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean_rstd,
+                                                                  float* __restrict__ running_mean, float* __restrict__ running_var, int S,
+                                                                  float eps, float momentum) {
+  __shared__ float s_tri[3 * BN_THREADS / WAVE];
+  const int c = blockIdx.x;
+  float mean, m2, n;
+  combine_slices(part, c, S, s_tri, mean, m2, n);
+  if (threadIdx.x == 0) {
+    const float var = m2 / n;
+    mean_rstd[2 * c] = mean;
+    mean_rstd[2 * c + 1] = rsqrtf(var + eps);
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
+    }
+  }
 }
 
 template <typename T>
@@ -272,123 +254,212 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const T* __res
   }
 }
 
-// ---- channels-last variant: x [N, C] with C contiguous (token-major maps: the MEH input projection output).  A workgroup owns
-// CL_ROWS rows x all C columns; a thread owns 4 consecutive columns and every RL-th row (RL = 256 / (C / 4) row lanes).
-constexpr int CL_ROWS = 128;
-
-template <typename T>
-__global__ __launch_bounds__(BN_THREADS) void bncl_stats_kernel(const T* __restrict__ x, float* __restrict__ part, int N, int C) {
-  __shared__ float s_acc[BN_THREADS][8];
-  const int cg = C / 4, rl = BN_THREADS / cg;          // column groups, row lanes
-  const int g = threadIdx.x % cg, r = threadIdx.x / cg;
-  const int row0 = blockIdx.x * CL_ROWS, nrow = min(CL_ROWS, N - row0), S = gridDim.x;
-  float k[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  if (r < rl) {
-    Elt<T>::ld4(x + (size_t)row0 * C + g * 4, k);       // shift by the block's first row: sums of (x - k) stay well conditioned
-    for (int i = r; i < nrow; i += rl) {
-      float v[4];
-      Elt<T>::ld4(x + (size_t)(row0 + i) * C + g * 4, v);
+// ---- channels-last variant: x [N, C] with C contiguous (token-major maps: the MEH input projection output, and the trunk when it
+// runs NHWC).  The map is cut into contiguous chunks of iters x 256 x V elements, V = the elements of one 16-byte load (8 bf16, 4 fp32);
+// one workgroup streams one chunk, thread t takes the t-th 16 bytes of every 256 x V piece.  256 x V is a multiple of C, so a
+// thread meets the same V columns in every piece: its per-column constants stay in registers, and a chunk starts on a row.
+template <typename T, int V>
+struct Vec;
+template <>
+struct Vec<float, 4> {
+  static __device__ __forceinline__ void ld(const float* p, float (&o)[4]) { Elt<float>::ld4(p, o); }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[4]) { Elt<float>::st4(p, v); }
+};
+template <>
+struct Vec<bf16_t, 4> {
+  static __device__ __forceinline__ void ld(const bf16_t* p, float (&o)[4]) { Elt<bf16_t>::ld4(p, o); }
+  static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[4]) { Elt<bf16_t>::st4(p, v); }
+};
+template <>
+struct Vec<bf16_t, 8> {
+  static __device__ __forceinline__ void ld(const bf16_t* p, float (&o)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const float d = v[j] - k[j]; s1[j] += d; s2[j] = fmaf(d, d, s2[j]); }
-    }
+    for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
   }
+  static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {
+    uint32_t w[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { s_acc[threadIdx.x][j] = s1[j]; s_acc[threadIdx.x][4 + j] = s2[j]; }
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+constexpr int CL_UNROLL = 4;   // 16-byte loads a thread keeps in flight; iters is a multiple of it
+
+// Per-column sums of the workgroup's 256 threads: s_acc[t][j] (j < W values per thread, thread t owns column group t % cg) ->
+// s_col[g * W + j] = the sum over the 256 / cg threads of group g.  Every thread adds 256 / cg values for W * cg / 256 outputs.
+template <int W>
+__device__ __forceinline__ void fold_row_lanes(const float (&mine)[W], float* s_acc, float* s_col, int cg) {
+#pragma unroll
+  for (int j = 0; j < W; ++j) s_acc[threadIdx.x * W + j] = mine[j];
   __syncthreads();
-  if (r == 0) {
-    for (int q = 1; q < rl; ++q)
+  const int rl = BN_THREADS / cg;
+  for (int o = threadIdx.x; o < cg * W; o += BN_THREADS) {
+    const int g = o / W, j = o % W;
+    float a = 0.f;
+    for (int q = 0; q < rl; ++q) a += s_acc[(q * cg + g) * W + j];
+    s_col[o] = a;
+  }
+  __syncthreads();
+}
+
+// part[c][chunk][3] = rows, mean, M2 of the chunk's rows in column c.  Sums are taken of (x - k), k = the chunk's first row (well
+// conditioned, and a load past the end of the map is redirected to that row: it adds 0).
+template <typename T, int V>
+__global__ __launch_bounds__(BN_THREADS) void bncl_stats_kernel(const T* __restrict__ x, float* __restrict__ part, size_t total, int C,
+                                                                 int iters) {
+  __shared__ float s_acc[BN_THREADS * 2 * V];
+  __shared__ float s_col[2 * 1024];
+  const size_t piece = (size_t)BN_THREADS * V, start = (size_t)blockIdx.x * iters * piece, end = min(total, start + iters * piece);
+  const int cg = C / V, g = threadIdx.x % cg, S = gridDim.x;
+  const T* home = x + start + (size_t)g * V;
+  float k[V], acc[2 * V];
+  Vec<T, V>::ld(home, k);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { s1[j] += s_acc[q * cg + g][j]; s2[j] += s_acc[q * cg + g][4 + j]; }
+  for (int j = 0; j < 2 * V; ++j) acc[j] = 0.f;
+  const size_t e0 = start + (size_t)threadIdx.x * V;
+  for (int it = 0; it < iters; it += CL_UNROLL) {
+    float v[CL_UNROLL][V];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float* o = part + ((size_t)(g * 4 + j) * S + blockIdx.x) * 3;
-      const float n = (float)nrow, m = s1[j] / n;
-      o[0] = n; o[1] = k[j] + m; o[2] = s2[j] - s1[j] * m;
+    for (int u = 0; u < CL_UNROLL; ++u) {
+      const size_t e = e0 + (size_t)(it + u) * piece;
+      Vec<T, V>::ld(e < end ? x + e : home, v[u]);
     }
+#pragma unroll
+    for (int u = 0; u < CL_UNROLL; ++u)
+#pragma unroll
+      for (int j = 0; j < V; ++j) { const float d = v[u][j] - k[j]; acc[j] += d; acc[V + j] = fmaf(d, d, acc[V + j]); }
+  }
+  fold_row_lanes<2 * V>(acc, s_acc, s_col, cg);
+  const float n = (float)((end - start) / C);
+  for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+    const float s1 = s_col[(c / V) * 2 * V + c % V], s2 = s_col[(c / V) * 2 * V + V + c % V], m = s1 / n;
+    float* o = part + ((size_t)c * S + blockIdx.x) * 3;
+    o[0] = n; o[1] = Elt<T>::ld(x + start + c) + m; o[2] = s2 - s1 * m;
   }
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(BN_THREADS) void bncl_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean_rstd,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                 T* __restrict__ y, size_t n4, int C, int act) {
-  const size_t i = (size_t)blockIdx.x * BN_THREADS + threadIdx.x;   // one float4-group of 4 columns
-  if (i >= n4) return;
-  const int c = (int)(i % (C / 4)) * 4;
-  float v[4];
-  Elt<T>::ld4(x + i * 4, v);
+                                                                 T* __restrict__ y, size_t total, int C, int iters, int act) {
+  const size_t piece = (size_t)BN_THREADS * V, start = (size_t)blockIdx.x * iters * piece, end = min(total, start + iters * piece);
+  const int c0 = (threadIdx.x % (C / V)) * V;
+  const size_t home = start + c0;   // first row of the chunk: where a load past the end is redirected
+  float mean[V], a[V], be[V];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = act_fwd(fmaf(v[j] - mean_rstd[2 * (c + j)], mean_rstd[2 * (c + j) + 1] * gamma[c + j], beta[c + j]), act);
-  Elt<T>::st4(y + i * 4, v);
+  for (int j = 0; j < V; ++j) { mean[j] = mean_rstd[2 * (c0 + j)]; a[j] = mean_rstd[2 * (c0 + j) + 1] * gamma[c0 + j]; be[j] = beta[c0 + j]; }
+  const size_t e0 = start + (size_t)threadIdx.x * V;
+  for (int it = 0; it < iters; it += CL_UNROLL) {
+    float v[CL_UNROLL][V];
+#pragma unroll
+    for (int u = 0; u < CL_UNROLL; ++u) {
+      const size_t e = e0 + (size_t)(it + u) * piece;
+      Vec<T, V>::ld(x + (e < end ? e : home), v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < CL_UNROLL; ++u) {
+      const size_t e = e0 + (size_t)(it + u) * piece;
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[u][j] = act_fwd(fmaf(v[u][j] - mean[j], a[j], be[j]), act);
+      if (e < end) Vec<T, V>::st(y + e, v[u]);
+    }
+  }
 }
 
-template <typename T>
+// part[c][chunk][2] = sum dz, sum dz * xhat over the chunk's rows
+template <typename T, int V>
 __global__ __launch_bounds__(BN_THREADS) void bncl_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restrict__ x,
                                                                       const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
-                                                                      const float* __restrict__ beta, float* __restrict__ part, int N, int C,
-                                                                      int act) {
-  __shared__ float s_acc[BN_THREADS][8];
-  const int cg = C / 4, rl = BN_THREADS / cg;
-  const int g = threadIdx.x % cg, r = threadIdx.x / cg;
-  const int row0 = blockIdx.x * CL_ROWS, nrow = min(CL_ROWS, N - row0), S = gridDim.x;
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  if (r < rl) {
-    float mean[4], rstd[4], gm[4], be[4];
+                                                                      const float* __restrict__ beta, float* __restrict__ part, size_t total,
+                                                                      int C, int iters, int act) {
+  __shared__ float s_acc[BN_THREADS * 2 * V];
+  __shared__ float s_col[2 * 1024];
+  const size_t piece = (size_t)BN_THREADS * V, start = (size_t)blockIdx.x * iters * piece, end = min(total, start + iters * piece);
+  const int cg = C / V, c0 = (threadIdx.x % cg) * V, S = gridDim.x;
+  const size_t home = start + c0;
+  float mean[V], rstd[V], gm[V], be[V], acc[2 * V];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { mean[j] = mean_rstd[2 * (g * 4 + j)]; rstd[j] = mean_rstd[2 * (g * 4 + j) + 1]; gm[j] = gamma[g * 4 + j]; be[j] = beta[g * 4 + j]; }
-    for (int i = r; i < nrow; i += rl) {
-      float xv[4], gv[4];
-      Elt<T>::ld4(x + (size_t)(row0 + i) * C + g * 4, xv);
-      Elt<T>::ld4(gy + (size_t)(row0 + i) * C + g * 4, gv);
+  for (int j = 0; j < V; ++j) {
+    mean[j] = mean_rstd[2 * (c0 + j)]; rstd[j] = mean_rstd[2 * (c0 + j) + 1]; gm[j] = gamma[c0 + j]; be[j] = beta[c0 + j];
+    acc[j] = 0.f; acc[V + j] = 0.f;
+  }
+  const size_t e0 = start + (size_t)threadIdx.x * V;
+  for (int it = 0; it < iters; it += CL_UNROLL) {
+    float xv[CL_UNROLL][V], gv[CL_UNROLL][V];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float xh = (xv[j] - mean[j]) * rstd[j];
-        const float dz = gv[j] * act_bwd(fmaf(xh, gm[j], be[j]), act);
-        s1[j] += dz; s2[j] = fmaf(dz, xh, s2[j]);
+    for (int u = 0; u < CL_UNROLL; ++u) {
+      const size_t e = e0 + (size_t)(it + u) * piece, ee = e < end ? e : home;
+      Vec<T, V>::ld(x + ee, xv[u]);
+      Vec<T, V>::ld(gy + ee, gv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < CL_UNROLL; ++u) {
+      const float live = e0 + (size_t)(it + u) * piece < end ? 1.f : 0.f;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float xh = (xv[u][j] - mean[j]) * rstd[j];
+        const float dz = live * gv[u][j] * act_bwd(fmaf(xh, gm[j], be[j]), act);
+        acc[j] += dz; acc[V + j] = fmaf(dz, xh, acc[V + j]);
       }
     }
   }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { s_acc[threadIdx.x][j] = s1[j]; s_acc[threadIdx.x][4 + j] = s2[j]; }
-  __syncthreads();
-  if (r == 0) {
-    for (int q = 1; q < rl; ++q)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { s1[j] += s_acc[q * cg + g][j]; s2[j] += s_acc[q * cg + g][4 + j]; }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { float* o = part + ((size_t)(g * 4 + j) * S + blockIdx.x) * 2; o[0] = s1[j]; o[1] = s2[j]; }
+  fold_row_lanes<2 * V>(acc, s_acc, s_col, cg);
+  for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+    float* o = part + ((size_t)c * S + blockIdx.x) * 2;
+    o[0] = s_col[(c / V) * 2 * V + c % V]; o[1] = s_col[(c / V) * 2 * V + V + c % V];
   }
 }
 
-// sums[c][2] = sum over the S row blocks (one wave per channel)
-__global__ __launch_bounds__(WAVE) void bncl_sum_kernel(const float* __restrict__ part, float* __restrict__ sums, float* __restrict__ ggamma,
-                                                        float* __restrict__ gbeta, int S) {
+// sums[c][2] = sum over the S chunks (one workgroup per channel)
+__global__ __launch_bounds__(BN_THREADS) void bncl_sum_kernel(const float* __restrict__ part, float* __restrict__ sums, float* __restrict__ ggamma,
+                                                               float* __restrict__ gbeta, int S) {
+  __shared__ float s_red[BN_THREADS / WAVE];
   const int c = blockIdx.x;
   float a = 0.f, b = 0.f;
-  for (int s = threadIdx.x; s < S; s += WAVE) { a += part[((size_t)c * S + s) * 2]; b += part[((size_t)c * S + s) * 2 + 1]; }
-  a = group_sum<WAVE>(a); b = group_sum<WAVE>(b);
+  for (int s = threadIdx.x; s < S; s += BN_THREADS) { a += part[((size_t)c * S + s) * 2]; b += part[((size_t)c * S + s) * 2 + 1]; }
+  a = block_sum(a, s_red); b = block_sum(b, s_red);
   if (threadIdx.x == 0) { sums[2 * c] = a; sums[2 * c + 1] = b; gbeta[c] = a; ggamma[c] = b; }
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(BN_THREADS) void bncl_bwd_apply_kernel(const T* __restrict__ gy, const T* __restrict__ x,
                                                                      const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                                      const float* __restrict__ beta, const float* __restrict__ sums,
-                                                                     T* __restrict__ gx, size_t n4, int C, int act, float inv_count) {
-  const size_t i = (size_t)blockIdx.x * BN_THREADS + threadIdx.x;
-  if (i >= n4) return;
-  const int c = (int)(i % (C / 4)) * 4;
-  float xv[4], gv[4], o[4];
-  Elt<T>::ld4(x + i * 4, xv);
-  Elt<T>::ld4(gy + i * 4, gv);
+                                                                     T* __restrict__ gx, size_t total, int C, int iters, int act,
+                                                                     float inv_count) {
+  const size_t piece = (size_t)BN_THREADS * V, start = (size_t)blockIdx.x * iters * piece, end = min(total, start + iters * piece);
+  const int c0 = (threadIdx.x % (C / V)) * V;
+  const size_t home = start + c0;   // first row of the chunk: where a load past the end is redirected
+  float mean[V], rstd[V], gm[V], be[V], k1[V], k2[V];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float rstd = mean_rstd[2 * (c + j) + 1], g = gamma[c + j];
-    const float xh = (xv[j] - mean_rstd[2 * (c + j)]) * rstd;
-    const float dz = gv[j] * act_bwd(fmaf(xh, g, beta[c + j]), act);
-    o[j] = g * rstd * (dz - sums[2 * (c + j)] * inv_count - xh * sums[2 * (c + j) + 1] * inv_count);
+  for (int j = 0; j < V; ++j) {
+    mean[j] = mean_rstd[2 * (c0 + j)]; rstd[j] = mean_rstd[2 * (c0 + j) + 1]; gm[j] = gamma[c0 + j]; be[j] = beta[c0 + j];
+    k1[j] = sums[2 * (c0 + j)] * inv_count; k2[j] = sums[2 * (c0 + j) + 1] * inv_count;
   }
-  Elt<T>::st4(gx + i * 4, o);
+  const size_t e0 = start + (size_t)threadIdx.x * V;
+  for (int it = 0; it < iters; it += CL_UNROLL) {
+    float xv[CL_UNROLL][V], gv[CL_UNROLL][V];
+#pragma unroll
+    for (int u = 0; u < CL_UNROLL; ++u) {
+      const size_t e = e0 + (size_t)(it + u) * piece, ee = e < end ? e : home;
+      Vec<T, V>::ld(x + ee, xv[u]);
+      Vec<T, V>::ld(gy + ee, gv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < CL_UNROLL; ++u) {
+      const size_t e = e0 + (size_t)(it + u) * piece;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float xh = (xv[u][j] - mean[j]) * rstd[j];
+        const float dz = gv[u][j] * act_bwd(fmaf(xh, gm[j], be[j]), act);
+        gv[u][j] = gm[j] * rstd[j] * (dz - k1[j] - xh * k2[j]);
+      }
+      if (e < end) Vec<T, V>::st(gx + e, gv[u]);
+    }
+  }
 }
 
 }  // namespace
@@ -450,13 +521,25 @@ extern "C" int tamtr_bn_act_bwd(const void* gy, const void* x, const float* gamm
 }
 
 // ---- channels-last entry points: x [N, C], C contiguous
-extern "C" int tamtr_bncl_blocks(long long N) { return (int)((N + CL_ROWS - 1) / CL_ROWS); }
+static int bncl_vec(int C, int dtype) { return dtype == TAMTR_BF16 && C % 8 == 0 ? 8 : 4; }
+static int bncl_iters(long long N, int C, int dtype) {   // chunk length: about 1024 workgroups, 16 KB .. 256 KB each
+  const long long piece = (long long)BN_THREADS * bncl_vec(C, dtype), total = N * C;
+  const long long it = (total / piece / 1024 + CL_UNROLL - 1) / CL_UNROLL * CL_UNROLL;
+  return (int)(it < 4 ? 4 : it > 64 ? 64 : it);
+}
+extern "C" int tamtr_bncl_blocks(long long N, int C, int dtype) {
+  if (N <= 0 || C <= 0) return 0;
+  const long long chunk = (long long)bncl_iters(N, C, dtype) * BN_THREADS * bncl_vec(C, dtype);
+  return (int)((N * C + chunk - 1) / chunk);
+}
 
 static int bncl_check(const void* a, const void* b, long long N, int C, int dtype, int act) {
   if (!a || !b || N <= 0 || C <= 0) return TAMTR_EINVAL;
   if ((dtype != TAMTR_F32 && dtype != TAMTR_BF16) || (act != 0 && act != 1)) return TAMTR_EINVAL;
-  const int cg = C / 4;
-  if (C % 4 || cg > BN_THREADS || (BN_THREADS % cg) || N > 2000000000LL) return TAMTR_EUNSUP;  // C in {4, 8, ..., 1024} with 256 % (C/4) == 0
+  const int cg = C / bncl_vec(C, dtype);
+  // C in {4, 8, ..., 1024} with 256 % (C / V) == 0, 16-byte (8-byte when V = 4 on bf16) aligned maps
+  if (C % 4 || C > 1024 || cg > BN_THREADS || (BN_THREADS % cg) || N > 2000000000LL / C) return TAMTR_EUNSUP;
+  if (((uintptr_t)a | (uintptr_t)b) % 16) return TAMTR_EUNSUP;
   return TAMTR_OK;
 }
 
@@ -466,18 +549,19 @@ extern "C" int tamtr_bncl_act_fwd(const void* x, const float* gamma, const float
   const int rc = bncl_check(x, y, N, C, dtype, act);
   if (rc) return rc;
   if (!gamma || !beta || !mean_rstd || !partials) return TAMTR_EINVAL;
-  const int S = tamtr_bncl_blocks(N);
-  const size_t n4 = (size_t)N * C / 4;
-  const unsigned ab = (unsigned)((n4 + BN_THREADS - 1) / BN_THREADS);
+  const int S = tamtr_bncl_blocks(N, C, dtype), V = bncl_vec(C, dtype), iters = bncl_iters(N, C, dtype);
+  const size_t total = (size_t)N * C;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == TAMTR_F32) hipLaunchKernelGGL(bncl_stats_kernel<float>, dim3(S), dim3(BN_THREADS), 0, s, (const float*)x, partials, (int)N, C);
-  else hipLaunchKernelGGL(bncl_stats_kernel<bf16_t>, dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)x, partials, (int)N, C);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(WAVE), 0, s, partials, mean_rstd, running_mean, running_var, S, eps, momentum);
+  if (dtype == TAMTR_F32) hipLaunchKernelGGL((bncl_stats_kernel<float, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const float*)x, partials, total, C, iters);
+  else if (V == 8) hipLaunchKernelGGL((bncl_stats_kernel<bf16_t, 8>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)x, partials, total, C, iters);
+  else hipLaunchKernelGGL((bncl_stats_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)x, partials, total, C, iters);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_THREADS), 0, s, partials, mean_rstd, running_mean, running_var, S, eps, momentum);
   if (dtype == TAMTR_F32)
-    hipLaunchKernelGGL(bncl_apply_kernel<float>, dim3(ab), dim3(BN_THREADS), 0, s, (const float*)x, mean_rstd, gamma, beta, (float*)y, n4, C, act);
+    hipLaunchKernelGGL((bncl_apply_kernel<float, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const float*)x, mean_rstd, gamma, beta, (float*)y, total, C, iters, act);
+  else if (V == 8)
+    hipLaunchKernelGGL((bncl_apply_kernel<bf16_t, 8>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)x, mean_rstd, gamma, beta, (bf16_t*)y, total, C, iters, act);
   else
-    hipLaunchKernelGGL(bncl_apply_kernel<bf16_t>, dim3(ab), dim3(BN_THREADS), 0, s, (const bf16_t*)x, mean_rstd, gamma, beta, (bf16_t*)y, n4, C,
-                       act);
+    hipLaunchKernelGGL((bncl_apply_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)x, mean_rstd, gamma, beta, (bf16_t*)y, total, C, iters, act);
   return tamtr_launch_status();
 }
 
@@ -485,25 +569,24 @@ extern "C" int tamtr_bncl_act_bwd(const void* gy, const void* x, const float* ga
                                   float* ggamma, float* gbeta, float* partials, long long N, int C, int act, int dtype, void* stream) {
   const int rc = bncl_check(gy, x, N, C, dtype, act);
   if (rc) return rc;
-  if (!gamma || !beta || !mean_rstd || !gx || !ggamma || !gbeta || !partials) return TAMTR_EINVAL;
-  const int S = tamtr_bncl_blocks(N);
-  const size_t n4 = (size_t)N * C / 4;
-  const unsigned ab = (unsigned)((n4 + BN_THREADS - 1) / BN_THREADS);
+  if (!gamma || !beta || !mean_rstd || !gx || !ggamma || !gbeta || !partials || (uintptr_t)gx % 16) return TAMTR_EINVAL;
+  const int S = tamtr_bncl_blocks(N, C, dtype), V = bncl_vec(C, dtype), iters = bncl_iters(N, C, dtype);
+  const size_t total = (size_t)N * C;
   hipStream_t s = (hipStream_t)stream;
-  float* sums = partials + (size_t)C * S * 2;  // [C][2] after the per-block partials
+  float* sums = partials + (size_t)C * S * 2;  // [C][2] after the per-chunk partials
   const float inv = 1.f / (float)N;
   if (dtype == TAMTR_F32)
-    hipLaunchKernelGGL(bncl_bwd_reduce_kernel<float>, dim3(S), dim3(BN_THREADS), 0, s, (const float*)gy, (const float*)x, mean_rstd, gamma, beta,
-                       partials, (int)N, C, act);
+    hipLaunchKernelGGL((bncl_bwd_reduce_kernel<float, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const float*)gy, (const float*)x, mean_rstd, gamma, beta, partials, total, C, iters, act);
+  else if (V == 8)
+    hipLaunchKernelGGL((bncl_bwd_reduce_kernel<bf16_t, 8>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, partials, total, C, iters, act);
   else
-    hipLaunchKernelGGL(bncl_bwd_reduce_kernel<bf16_t>, dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma,
-                       beta, partials, (int)N, C, act);
-  hipLaunchKernelGGL(bncl_sum_kernel, dim3(C), dim3(WAVE), 0, s, partials, sums, ggamma, gbeta, S);
+    hipLaunchKernelGGL((bncl_bwd_reduce_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, partials, total, C, iters, act);
+  hipLaunchKernelGGL(bncl_sum_kernel, dim3(C), dim3(BN_THREADS), 0, s, partials, sums, ggamma, gbeta, S);
   if (dtype == TAMTR_F32)
-    hipLaunchKernelGGL(bncl_bwd_apply_kernel<float>, dim3(ab), dim3(BN_THREADS), 0, s, (const float*)gy, (const float*)x, mean_rstd, gamma, beta,
-                       sums, (float*)gx, n4, C, act, inv);
+    hipLaunchKernelGGL((bncl_bwd_apply_kernel<float, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const float*)gy, (const float*)x, mean_rstd, gamma, beta, sums, (float*)gx, total, C, iters, act, inv);
+  else if (V == 8)
+    hipLaunchKernelGGL((bncl_bwd_apply_kernel<bf16_t, 8>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, sums, (bf16_t*)gx, total, C, iters, act, inv);
   else
-    hipLaunchKernelGGL(bncl_bwd_apply_kernel<bf16_t>, dim3(ab), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma,
-                       beta, sums, (bf16_t*)gx, n4, C, act, inv);
+    hipLaunchKernelGGL((bncl_bwd_apply_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, sums, (bf16_t*)gx, total, C, iters, act, inv);
   return tamtr_launch_status();
 }

@@ -77,7 +77,8 @@ class GradReducer:
             off = 0
             bucket = {'flat': flat, 'params': g, 'pending': 0, 'handle': None, 'views': []}
             for _, p in g:
-                v = flat[off:off + p.numel()].view_as(p)
+                # same strides as the parameter (channels-last conv weights): autograd and the optimizer stay on their fast paths
+                v = flat[off:off + p.numel()].view_as(p) if p.is_contiguous() else torch.as_strided(flat, p.shape, p.stride(), off)
                 off += p.numel()
                 bucket['views'].append(v)
                 if dt == p.dtype:

@@ -47,10 +47,16 @@ class ManbaWorldDecoder(nn.Module):
         self._reset_parameters()
 
     def forward(self, x, text, batch=None):
+        return self.decode(*self.encode(x), text, batch)
+
+    def encode(self, x):
+        """The three trunk maps -> the token memory `feats` [B, L, hd] and the level shapes.  Shapes depend on the image size only."""
         # VSS blocks run channels-last ([B,H,W,C], head.py:1136-1140); their outputs stay token-major: the 1x1 input projection
         # is a GEMM over tokens and its result is already in the [B, L, hd] layout of the token memory
         toks = [blk(f.permute(0, 2, 3, 1)) for blk, f in zip(self.VSSBlocks, x)]
-        feats, shapes = self._get_encoder_input(toks)
+        return self._get_encoder_input(toks)
+
+    def decode(self, feats, shapes, text, batch=None):
         dn_embed, dn_bbox, attn_mask, dn_meta = get_cdn_group(batch, self.nc, self.num_queries,
                                                               self.denoising_class_embed.weight, self.num_denoising,
                                                               self.label_noise_ratio, self.box_noise_scale, self.training)
@@ -96,7 +102,7 @@ class ManbaWorldDecoder(nn.Module):
             else:
                 y = torch.nn.functional.linear(t2, w.to(t2.dtype))
             C2 = y.shape[1]
-            if y.is_cuda and bn.training and C2 % 4 == 0 and C2 <= 1024 and 256 % (C2 // 4) == 0:
+            if y.is_cuda and bn.training and ops.bn_cl_ok(C2, y.dtype):
                 y = ops.bn_act(y, bn, False)  # channels-last BatchNorm kernels (csrc/bn.hip)
             else:
                 if bn.training and bn.track_running_stats:

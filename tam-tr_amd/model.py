@@ -67,7 +67,10 @@ def build_graph(spec, ch=3, nc=10):
 
 
 import os
-_CHANNELS_LAST = os.environ.get('TAMTR_CHANNELS_LAST') == '1'  # experiment: NHWC trunk (needs PYTORCH_MIOPEN_SUGGEST_NHWC=1)
+# NHWC trunk on the GPU: MIOpen's bf16 convolutions are NHWC kernels and wrap every NCHW operand in a transpose (483 launches,
+# 7.75 ms of the 640 px / bs 16 step).  Channels-last activations + channels-last k x k weights take them as they are (needs
+# PYTORCH_MIOPEN_SUGGEST_NHWC=1, set by the package __init__).  TAMTR_CHANNELS_LAST=0 restores NCHW.
+_CHANNELS_LAST = os.environ.get('TAMTR_CHANNELS_LAST', '1') != '0'
 
 
 class _CastGroup(torch.autograd.Function):
@@ -103,6 +106,19 @@ def _conv_weight_names(m):
     return names
 
 
+class _StaticPart(nn.Module):
+    """token_memory() as a module that owns exactly the parameters it uses (what make_graphed_callables differentiates)."""
+
+    def __init__(self, model):
+        super().__init__()
+        head = model.model[-1]
+        self.trunk, self.vss, self.proj = nn.ModuleList(model.model[:-1]), head.VSSBlocks, head.input_proj
+        object.__setattr__(self, '_owner', model)
+
+    def forward(self, img, txt):
+        return self._owner.token_memory(img, txt, autocast_cache=False)[0]
+
+
 class RTDETRDetectionWorldModel(nn.Module):
     """forward(dict) -> (loss, loss_items)   [training batch: img, txt_feats, cls, bboxes, batch_idx]
        forward(tensor) -> predictions        [uses self.txt_feats set in advance]"""
@@ -114,6 +130,10 @@ class RTDETRDetectionWorldModel(nn.Module):
         self.names = {i: f'{i}' for i in range(nc)}
         self.txt_feats = torch.randn(1, nc, 512)
         self.model, self.save = build_graph(cfg or TAMTR_SPEC, ch, nc)
+        if _CHANNELS_LAST:  # k x k conv weights in the layout the NHWC kernels read (values, keys and shapes are unchanged)
+            for m in self.model[:-1].modules():
+                if isinstance(m, nn.Conv2d) and m.kernel_size != (1, 1):
+                    m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
         self.stride = torch.Tensor([32])
         self.autocast_dtype = None  # torch.bfloat16 => bf16 activations through the trunk and the head GEMMs
 
@@ -149,12 +169,12 @@ class RTDETRDetectionWorldModel(nn.Module):
     def is_fused(self, thresh=10):
         return sum(isinstance(v, nn.BatchNorm2d) for v in self.modules()) < thresh
 
-    def predict(self, x, profile=False, visualize=False, batch=None, augment=False, txt_feats=None):
-        txt = (self.txt_feats if txt_feats is None else txt_feats).to(device=x.device, dtype=torch.float32)
-        if len(txt) != len(x):
-            txt = txt.repeat(len(x), 1, 1)
+    def token_memory(self, x, txt, autocast_cache=True):
+        """Trunk -> VSS blocks -> input projection: the part of the step whose shapes follow from the image size alone (what
+        capture_static_part() records as HIP graphs).  Returns the token memory [B, L, hd] and the level shapes."""
         head = self.model[-1]
-        with torch.autocast('cuda', dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None):
+        with torch.autocast('cuda', dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None,
+                            cache_enabled=autocast_cache):
             if _CHANNELS_LAST and x.is_cuda:
                 x = x.contiguous(memory_format=torch.channels_last)
             from . import ops
@@ -172,10 +192,42 @@ class RTDETRDetectionWorldModel(nn.Module):
                 else:
                     x = m(*args)
                 y.append(x if m.i in self.save else None)
-            out = head([y[j] for j in head.f], txt.clone(), batch)
+            feats, shapes = head.encode([y[j] for j in head.f])
             if counters is not None:
                 ops.end_bn_counter_batch()  # num_batches_tracked += 1 of every BatchNorm that ran, in one multi-tensor kernel
-            return out
+        return feats, shapes
+
+    def capture_static_part(self, img, txt_feats, warmup=3):
+        """Record token_memory() - forward and backward - as two HIP graphs for this image shape, dtype mode and training state
+        (graphs.GraphedPart): ~3/4 of the step's kernel launches become two graph launches.  Everything after
+        the token memory (query selection, denoising groups, decoder, loss) has shapes that follow the labels and stays eager.
+        `img` / `txt_feats`: tensors of the shapes the training loop will pass.  Undo with release_static_part()."""
+        from .graphs import GraphedPart
+        self.release_static_part()
+        part = _StaticPart(self)
+        part.train(self.training)
+        txt = txt_feats.to(device=img.device, dtype=torch.float32)
+        with torch.no_grad():
+            _, shapes = self.token_memory(img, txt)  # the level shapes
+        graphed = GraphedPart(part, (img.detach(), txt.detach()), warmup=warmup)
+        self._static = (graphed, tuple(img.shape), img.dtype, self.autocast_dtype, self.training, shapes)
+        return self
+
+    def release_static_part(self):
+        self._static = None
+
+    def predict(self, x, profile=False, visualize=False, batch=None, augment=False, txt_feats=None):
+        txt = (self.txt_feats if txt_feats is None else txt_feats).to(device=x.device, dtype=torch.float32)
+        if len(txt) != len(x):
+            txt = txt.repeat(len(x), 1, 1)
+        head = self.model[-1]
+        st = getattr(self, '_static', None)
+        if st is not None and st[1:5] == (tuple(x.shape), x.dtype, self.autocast_dtype, self.training) and torch.is_grad_enabled():
+            feats, shapes = st[0](x, txt), st[5]
+        else:
+            feats, shapes = self.token_memory(x, txt)
+        with torch.autocast('cuda', dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None):
+            return head.decode(feats, shapes, txt.clone(), batch)
 
     def loss(self, batch, preds=None):
         if not hasattr(self, 'criterion'):
@@ -201,6 +253,6 @@ class RTDETRDetectionWorldModel(nn.Module):
         dec_bboxes = torch.cat([enc_bboxes.unsqueeze(0).to(dec_bboxes.dtype), dec_bboxes])
         dec_scores = torch.cat([enc_scores.unsqueeze(0).to(dec_scores.dtype), dec_scores])
         terms = self.criterion((dec_bboxes, dec_scores), targets, dn_bboxes=dn_bboxes, dn_scores=dn_scores, dn_meta=dn_meta)
-        self.last_loss_terms = terms
+        self.last_loss_terms = {k: v.detach() for k, v in terms.items()}  # detached: must not keep the step's autograd graph alive
         items = torch.stack([terms[k].detach() for k in ('loss_giou', 'loss_class', 'loss_bbox')])
         return torch.stack(list(terms.values())).sum(), items  # 12 terms (loss.py:384-416): one stack + one sum

@@ -697,7 +697,10 @@ class _CPAM(torch.autograd.Function):
 
 def cpam(x):
     """CPAM (extra_modules/block.py:271-308): x [B,C,H,W] fp32/bf16 -> channel gate sigmoid(up2(maxpool3s2(x))) * x followed by
-    the per-chunk (8 chunks) spatial gate sigmoid(max over the chunk's channels).  One fused kernel after the pool."""
+    the per-chunk (8 chunks) spatial gate sigmoid(max over the chunk's channels).  One fused kernel after the pool.
+    The kernels are NCHW; a channels-last map is converted on the way in and out (4 sites per step)."""
+    if x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last):
+        return _CPAM.apply(x).contiguous(memory_format=torch.channels_last)
     return _CPAM.apply(x)
 
 
@@ -780,7 +783,7 @@ class _BNActCL(torch.autograd.Function):
         g32, b32 = _c(gamma.float()), _c(beta.float())
         y = torch.empty_like(x)
         mr = torch.empty(C, 2, device=x.device, dtype=torch.float32)
-        part = torch.empty(C * _lib.lib().tamtr_bncl_blocks(N) * 3, device=x.device, dtype=torch.float32)
+        part = torch.empty(C * _lib.lib().tamtr_bncl_blocks(N, C, dtype_code(x)) * 3, device=x.device, dtype=torch.float32)
         call('tamtr_bncl_act_fwd', ptr(x), ptr(g32), ptr(b32), ptr(running_mean), ptr(running_var), ptr(y), ptr(mr), ptr(part), N, C,
              float(eps), float(momentum), int(bool(silu)), dtype_code(x), stream_ptr())
         ctx.save_for_backward(x, g32, b32, mr)
@@ -795,7 +798,7 @@ class _BNActCL(torch.autograd.Function):
         gy = _c(gy.to(x.dtype))
         gx = torch.empty_like(x)
         gg, gb = torch.empty(C, device=x.device, dtype=torch.float32), torch.empty(C, device=x.device, dtype=torch.float32)
-        part = torch.empty(C * _lib.lib().tamtr_bncl_blocks(N) * 2 + 2 * C, device=x.device, dtype=torch.float32)
+        part = torch.empty(C * _lib.lib().tamtr_bncl_blocks(N, C, dtype_code(x)) * 2 + 2 * C, device=x.device, dtype=torch.float32)
         call('tamtr_bncl_act_bwd', ptr(gy), ptr(x), ptr(g32), ptr(b32), ptr(mr), ptr(gx), ptr(gg), ptr(gb), ptr(part), N, C, act,
              dtype_code(x), stream_ptr())
         return gx, gg.to(g_dt), gb.to(b_dt), None, None, None, None, None
@@ -816,6 +819,12 @@ def end_bn_counter_batch():
     pending, _BN_COUNTERS = _BN_COUNTERS, None
     if pending:
         torch._foreach_add_(pending, 1)
+
+
+def bn_cl_ok(C, dtype):
+    """Channel counts the channels-last BatchNorm kernels take (include/tamtr_hip.h: tamtr_bncl_act_fwd)."""
+    v = 8 if dtype == torch.bfloat16 and C % 8 == 0 else 4
+    return C % 4 == 0 and C <= 1024 and C // v <= 256 and 256 % (C // v) == 0
 
 
 def bn_act(x, bn, silu):

@@ -127,8 +127,9 @@ def test_full_model_640_fp32_vs_oracle(pkg, case640):
 # loss 1.5e-3; denoising terms <= 1.2e-2; denoising boxes 1.1e-2 max / 1.3e-3 mean; denoising class logits (scale 10) 1.4 max /
 # 0.20 mean).  bf16 keeps 8 significant bits and the graph is ~60 layers deep.  The six terms of the MATCHED queries are not a
 # rounding measure: a 2 % logit change moves a few of the 100 top-k picks and Hungarian pairs, i.e. discrete flips (measured
-# 1e-2 .. 1.8e-1 per term, while their sum stays within 1e-2 of the oracle's) - they get a loose sanity bound only.
-BF16_BOUNDS = {'loss_rel': 1e-2, 'dn_term_rel_max': 4e-2, 'matched_term_rel_max': 0.5, 'dn_box_abs_max': 4e-2, 'dn_box_abs_mean': 4e-3,
+# 1e-2 .. 8e-1 per term: the NCHW trunk gave 7.7e-2 / loss 4.9e-3, the NHWC trunk - same arithmetic, another summation order in
+# BatchNorm - 8.2e-1 on the last layer's class term / loss 1.6e-2) - they and the total get a loose sanity bound only.
+BF16_BOUNDS = {'loss_rel': 3e-2, 'dn_term_rel_max': 4e-2, 'matched_term_rel_max': 1.0, 'dn_box_abs_max': 4e-2, 'dn_box_abs_mean': 4e-3,
                'dn_cls_logit_abs_max': 4.0, 'dn_cls_logit_abs_mean': 0.5}
 
 
@@ -375,12 +376,20 @@ def test_config4_1280_properties(pkg):
     assert y01.shape == (B, 100, 14) and torch.isfinite(y01).all()
     from scipy.optimize import linear_sum_assignment
     for i in range(B):   # as row sets; the invalid border anchors share one score (SURVEY 8g "top-k ties"): where that tie group
-        # straddles rank 100, WHICH of its members are picked is up to top-k's tie-breaking - those rows may differ
-        cost = torch.cdist(y01[i].double().cpu(), y10[B - 1 - i].double().cpu(), p=float('inf'))
+        # straddles rank 100, WHICH of its members are picked is up to top-k's tie-breaking - those rows may differ.  Every row
+        # ranked above the tie group must have an identical partner.
+        a, bb = y01[i].double().cpu(), y10[B - 1 - i].double().cpu()
+        cost = torch.cdist(a, bb, p=float('inf'))
         r, c = linear_sum_assignment(cost.numpy())
-        matched = int((cost[r, c] <= 1e-3).sum())
-        print(f'image {i}: {matched} of 100 rows identical (<= 1e-3) under the batch permutation')
-        assert matched >= 80, matched
+        same = cost[r, c] <= 1e-3
+        score = a[:, 4:].max(-1).values
+        vals, counts = torch.unique((score * 1e4).round(), return_counts=True)
+        tie = float(vals[counts.argmax()]) / 1e4 if int(counts.max()) > 1 else -1.0
+        firm = score[r] > tie + 1e-3
+        print(f'image {i}: {int(same.sum())} of 100 rows identical (<= 1e-3) under the batch permutation; tie score {tie:.4f} shared by '
+              f'{int(counts.max())} rows, {int(firm.sum())} rows above it of which {int((same & firm).sum())} identical')
+        assert int((same & firm).sum()) == int(firm.sum()), (int(same.sum()), int(firm.sum()), int((same & firm).sum()))
+        assert int(same.sum()) >= 50, int(same.sum())
     # (3) training step, bf16 vs fp32 mode
     losses = {}
     for name, dt in (('fp32', None), ('bf16', torch.bfloat16)):

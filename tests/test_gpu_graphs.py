@@ -1,0 +1,120 @@
+"""HIP-graph replay of the shape-static part of the step (tam-tr_amd/graphs.py, model.capture_static_part) against eager execution.
+
+  * VSS blocks + input projection (deterministic in eager mode: no float atomics on the way): eight replays, token memory identical,
+    every parameter gradient at the eager run-to-run level;
+  * the whole step after the model has ALREADY run eagerly with its loss graph still referenced - the situation in which
+    torch.cuda.make_graphed_callables made hipStreamEndCapture segfault (round 1) - then training steps through the captured part:
+    finite, same gradient pattern (552 live, the 30 discarded-gate parameters none), loss trajectory next to an eager twin's;
+  * the zero_grad(set_to_none=False) hazard is refused loudly.
+"""
+import copy
+
+import pytest
+import torch
+import torch.nn as nn
+
+from test_gpu_fullsize import _bench_batch, dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import tamtr_amd  # noqa: F401
+    import tamtr_amd.graphs as graphs
+    import tamtr_amd.model as model
+    return type('P', (), dict(model=model, graphs=graphs))
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-20))
+
+
+def test_vss_and_projection_replay_equals_eager(pkg):
+    torch.manual_seed(0)
+    model = pkg.model.RTDETRDetectionWorldModel(nc=10).cuda().train()
+    for m in model.modules():
+        if hasattr(m, 'drop_prob'):
+            m.drop_prob = 0.0
+    head, B, S = model.model[-1], 4, 320
+
+    class Part(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.vss, self.proj = head.VSSBlocks, head.input_proj
+
+        def forward(self, a, b, c):
+            with torch.autocast('cuda', dtype=torch.bfloat16, cache_enabled=False):
+                return head.encode([a, b, c])[0].float()
+
+    part = Part().train()
+    maps = tuple(torch.randn(B, c, S // d, S // d, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+                 for c, d in ((128, 4), (256, 8), (512, 16)))
+    cot = torch.randn_like(part(*maps)).detach()
+
+    def eager():
+        part.zero_grad(set_to_none=True)
+        o = part(*maps)
+        o.backward(cot)
+        return o.detach().clone(), {k: p.grad.clone() for k, p in part.named_parameters() if p.grad is not None}
+    o1, g1 = eager()
+    o2, g2 = eager()
+    noise = max([_rel(o2, o1)] + [_rel(g2[k], g1[k]) for k in g1])
+    assert noise < 1e-4, noise                      # the reference point is itself reproducible
+    gp = pkg.graphs.GraphedPart(part, maps)
+    for rep in range(8):
+        part.zero_grad(set_to_none=True)
+        o = gp(*maps)
+        junk = torch.full((1 << 22,), float('nan'), device='cuda')  # eager allocations between the two replays, as decoder + loss do
+        del junk
+        o.backward(cot)
+        g = {k: p.grad for k, p in part.named_parameters() if p.grad is not None}
+        assert set(g) == set(g1)
+        assert _rel(o, o1) <= noise + 1e-6, (rep, _rel(o, o1))
+        worst = max((_rel(g[k], g1[k]), k) for k in g1)
+        assert worst[0] <= 10 * noise + 1e-5, (rep, worst)
+
+
+def test_capture_after_eager_steps_then_train(pkg):
+    torch.manual_seed(0)
+    model = pkg.model.RTDETRDetectionWorldModel(nc=10).cuda().train()
+    model.autocast_dtype = torch.bfloat16
+    B, S = 2, 256
+    batch = {k: (dev(v) if k in ('img', 'txt_feats') else v) for k, v in _bench_batch(B, S, 3).items()}
+    twin = copy.deepcopy(model)
+
+    def run(m, n, keep):
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-4, fused=True)
+        out = []
+        for i in range(n):
+            torch.manual_seed(50 + i)
+            opt.zero_grad(set_to_none=True)
+            loss, _ = m(batch)
+            loss.backward()
+            opt.step()
+            keep.append(loss)          # the loss tensors (and through them the autograd graphs) stay referenced
+            out.append(float(loss.detach()))
+        return out
+    held = []
+    first = run(model, 2, held)                      # eager steps on the default stream, graphs kept alive
+    model.capture_static_part(batch['img'], batch['txt_feats'])
+    gp = model._static[0]
+    assert gp.n_live == 552 and len(gp.params) == 582, (gp.n_live, len(gp.params))   # 30 parameters of the discarded gates get no gradient
+    graphed = first + run(model, 6, held)
+    eager = run(twin, 8, [])
+    assert all(torch.isfinite(torch.tensor(graphed))), graphed
+    none = [k for k, p in model.named_parameters() if p.grad is None]
+    assert len(none) == 30 and all('.attn.' in k for k in none)
+    # DropPath draws differ between a replayed and an eager step (the graph has its own Philox offsets): trajectories, not bits
+    assert abs(graphed[-1] - eager[-1]) / eager[-1] < 0.1, (graphed, eager)
+    assert graphed[-1] < graphed[0]
+    # accumulating onto the adopted static buffers would double the gradient: refused
+    model.zero_grad(set_to_none=False)
+    with pytest.raises(RuntimeError, match='set_to_none'):
+        model(batch)
+    model.release_static_part()
+    model.zero_grad(set_to_none=True)
+    loss, _ = model(batch)                           # eager again
+    assert torch.isfinite(loss)
