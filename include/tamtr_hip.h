@@ -278,6 +278,15 @@ int tamtr_bncl_act_fwd(const void* x, const float* gamma, const float* beta, flo
 int tamtr_bncl_act_bwd(const void* gy, const void* x, const float* gamma, const float* beta, const float* mean_rstd, void* gx,
                        float* ggamma, float* gbeta, float* partials, long long N, int C, int act, int dtype, void* stream);
 
+/* ---- layout: NCHW <-> NHWC repacking of a feature map (tiled transpose through LDS).  The trunk runs channels-last around
+ *      MIOpen's NHWC convolutions; the gate (a-1) and CPAM (next-3) kernels read NCHW planes.  Replaces torch's
+ *      `.contiguous()` / `.contiguous(memory_format=torch.channels_last)` on those edges (same values, no arithmetic).
+ *      to_nhwc != 0: src [B, C, HW] -> dst [B, HW, C];  to_nhwc == 0: src [B, HW, C] -> dst [B, C, HW].  T = f32 | bf16.
+ *      ld: pixel pitch of the NHWC side in elements (ld == C: packed; ld > C: a channel slice of a wider map, e.g. one half of
+ *      `cv1(x).chunk(2, 1)`, extra_modules/block.py:147).
+ */
+int tamtr_relayout(const void* src, void* dst, int B, int C, int HW, int ld, int to_nhwc, int dtype, void* stream);
+
 /* ---- data path: the pixel half of the training transforms on the device.
  *      Replaces, for a whole batch and in this order: cv2.warpAffine(img, M[:2], dsize, borderValue=114) of RandomPerspective
  *      (ultralytics/data/augment.py:415-420), the BGR2HSV -> LUT -> HSV2BGR chain of RandomHSV (:590-609), RandomFlip's

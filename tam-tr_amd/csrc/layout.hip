@@ -1,0 +1,77 @@
+// layout.hip - NCHW <-> NHWC repacking of a feature map, gfx950.
+//
+// The trunk runs channels-last (MIOpen's bf16 convolutions are NHWC kernels); the gate and CPAM kernels (gate.hip, cpam.hip) are
+// written for NCHW planes.  torch's generic strided copy moved the [16, 128, 160, 160] map of CPAM site 33 at 0.4 TB/s (262 us per
+// direction, four times per step).  This is the plain tiled transpose of the per-image [C, HW] matrix: a 64 x 64 tile goes through
+// LDS, global reads run along the source's contiguous axis and global writes along the destination's, 8 bytes (bf16) / 16 bytes
+// (fp32) per lane.  HBM-bound: 2 x map bytes.
+#include "common.h"
+
+namespace {
+
+constexpr int LT = 64;          // tile edge
+constexpr int L_THREADS = 256;
+
+// src: [B][R][S] (S contiguous, row pitch lds)  ->  dst: [B][S][R] (R contiguous, row pitch ldd).  grid: (ceil(S / 64), ceil(R / 64), B)
+template <typename E>
+__global__ __launch_bounds__(L_THREADS) void transpose_tiles_kernel(const E* __restrict__ src, E* __restrict__ dst, int R, int S, int lds,
+                                                                    int ldd, int vec) {
+  __shared__ E tile[LT][LT + 4 / sizeof(E) + 1];
+  const int s0 = blockIdx.x * LT, r0 = blockIdx.y * LT;
+  const size_t splane = (size_t)blockIdx.z * R * lds, dplane = (size_t)blockIdx.z * S * ldd;
+  const int q = (threadIdx.x % 16) * 4, row = threadIdx.x / 16;
+  // read: 16 lanes x 4 elements along S per source row, 16 rows per pass
+#pragma unroll
+  for (int k = 0; k < LT; k += 16) {
+    const int r = r0 + row + k, s = s0 + q;
+    if (r < R) {
+      const E* p = src + splane + (size_t)r * lds + s;
+      if (vec && s + 3 < S) {
+        E v[4];
+        __builtin_memcpy(v, __builtin_assume_aligned(p, 4 * sizeof(E)), 4 * sizeof(E));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tile[row + k][q + i] = v[i];
+      } else {
+        for (int i = 0; i < 4; ++i) if (s + i < S) tile[row + k][q + i] = p[i];
+      }
+    }
+  }
+  __syncthreads();
+  // write: 16 lanes x 4 elements along R per destination row
+#pragma unroll
+  for (int k = 0; k < LT; k += 16) {
+    const int s = s0 + row + k, r = r0 + q;
+    if (s < S) {
+      E* p = dst + dplane + (size_t)s * ldd + r;
+      if (vec && r + 3 < R) {
+        E v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = tile[q + i][row + k];
+        __builtin_memcpy(__builtin_assume_aligned(p, 4 * sizeof(E)), v, 4 * sizeof(E));
+      } else {
+        for (int i = 0; i < 4; ++i) if (r + i < R) p[i] = tile[q + i][row + k];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// to_nhwc != 0: src [B, C, HW] -> dst [B, HW, C];  to_nhwc == 0: src [B, HW, C] -> dst [B, C, HW].  The NHWC side may be a channel
+// slice of a wider map: its pixel pitch is ld >= C elements (ld == C: packed).
+extern "C" int tamtr_relayout(const void* src, void* dst, int B, int C, int HW, int ld, int to_nhwc, int dtype, void* stream) {
+  if (!src || !dst || B <= 0 || C <= 0 || HW <= 0 || ld < C) return TAMTR_EINVAL;
+  if (dtype != TAMTR_F32 && dtype != TAMTR_BF16) return TAMTR_EINVAL;
+  const int R = to_nhwc ? C : HW, S = to_nhwc ? HW : C;
+  const unsigned gx = (S + LT - 1) / LT, gy = (R + LT - 1) / LT;
+  if (B > 65535 || gy > 65535) return TAMTR_EUNSUP;
+  const int e = dtype == TAMTR_F32 ? 4 : 2;
+  const int lds = to_nhwc ? HW : ld, ldd = to_nhwc ? ld : HW;
+  const int vec = R % 4 == 0 && S % 4 == 0 && ld % 4 == 0 && ((uintptr_t)src % (4 * e)) == 0 && ((uintptr_t)dst % (4 * e)) == 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == TAMTR_F32)
+    hipLaunchKernelGGL(transpose_tiles_kernel<uint32_t>, dim3(gx, gy, B), dim3(L_THREADS), 0, s, (const uint32_t*)src, (uint32_t*)dst, R, S, lds, ldd, vec);
+  else
+    hipLaunchKernelGGL(transpose_tiles_kernel<uint16_t>, dim3(gx, gy, B), dim3(L_THREADS), 0, s, (const uint16_t*)src, (uint16_t*)dst, R, S, lds, ldd, vec);
+  return tamtr_launch_status();
+}

@@ -29,7 +29,8 @@ class GraphedPart:
     def __init__(self, module, sample_args, warmup=3):
         if not all(isinstance(a, torch.Tensor) and a.is_cuda for a in sample_args):
             raise ValueError('sample_args must be CUDA tensors')
-        if os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') != '0':
+        from . import GRAPH_REPLAY_SAFE
+        if os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') != '0' or not GRAPH_REPLAY_SAFE:
             raise RuntimeError('GraphedPart needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before the HIP runtime starts (see the module docstring)')
         self.module = module
         self.names, self.params = zip(*[(n, p) for n, p in module.named_parameters()])

@@ -22,6 +22,60 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# ------------------------------------------------------------------------------------------------ layout edges
+def _is_cl(t):
+    return t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def _cl_pitch(t):
+    """Pixel pitch ld if t [B,C,H,W] is a channels-last map or a channel slice of one (strides (H*W*ld, 1, W*ld, ld), ld >= C), else 0."""
+    if t.dim() != 4:
+        return 0
+    B, C, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    ok = sc == 1 and sw >= C and sh == W * sw and (B == 1 or sb == H * W * sw)
+    return sw if ok else 0
+
+
+class _Relayout(torch.autograd.Function):
+    """Channels-last map -> NCHW-contiguous copy (to_nchw) or back, by the tiled transpose of csrc/layout.hip; values unchanged.
+    The backward is the opposite repacking of the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, to_nchw):
+        require_gpu(x)
+        ctx.to_nchw = to_nchw
+        return _relayout(x, to_nchw)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.to_nchw:   # gradient arrives NCHW-shaped; hand it back channels-last like the input was
+            return (_relayout(g, False) if g.is_contiguous() else g.contiguous(memory_format=torch.channels_last)), None
+        return (_relayout(g, True) if _cl_pitch(g) else g.contiguous()), None
+
+
+def _relayout(x, to_nchw):
+    B, C, H, W = x.shape
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        return x.contiguous() if to_nchw else x.contiguous(memory_format=torch.channels_last)
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device, memory_format=torch.contiguous_format if to_nchw else torch.channels_last)
+    call('tamtr_relayout', ptr(x), ptr(out), B, C, H * W, _cl_pitch(x) if to_nchw else C, 0 if to_nchw else 1, dtype_code(x), stream_ptr())
+    return out
+
+
+def to_nchw(x):
+    """NCHW-contiguous version of a feature map; a channels-last one (or a channel slice of one) goes through the transpose kernel."""
+    if x.is_contiguous():
+        return x
+    return _Relayout.apply(x, True) if (x.is_cuda and _cl_pitch(x)) else x.contiguous()
+
+
+def to_channels_last(x):
+    if x.dim() != 4 or _is_cl(x):
+        return x
+    return _Relayout.apply(x, False) if (x.is_contiguous() and x.is_cuda) else x.contiguous(memory_format=torch.channels_last)
+
+
 # ------------------------------------------------------------------------------------------------ a-1 text gate
 class _MaxSigmoidGate(torch.autograd.Function):
     """out = v * sigmoid(max_n <x, gk_n> / sqrt(hc) + bias) * scale  (extra_modules/block.py:217-226)."""
@@ -32,7 +86,7 @@ class _MaxSigmoidGate(torch.autograd.Function):
         B, C, H, W = x.shape
         T = gk.shape[1]
         hc = C // nh
-        x, v = _c(x), _c(v)
+        x, v = to_nchw(x), to_nchw(v)   # the kernels read NCHW planes; channels-last maps (NHWC trunk) are repacked
         gk32, b32 = _c(gk.float()), _c(bias.float())
         out = torch.empty_like(x)
         aw = torch.empty(B, nh, H * W, device=x.device, dtype=torch.float32)
@@ -698,9 +752,9 @@ class _CPAM(torch.autograd.Function):
 def cpam(x):
     """CPAM (extra_modules/block.py:271-308): x [B,C,H,W] fp32/bf16 -> channel gate sigmoid(up2(maxpool3s2(x))) * x followed by
     the per-chunk (8 chunks) spatial gate sigmoid(max over the chunk's channels).  One fused kernel after the pool.
-    The kernels are NCHW; a channels-last map is converted on the way in and out (4 sites per step)."""
-    if x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last):
-        return _CPAM.apply(x).contiguous(memory_format=torch.channels_last)
+    The kernels are NCHW; a channels-last map is repacked on the way in and out (csrc/layout.hip; 4 sites per step)."""
+    if _is_cl(x):
+        return to_channels_last(_CPAM.apply(to_nchw(x)))
     return _CPAM.apply(x)
 
 

@@ -1,6 +1,9 @@
 import os
 import sys
 
+# read by the HIP runtime when it starts (the first torch.cuda call of a test may come before the package import): tam-tr_amd/graphs.py
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+
 import numpy as np
 import pytest
 import torch

@@ -503,3 +503,26 @@ def test_img_augment_matches_host_kernels_bit_for_bit(ops, tmp_path):
     with pytest.raises(Exception):
         ops.img_augment(torch.zeros(1, 4, 4, 3), torch.zeros(1, 6, dtype=torch.float64), torch.zeros(1, 3, 256, dtype=torch.uint8),
                         torch.zeros(1, dtype=torch.int32), (4, 4))
+
+
+# ------------------------------------------------------------------------------------------------ layout edges (csrc/layout.hip)
+@pytest.mark.parametrize('B,C,H,W,dt', [(2, 64, 16, 16, torch.bfloat16), (3, 50, 7, 11, torch.float32), (2, 128, 40, 40, torch.bfloat16),
+                                        (1, 6, 5, 13, torch.bfloat16), (2, 256, 20, 24, torch.float32)])
+def test_relayout_is_a_pure_permutation(ops, B, C, H, W, dt):
+    """NHWC <-> NCHW repacking against torch's own .contiguous(): bit-identical both ways, also from a channel slice of a wider
+    channels-last map (`cv1(x).chunk(2, 1)`), and as an autograd edge (the gradient comes back in the input's layout)."""
+    x = rnd((B, C, H, W), 5).to(dt).cuda()
+    xcl = x.contiguous(memory_format=torch.channels_last)
+    a = ops.to_nchw(xcl)
+    assert a.is_contiguous() and torch.equal(a, x)
+    b = ops.to_channels_last(x)
+    assert b.is_contiguous(memory_format=torch.channels_last) and torch.equal(b, x) and b.stride() == xcl.stride()
+    wide = rnd((B, 2 * C, H, W), 6).to(dt).cuda().contiguous(memory_format=torch.channels_last)
+    for half in wide.chunk(2, 1):
+        assert ops._cl_pitch(half) == 2 * C
+        c = ops.to_nchw(half)
+        assert c.is_contiguous() and torch.equal(c, half.contiguous())
+    xg = xcl.clone().requires_grad_()
+    cot = rnd((B, C, H, W), 7).to(dt).cuda()
+    (ops.to_nchw(xg) * cot).sum().backward()
+    assert torch.equal(xg.grad, cot) and xg.grad.is_contiguous(memory_format=torch.channels_last)

@@ -6,6 +6,7 @@
   static  model.capture_static_part(): trunk + VSS + input projection; 10 eager vs 10 graphed training steps, same seeds"""
 import faulthandler, os, sys, time
 faulthandler.enable()
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', os.environ.get('PACKET_CAPTURE', '0'))  # PACKET_CAPTURE=1 reproduces the garbage replays
 import torch
 import torch.nn as nn
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
