@@ -195,47 +195,65 @@ def process_batch(detections, labels, iouv=IOUV):
 
 
 def smooth(y, f=0.05):
-    nf = round(len(y) * f * 2) // 2 + 1
-    p = np.ones(nf // 2)
-    yp = np.concatenate((p * y[0], y, p * y[-1]), 0)
-    return np.convolve(yp, np.ones(nf) / nf, mode='valid')
+    """Centred moving average of y over an odd window of about 2*f*len(y) samples; beyond the ends y is held at y[0] / y[-1].
+    (metrics.py:941-946 does the same with a padded convolution; here a running sum.)"""
+    win = round(len(y) * f * 2) // 2 + 1
+    half = win // 2
+    held = np.concatenate((np.full(half, y[0]), y, np.full(half, y[-1])))
+    run = np.concatenate(([0.0], np.cumsum(held)))
+    return (run[win:win + len(held) - win + 1] - run[:len(held) - win + 1]) / win
+
+
+_AP_GRID = np.linspace(0.0, 1.0, 101)   # COCO's 101 recall samples
 
 
 def compute_ap(recall, precision):
-    mrec = np.concatenate(([0.0], recall, [1.0]))
-    mpre = np.concatenate(([1.0], precision, [0.0]))
-    mpre = np.flip(np.maximum.accumulate(np.flip(mpre)))
-    x = np.linspace(0, 1, 101)
-    return np.trapezoid(np.interp(x, mrec, mpre), x), mpre, mrec
+    """Area under the precision envelope sampled on the 101-point recall grid (metrics.py:999-1029).  recall, precision: the
+    cumulative curves of one class at one IoU threshold, in descending-confidence order.  Returns (ap, envelope, recall knots)."""
+    knots_r = np.empty(len(recall) + 2)
+    knots_p = np.empty(len(precision) + 2)
+    knots_r[0], knots_r[1:-1], knots_r[-1] = 0.0, recall, 1.0
+    knots_p[0], knots_p[1:-1], knots_p[-1] = 1.0, precision, 0.0
+    envelope = np.maximum.accumulate(knots_p[::-1])[::-1]        # best precision attainable at recall >= r
+    y = np.interp(_AP_GRID, knots_r, envelope)
+    h = _AP_GRID[1] - _AP_GRID[0]
+    area = h * (y.sum() - 0.5 * (y[0] + y[-1]))                   # trapezoid rule on the uniform grid
+    return area, envelope, knots_r
+
+
+def _curves_of_class(hit, score, n_gt, grid, eps):
+    """hit [n, T] bool (descending score), score [n]: recall / precision of the first IoU threshold resampled on `grid` (confidence
+    axis) and the AP of every threshold."""
+    tp_run = hit.cumsum(0)
+    fp_run = (1 - hit).cumsum(0)
+    recall = tp_run / (n_gt + eps)
+    precision = tp_run / (tp_run + fp_run)
+    r_grid = np.interp(-grid, -score, recall[:, 0], left=0)          # confidence decreases along the arrays: negate to interpolate
+    p_grid = np.interp(-grid, -score, precision[:, 0], left=1)
+    ap = np.array([compute_ap(recall[:, t], precision[:, t])[0] for t in range(hit.shape[1])])
+    return r_grid, p_grid, ap
 
 
 def ap_per_class(tp, conf, pred_cls, target_cls, eps=1e-16):
-    """-> tp, fp, p, r, f1 (at the max-F1 confidence), ap [nc, 10], unique_classes."""
-    i = np.argsort(-conf)
-    tp, conf, pred_cls = tp[i], conf[i], pred_cls[i]
-    unique_classes, nt = np.unique(target_cls, return_counts=True)
-    nc = unique_classes.shape[0]
-    x = np.linspace(0, 1, 1000)
-    ap, p_curve, r_curve = np.zeros((nc, tp.shape[1])), np.zeros((nc, 1000)), np.zeros((nc, 1000))
-    for ci, c in enumerate(unique_classes):
-        i = pred_cls == c
-        n_l, n_p = nt[ci], i.sum()
-        if n_p == 0 or n_l == 0:
+    """-> tp, fp, p, r, f1 (at the max-F1 confidence), ap [nc, 10], unique_classes   (metrics.py:1032-1128, plots dropped).
+    Classes are the ones that have ground truth; a class nobody predicted keeps zero curves."""
+    order = np.argsort(-conf)
+    tp, conf, pred_cls = tp[order], conf[order], pred_cls[order]
+    classes, n_gt = np.unique(target_cls, return_counts=True)
+    grid = np.linspace(0, 1, 1000)
+    ap = np.zeros((len(classes), tp.shape[1]))
+    p_curve, r_curve = np.zeros((len(classes), grid.size)), np.zeros((len(classes), grid.size))
+    for row, (c, n) in enumerate(zip(classes, n_gt)):
+        mine = pred_cls == c
+        if n == 0 or not mine.any():
             continue
-        fpc = (1 - tp[i]).cumsum(0)
-        tpc = tp[i].cumsum(0)
-        recall = tpc / (n_l + eps)
-        r_curve[ci] = np.interp(-x, -conf[i], recall[:, 0], left=0)
-        precision = tpc / (tpc + fpc)
-        p_curve[ci] = np.interp(-x, -conf[i], precision[:, 0], left=1)
-        for j in range(tp.shape[1]):
-            ap[ci, j], _, _ = compute_ap(recall[:, j], precision[:, j])
+        r_curve[row], p_curve[row], ap[row] = _curves_of_class(tp[mine], conf[mine], n, grid, eps)
     f1_curve = 2 * p_curve * r_curve / (p_curve + r_curve + eps)
-    i = smooth(f1_curve.mean(0), 0.1).argmax()
-    p, r, f1 = p_curve[:, i], r_curve[:, i], f1_curve[:, i]
-    tpn = (r * nt).round()
+    best = smooth(f1_curve.mean(0), 0.1).argmax()                       # one operating confidence for all classes
+    p, r, f1 = p_curve[:, best], r_curve[:, best], f1_curve[:, best]
+    tpn = (r * n_gt).round()
     fpn = (tpn / (p + eps) - tpn).round()
-    return tpn, fpn, p, r, f1, ap, unique_classes.astype(int)
+    return tpn, fpn, p, r, f1, ap, classes.astype(int)
 
 
 class Validator:
