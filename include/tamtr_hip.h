@@ -287,6 +287,19 @@ int tamtr_bncl_act_bwd(const void* gy, const void* x, const float* gamma, const 
  */
 int tamtr_relayout(const void* src, void* dst, int B, int C, int HW, int ld, int to_nhwc, int dtype, void* stream);
 
+/* ---- max pooling k x k / stride s / padding p (floor mode), NCHW (nhwc = 0) or NHWC (nhwc = 1) maps.  Replaces nn.MaxPool2d as
+ *      used by SPPELAN (5/1/2, three chained: ultralytics/nn/extra_modules/block.py:255-268) and by CPAM's channel gate (3/2/1,
+ *      block.py:274), forward and backward.  code: one byte per output element = position of the winner inside the unclipped
+ *      window (row-major; first maximum wins, NaN wins over everything - torch's rule).  The backward gathers (no atomics).
+ *      addend (T, same layout as gx, may be NULL): gx = addend + pooled gradient (CPAM adds its direct term this way).
+ *      x, gx (T) [B,C,H,W] in the given layout; y, gy (T) and code (u8) [B,C,Ho,Wo], Ho = tamtr_maxpool_out(H, k, s, p).  k <= 15.
+ */
+int tamtr_maxpool_out(int n, int k, int s, int p);
+int tamtr_maxpool_fwd(const void* x, void* y, uint8_t* code, int B, int C, int H, int W, int k, int s, int p, int nhwc, int dtype,
+                      void* stream);
+int tamtr_maxpool_bwd(const void* gy, const uint8_t* code, const void* addend, void* gx, int B, int C, int H, int W, int k, int s, int p, int nhwc, int dtype,
+                      void* stream);
+
 /* ---- data path: the pixel half of the training transforms on the device.
  *      Replaces, for a whole batch and in this order: cv2.warpAffine(img, M[:2], dsize, borderValue=114) of RandomPerspective
  *      (ultralytics/data/augment.py:415-420), the BGR2HSV -> LUT -> HSV2BGR chain of RandomHSV (:590-609), RandomFlip's

@@ -150,9 +150,10 @@ class SPPELAN(nn.Module):
         self.cv5 = Conv(4 * c3, c2, 1, 1)
 
     def forward(self, x):
+        from . import ops
         y = [self.cv1(x)]
         for _ in range(3):
-            y.append(F.max_pool2d(y[-1], 5, 1, 2))
+            y.append(ops.max_pool2d(y[-1], 5, 1, 2) if y[-1].is_cuda else F.max_pool2d(y[-1], 5, 1, 2))
         return self.cv5(torch.cat(y, 1))
 
 

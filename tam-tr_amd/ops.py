@@ -76,6 +76,43 @@ def to_channels_last(x):
     return _Relayout.apply(x, False) if (x.is_contiguous() and x.is_cuda) else x.contiguous(memory_format=torch.channels_last)
 
 
+class _MaxPool(torch.autograd.Function):
+    """nn.MaxPool2d(k, s, p) on an NCHW or channels-last map - csrc/pool.hip (one-byte winner codes, gather backward)."""
+
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        require_gpu(x)
+        nhwc = _is_cl(x)
+        if not nhwc:
+            x = _c(x)
+        B, C, H, W = x.shape
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        fmt = torch.channels_last if nhwc else torch.contiguous_format
+        y = torch.empty((B, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=fmt)
+        code = torch.empty((B, C, Ho, Wo), dtype=torch.uint8, device=x.device, memory_format=fmt)
+        call('tamtr_maxpool_fwd', ptr(x), ptr(y), ptr(code), B, C, H, W, k, s, p, int(nhwc), dtype_code(x), stream_ptr())
+        ctx.save_for_backward(code)
+        ctx.cfg = (B, C, H, W, k, s, p, nhwc, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        code, = ctx.saved_tensors
+        B, C, H, W, k, s, p, nhwc, dt = ctx.cfg
+        gy = gy.to(dt)
+        gy = gy.contiguous(memory_format=torch.channels_last) if nhwc else _c(gy)
+        gx = torch.empty((B, C, H, W), dtype=dt, device=gy.device, memory_format=torch.channels_last if nhwc else torch.contiguous_format)
+        call('tamtr_maxpool_bwd', ptr(gy), ptr(code), None, ptr(gx), B, C, H, W, k, s, p, int(nhwc), dtype_code(gy), stream_ptr())
+        return gx, None, None, None
+
+
+def max_pool2d(x, k, s, p):
+    """F.max_pool2d(x, k, s, p) for fp32 / bf16 CUDA maps (NCHW or channels-last); anything else goes to torch."""
+    if x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and k <= 15 and 2 * p <= k:
+        return _MaxPool.apply(x, int(k), int(s), int(p))
+    return torch.nn.functional.max_pool2d(x, k, s, p)
+
+
 # ------------------------------------------------------------------------------------------------ a-1 text gate
 class _MaxSigmoidGate(torch.autograd.Function):
     """out = v * sigmoid(max_n <x, gk_n> / sqrt(hc) + bias) * scale  (extra_modules/block.py:217-226)."""
@@ -729,7 +766,10 @@ class _CPAM(torch.autograd.Function):
         require_gpu(x)
         x = _c(x)
         B, C, H, W = x.shape
-        p, idx = torch.nn.functional.max_pool2d(x, 3, 2, 1, return_indices=True)  # ChannelAttentionModule.Maxpool (block.py:274)
+        Hp, Wp = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        p = torch.empty(B, C, Hp, Wp, dtype=x.dtype, device=x.device)   # ChannelAttentionModule.Maxpool 3/2/1 (block.py:274): csrc/pool.hip
+        idx = torch.empty(B, C, Hp, Wp, dtype=torch.uint8, device=x.device)
+        call('tamtr_maxpool_fwd', ptr(x), ptr(p), ptr(idx), B, C, H, W, 3, 2, 1, 0, dtype_code(x), stream_ptr())
         out = torch.empty_like(x)
         s2 = torch.empty(B, 8, H, W, device=x.device, dtype=torch.float32)
         arg = torch.empty(B, 8, H, W, device=x.device, dtype=torch.int32)
@@ -745,8 +785,9 @@ class _CPAM(torch.autograd.Function):
         dxd, du, dp = torch.empty_like(x), torch.empty_like(x), torch.empty_like(p)
         call('tamtr_cpam_bwd', ptr(gout), ptr(x), ptr(p), ptr(s2), ptr(arg), ptr(dxd), ptr(du), ptr(dp), B, C, H, W, dtype_code(x),
              stream_ptr())
-        dx = torch.ops.aten.max_pool2d_with_indices_backward(dp, x, [3, 3], [2, 2], [1, 1], [1, 1], False, idx)
-        return dx.add_(dxd)
+        dx = torch.empty_like(x)
+        call('tamtr_maxpool_bwd', ptr(dp), ptr(idx), ptr(dxd), ptr(dx), B, C, H, W, 3, 2, 1, 0, dtype_code(x), stream_ptr())  # + the direct term
+        return dx
 
 
 def cpam(x):

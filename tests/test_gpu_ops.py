@@ -6,6 +6,7 @@ bf16 rounding (documented per test).  Run with `pytest -m gpu` on an MI355X.
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import T, assert_close, check_param_grads, check_summary
 from oracle import tamtr_oracle as O
@@ -526,3 +527,26 @@ def test_relayout_is_a_pure_permutation(ops, B, C, H, W, dt):
     cot = rnd((B, C, H, W), 7).to(dt).cuda()
     (ops.to_nchw(xg) * cot).sum().backward()
     assert torch.equal(xg.grad, cot) and xg.grad.is_contiguous(memory_format=torch.channels_last)
+
+
+# ------------------------------------------------------------------------------------------------ max pooling (csrc/pool.hip)
+@pytest.mark.parametrize('B,C,H,W,k,s,p,dt,cl', [(2, 16, 20, 20, 5, 1, 2, torch.bfloat16, True), (2, 8, 17, 23, 3, 2, 1, torch.float32, False),
+                                                 (1, 32, 40, 40, 3, 2, 1, torch.bfloat16, False), (2, 6, 9, 9, 5, 1, 2, torch.float32, True),
+                                                 (1, 4, 8, 10, 2, 2, 0, torch.float32, False)])
+def test_max_pool_vs_torch(ops, B, C, H, W, k, s, p, dt, cl):
+    """SPPELAN's 5/1/2 pools (block.py:255-268) and CPAM's 3/2/1 pool (block.py:274) against F.max_pool2d on the CPU: values
+    bit-identical, gradients routed to the same winners (bf16 inputs tie often: the first maximum in window order must win)."""
+    x = rnd((B, C, H, W), 11).to(dt)
+    xr = x.float().clone().requires_grad_()
+    ref = F.max_pool2d(xr, k, s, p)
+    cot = rnd(tuple(ref.shape), 12).to(dt).float()
+    (ref * cot).sum().backward()
+    xd = x.cuda()
+    if cl:
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    xd.requires_grad_()
+    out = ops.max_pool2d(xd, k, s, p)
+    assert out.is_contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format)
+    assert torch.equal(out.float().cpu(), ref.detach())
+    (out.float() * cot.cuda()).sum().backward()
+    assert_close(xd.grad.float().cpu(), xr.grad, 1e-2 if dt == torch.bfloat16 else 1e-6, 1e-6, 'maxpool dx')
