@@ -270,13 +270,14 @@ int tamtr_bn_act_bwd(const void* gy, const void* x, const float* gamma, const fl
 /*      Channels-last variant (token-major maps, e.g. the MEH input projection output [B*L, hd] of head.py:1087 run as a GEMM):
  *      x, y, gy, gx (T) [N, C], C contiguous and 16-byte aligned, C <= 1024, C % 4 == 0 and 256 % (C / V) == 0 with V = 8 for
  *      bf16 maps with C % 8 == 0, else 4.  partials: caller workspace of S = tamtr_bncl_blocks(N, C, dtype) chunks:
- *      C * S * 3 floats (forward) / C * S * 2 + 2 * C floats (backward).
+ *      C * S * 3 floats (forward) / C * S * 2 + 2 * C floats (backward).  ldgy: row pitch of gy in elements (C = packed; larger when
+ *      the gradient is a channel slice of the gradient of a `torch.cat(..., 1)`, so that no packing copy is needed).
  */
 int tamtr_bncl_blocks(long long N, int C, int dtype);
 int tamtr_bncl_act_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y,
                        float* mean_rstd, float* partials, long long N, int C, float eps, float momentum, int act, int dtype, void* stream);
-int tamtr_bncl_act_bwd(const void* gy, const void* x, const float* gamma, const float* beta, const float* mean_rstd, void* gx,
-                       float* ggamma, float* gbeta, float* partials, long long N, int C, int act, int dtype, void* stream);
+int tamtr_bncl_act_bwd(const void* gy, long long ldgy, const void* x, const float* gamma, const float* beta, const float* mean_rstd,
+                       void* gx, float* ggamma, float* gbeta, float* partials, long long N, int C, int act, int dtype, void* stream);
 
 /* ---- layout: NCHW <-> NHWC repacking of a feature map (tiled transpose through LDS).  The trunk runs channels-last around
  *      MIOpen's NHWC convolutions; the gate (a-1) and CPAM (next-3) kernels read NCHW planes.  Replaces torch's
@@ -286,6 +287,9 @@ int tamtr_bncl_act_bwd(const void* gy, const void* x, const float* gamma, const 
  *      `cv1(x).chunk(2, 1)`, extra_modules/block.py:147).
  */
 int tamtr_relayout(const void* src, void* dst, int B, int C, int HW, int ld, int to_nhwc, int dtype, void* stream);
+/*      Channel-slice copy on channels-last maps: dst[r][0..C) = src[r][0..C), N = B*H*W rows, row pitches lds / ldd elements.
+ *      Replaces the strided copies behind `torch.cat(y, 1)` / `x.chunk(2, 1)` (extra_modules/block.py:133,147,152) in NHWC. */
+int tamtr_copy_rows(const void* src, long long lds, void* dst, long long ldd, long long N, int C, int dtype, void* stream);
 
 /* ---- max pooling k x k / stride s / padding p (floor mode), NCHW (nhwc = 0) or NHWC (nhwc = 1) maps.  Replaces nn.MaxPool2d as
  *      used by SPPELAN (5/1/2, three chained: ultralytics/nn/extra_modules/block.py:255-268) and by CPAM's channel gate (3/2/1,

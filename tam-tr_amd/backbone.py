@@ -118,7 +118,8 @@ class RepNCSP(nn.Module):
         self.m = nn.Sequential(*(RepNBottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)))
 
     def forward(self, x):
-        return self.cv3(torch.cat((self.m(self.cv1(x)), self.cv2(x)), 1))
+        from . import ops
+        return self.cv3(ops.cat_channels((self.m(self.cv1(x)), self.cv2(x))))
 
 
 class RepNCSPELAN4(nn.Module):
@@ -133,13 +134,15 @@ class RepNCSPELAN4(nn.Module):
         self.cv4 = Conv(c3 + 2 * c4, c2, 1, 1)
 
     def branches(self, x):
+        from . import ops
         y = list(self.cv1(x).chunk(2, 1))
-        y.append(self.cv2(y[-1]))
+        y.append(self.cv2(ops.pack_channels(y[-1])))   # one packed copy of the half for the two convolutions that read it
         y.append(self.cv3(y[-1]))
         return y
 
     def forward(self, x):
-        return self.cv4(torch.cat(self.branches(x), 1))
+        from . import ops
+        return self.cv4(ops.cat_channels(self.branches(x)))
 
 
 class SPPELAN(nn.Module):
@@ -154,7 +157,7 @@ class SPPELAN(nn.Module):
         y = [self.cv1(x)]
         for _ in range(3):
             y.append(ops.max_pool2d(y[-1], 5, 1, 2) if y[-1].is_cuda else F.max_pool2d(y[-1], 5, 1, 2))
-        return self.cv5(torch.cat(y, 1))
+        return self.cv5(ops.cat_channels(y))
 
 
 class CPAM(nn.Module):
@@ -192,4 +195,7 @@ class Concat(nn.Module):
         self.d = dimension
 
     def forward(self, x):
+        if self.d == 1:
+            from . import ops
+            return ops.cat_channels(x)
         return torch.cat(x, self.d)

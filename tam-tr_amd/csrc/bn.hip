@@ -374,7 +374,7 @@ template <typename T, int V>
 __global__ __launch_bounds__(BN_THREADS) void bncl_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restrict__ x,
                                                                       const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                                       const float* __restrict__ beta, float* __restrict__ part, size_t total,
-                                                                      int C, int iters, int act) {
+                                                                      int C, int iters, int act, size_t ldgy, int cshift) {
   __shared__ float s_acc[BN_THREADS * 2 * V];
   __shared__ float s_col[2 * 1024];
   const size_t piece = (size_t)BN_THREADS * V, start = (size_t)blockIdx.x * iters * piece, end = min(total, start + iters * piece);
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(BN_THREADS) void bncl_bwd_reduce_kernel(const T* __
     for (int u = 0; u < CL_UNROLL; ++u) {
       const size_t e = e0 + (size_t)(it + u) * piece, ee = e < end ? e : home;
       Vec<T, V>::ld(x + ee, xv[u]);
-      Vec<T, V>::ld(gy + ee, gv[u]);
+      Vec<T, V>::ld(gy + (ee >> cshift) * ldgy + (ee & (size_t)(C - 1)), gv[u]);   // gy may be a channel slice of a wider map
     }
 #pragma unroll
     for (int u = 0; u < CL_UNROLL; ++u) {
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(BN_THREADS) void bncl_bwd_apply_kernel(const T* __r
                                                                      const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                                      const float* __restrict__ beta, const float* __restrict__ sums,
                                                                      T* __restrict__ gx, size_t total, int C, int iters, int act,
-                                                                     float inv_count) {
+                                                                     float inv_count, size_t ldgy, int cshift) {
   const size_t piece = (size_t)BN_THREADS * V, start = (size_t)blockIdx.x * iters * piece, end = min(total, start + iters * piece);
   const int c0 = (threadIdx.x % (C / V)) * V;
   const size_t home = start + c0;   // first row of the chunk: where a load past the end is redirected
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(BN_THREADS) void bncl_bwd_apply_kernel(const T* __r
     for (int u = 0; u < CL_UNROLL; ++u) {
       const size_t e = e0 + (size_t)(it + u) * piece, ee = e < end ? e : home;
       Vec<T, V>::ld(x + ee, xv[u]);
-      Vec<T, V>::ld(gy + ee, gv[u]);
+      Vec<T, V>::ld(gy + (ee >> cshift) * ldgy + (ee & (size_t)(C - 1)), gv[u]);   // gy may be a channel slice of a wider map
     }
 #pragma unroll
     for (int u = 0; u < CL_UNROLL; ++u) {
@@ -565,10 +565,14 @@ extern "C" int tamtr_bncl_act_fwd(const void* x, const float* gamma, const float
   return tamtr_launch_status();
 }
 
-extern "C" int tamtr_bncl_act_bwd(const void* gy, const void* x, const float* gamma, const float* beta, const float* mean_rstd, void* gx,
-                                  float* ggamma, float* gbeta, float* partials, long long N, int C, int act, int dtype, void* stream) {
+extern "C" int tamtr_bncl_act_bwd(const void* gy, long long ldgy, const void* x, const float* gamma, const float* beta,
+                                  const float* mean_rstd, void* gx, float* ggamma, float* gbeta, float* partials, long long N, int C, int act,
+                                  int dtype, void* stream) {
   const int rc = bncl_check(gy, x, N, C, dtype, act);
   if (rc) return rc;
+  if (ldgy < C || ldgy % bncl_vec(C, dtype) || (C & (C - 1))) return TAMTR_EUNSUP;   // row pitch of gy in elements (C: packed)
+  int cshift = 0;
+  while ((1 << cshift) < C) ++cshift;
   if (!gamma || !beta || !mean_rstd || !gx || !ggamma || !gbeta || !partials || (uintptr_t)gx % 16) return TAMTR_EINVAL;
   const int S = tamtr_bncl_blocks(N, C, dtype), V = bncl_vec(C, dtype), iters = bncl_iters(N, C, dtype);
   const size_t total = (size_t)N * C;
@@ -576,17 +580,17 @@ extern "C" int tamtr_bncl_act_bwd(const void* gy, const void* x, const float* ga
   float* sums = partials + (size_t)C * S * 2;  // [C][2] after the per-chunk partials
   const float inv = 1.f / (float)N;
   if (dtype == TAMTR_F32)
-    hipLaunchKernelGGL((bncl_bwd_reduce_kernel<float, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const float*)gy, (const float*)x, mean_rstd, gamma, beta, partials, total, C, iters, act);
+    hipLaunchKernelGGL((bncl_bwd_reduce_kernel<float, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const float*)gy, (const float*)x, mean_rstd, gamma, beta, partials, total, C, iters, act, (size_t)ldgy, cshift);
   else if (V == 8)
-    hipLaunchKernelGGL((bncl_bwd_reduce_kernel<bf16_t, 8>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, partials, total, C, iters, act);
+    hipLaunchKernelGGL((bncl_bwd_reduce_kernel<bf16_t, 8>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, partials, total, C, iters, act, (size_t)ldgy, cshift);
   else
-    hipLaunchKernelGGL((bncl_bwd_reduce_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, partials, total, C, iters, act);
+    hipLaunchKernelGGL((bncl_bwd_reduce_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, partials, total, C, iters, act, (size_t)ldgy, cshift);
   hipLaunchKernelGGL(bncl_sum_kernel, dim3(C), dim3(BN_THREADS), 0, s, partials, sums, ggamma, gbeta, S);
   if (dtype == TAMTR_F32)
-    hipLaunchKernelGGL((bncl_bwd_apply_kernel<float, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const float*)gy, (const float*)x, mean_rstd, gamma, beta, sums, (float*)gx, total, C, iters, act, inv);
+    hipLaunchKernelGGL((bncl_bwd_apply_kernel<float, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const float*)gy, (const float*)x, mean_rstd, gamma, beta, sums, (float*)gx, total, C, iters, act, inv, (size_t)ldgy, cshift);
   else if (V == 8)
-    hipLaunchKernelGGL((bncl_bwd_apply_kernel<bf16_t, 8>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, sums, (bf16_t*)gx, total, C, iters, act, inv);
+    hipLaunchKernelGGL((bncl_bwd_apply_kernel<bf16_t, 8>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, sums, (bf16_t*)gx, total, C, iters, act, inv, (size_t)ldgy, cshift);
   else
-    hipLaunchKernelGGL((bncl_bwd_apply_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, sums, (bf16_t*)gx, total, C, iters, act, inv);
+    hipLaunchKernelGGL((bncl_bwd_apply_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, sums, (bf16_t*)gx, total, C, iters, act, inv, (size_t)ldgy, cshift);
   return tamtr_launch_status();
 }

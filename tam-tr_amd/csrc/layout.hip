@@ -55,7 +55,41 @@ __global__ __launch_bounds__(L_THREADS) void transpose_tiles_kernel(const E* __r
   }
 }
 
+// dst[r][0..C) = src[r][0..C) for N rows with row pitches lds / ldd (elements): the channel-slice copies around torch.cat / chunk on
+// channels-last maps.  One 16-byte vector (or one element when C or the pitches do not allow it) per thread.
+template <typename V>
+__global__ __launch_bounds__(L_THREADS) void copy_rows_kernel(const V* __restrict__ src, V* __restrict__ dst, size_t n, int per_row, size_t lds,
+                                                              size_t ldd) {
+  const size_t i = (size_t)blockIdx.x * L_THREADS + threadIdx.x;
+  if (i >= n) return;
+  const size_t r = i / per_row, c = i % per_row;
+  dst[r * ldd + c] = src[r * lds + c];
+}
+
 }  // namespace
+
+// N rows of C elements, source / destination row pitch lds / ldd elements (>= C).  T = f32 | bf16 (any 2- or 4-byte element).
+extern "C" int tamtr_copy_rows(const void* src, long long lds, void* dst, long long ldd, long long N, int C, int dtype, void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || lds < C || ldd < C) return TAMTR_EINVAL;
+  if (dtype != TAMTR_F32 && dtype != TAMTR_BF16) return TAMTR_EINVAL;
+  const int e = dtype == TAMTR_F32 ? 4 : 2, v = 16 / e;
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = C % v == 0 && lds % v == 0 && ldd % v == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0;
+  if (vec) {
+    const size_t n = (size_t)N * (C / v);
+    hipLaunchKernelGGL(copy_rows_kernel<uint4>, dim3((unsigned)((n + L_THREADS - 1) / L_THREADS)), dim3(L_THREADS), 0, s, (const uint4*)src,
+                       (uint4*)dst, n, C / v, (size_t)lds / v, (size_t)ldd / v);
+  } else if (e == 4) {
+    const size_t n = (size_t)N * C;
+    hipLaunchKernelGGL(copy_rows_kernel<uint32_t>, dim3((unsigned)((n + L_THREADS - 1) / L_THREADS)), dim3(L_THREADS), 0, s, (const uint32_t*)src,
+                       (uint32_t*)dst, n, C, (size_t)lds, (size_t)ldd);
+  } else {
+    const size_t n = (size_t)N * C;
+    hipLaunchKernelGGL(copy_rows_kernel<uint16_t>, dim3((unsigned)((n + L_THREADS - 1) / L_THREADS)), dim3(L_THREADS), 0, s, (const uint16_t*)src,
+                       (uint16_t*)dst, n, C, (size_t)lds, (size_t)ldd);
+  }
+  return tamtr_launch_status();
+}
 
 // to_nhwc != 0: src [B, C, HW] -> dst [B, HW, C];  to_nhwc == 0: src [B, HW, C] -> dst [B, C, HW].  The NHWC side may be a channel
 // slice of a wider map: its pixel pitch is ld >= C elements (ld == C: packed).

@@ -68,7 +68,7 @@ class TIAGELAN(RepNCSPELAN4):
         else:
             with torch.no_grad():  # result discarded by the reference: no graph is ever needed
                 self.attn(y[-3].detach(), guide.detach())
-        return self.cv4(torch.cat(y, 1))
+        return self.cv4(ops.cat_channels(y))
 
 
 class MLP(nn.Module):

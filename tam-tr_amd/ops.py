@@ -70,6 +70,58 @@ def to_nchw(x):
     return _Relayout.apply(x, True) if (x.is_cuda and _cl_pitch(x)) else x.contiguous()
 
 
+class _CatChannels(torch.autograd.Function):
+    """torch.cat(maps, 1) for channels-last maps (or channel slices of such): one 16-byte-vector row copy per input
+    (csrc/layout.hip tamtr_copy_rows); the backward hands out channel slices of the gradient, no copies."""
+
+    @staticmethod
+    def forward(ctx, *maps):
+        B, _, H, W = maps[0].shape
+        widths = [m.shape[1] for m in maps]
+        out = torch.empty((B, sum(widths), H, W), dtype=maps[0].dtype, device=maps[0].device, memory_format=torch.channels_last)
+        ct, off, e = sum(widths), 0, maps[0].element_size()
+        for m, c in zip(maps, widths):
+            call('tamtr_copy_rows', ptr(m), _cl_pitch(m), out.data_ptr() + off * e, ct, B * H * W, c, dtype_code(m), stream_ptr())
+            off += c
+        ctx.widths = widths
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g.split(ctx.widths, 1))
+
+
+def cat_channels(maps):
+    """torch.cat(maps, 1); channels-last CUDA maps of one dtype take the row-copy kernel."""
+    maps = list(maps)
+    if len(maps) > 1 and all(m.is_cuda and m.dim() == 4 and m.dtype == maps[0].dtype and m.dtype in (torch.float32, torch.bfloat16)
+                             and m.shape[0] == maps[0].shape[0] and m.shape[2:] == maps[0].shape[2:] and _cl_pitch(m) and not m.is_contiguous()
+                             for m in maps):
+        return _CatChannels.apply(*maps)
+    return torch.cat(maps, 1)
+
+
+class _PackChannels(torch.autograd.Function):
+    """Packed channels-last copy of a channel slice of a channels-last map (what a convolution makes of `x.chunk(2, 1)[1]`)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, C, H, W = x.shape
+        out = torch.empty((B, C, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        call('tamtr_copy_rows', ptr(x), _cl_pitch(x), ptr(out), C, B * H * W, C, dtype_code(x), stream_ptr())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def pack_channels(x):
+    if x.is_cuda and x.dim() == 4 and not _is_cl(x) and not x.is_contiguous() and _cl_pitch(x) and x.dtype in (torch.float32, torch.bfloat16):
+        return _PackChannels.apply(x)
+    return x
+
+
 def to_channels_last(x):
     if x.dim() != 4 or _is_cl(x):
         return x
@@ -100,7 +152,7 @@ class _MaxPool(torch.autograd.Function):
         code, = ctx.saved_tensors
         B, C, H, W, k, s, p, nhwc, dt = ctx.cfg
         gy = gy.to(dt)
-        gy = gy.contiguous(memory_format=torch.channels_last) if nhwc else _c(gy)
+        gy = (pack_channels(gy) if _cl_pitch(gy) else gy.contiguous(memory_format=torch.channels_last)) if nhwc else _c(gy)
         gx = torch.empty((B, C, H, W), dtype=dt, device=gy.device, memory_format=torch.channels_last if nhwc else torch.contiguous_format)
         call('tamtr_maxpool_bwd', ptr(gy), ptr(code), None, ptr(gx), B, C, H, W, k, s, p, int(nhwc), dtype_code(gy), stream_ptr())
         return gx, None, None, None
@@ -890,11 +942,14 @@ class _BNActCL(torch.autograd.Function):
         x, g32, b32, mr = ctx.saved_tensors
         act, g_dt, b_dt = ctx.cfg
         N, C = x.shape
-        gy = _c(gy.to(x.dtype))
+        gy = gy.to(x.dtype)
+        v = 8 if (x.dtype == torch.bfloat16 and C % 8 == 0) else 4
+        if not (gy.stride(1) == 1 and gy.stride(0) >= C and gy.stride(0) % v == 0 and gy.data_ptr() % 16 == 0 and (C & (C - 1)) == 0):
+            gy = gy.contiguous()   # (a channel slice of a concatenation's gradient is read in place through its row pitch)
         gx = torch.empty_like(x)
         gg, gb = torch.empty(C, device=x.device, dtype=torch.float32), torch.empty(C, device=x.device, dtype=torch.float32)
         part = torch.empty(C * _lib.lib().tamtr_bncl_blocks(N, C, dtype_code(x)) * 2 + 2 * C, device=x.device, dtype=torch.float32)
-        call('tamtr_bncl_act_bwd', ptr(gy), ptr(x), ptr(g32), ptr(b32), ptr(mr), ptr(gx), ptr(gg), ptr(gb), ptr(part), N, C, act,
+        call('tamtr_bncl_act_bwd', ptr(gy), gy.stride(0), ptr(x), ptr(g32), ptr(b32), ptr(mr), ptr(gx), ptr(gg), ptr(gb), ptr(part), N, C, act,
              dtype_code(x), stream_ptr())
         return gx, gg.to(g_dt), gb.to(b_dt), None, None, None, None, None
 

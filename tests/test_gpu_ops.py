@@ -550,3 +550,50 @@ def test_max_pool_vs_torch(ops, B, C, H, W, k, s, p, dt, cl):
     assert torch.equal(out.float().cpu(), ref.detach())
     (out.float() * cot.cuda()).sum().backward()
     assert_close(xd.grad.float().cpu(), xr.grad, 1e-2 if dt == torch.bfloat16 else 1e-6, 1e-6, 'maxpool dx')
+
+
+# ------------------------------------------------------------------------------------------------ channel concatenation in NHWC
+def test_cat_and_pack_channels_vs_torch(ops):
+    """ops.cat_channels / pack_channels (csrc/layout.hip tamtr_copy_rows) against torch.cat / .contiguous() on channels-last maps,
+    including the two halves of a chunk(2, 1); gradients come back as channel slices with the right values."""
+    B, H, W = 2, 12, 20
+    a = rnd((B, 32, H, W), 1).bfloat16().cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    b = rnd((B, 16, H, W), 2).bfloat16().cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    h0, h1 = a.chunk(2, 1)
+    out = ops.cat_channels([h0, h1, b, ops.pack_channels(h1)])
+    ref = torch.cat([h0, h1, b, h1], 1)
+    assert out.is_contiguous(memory_format=torch.channels_last) and torch.equal(out, ref)
+    cot = rnd(tuple(ref.shape), 3).bfloat16().cuda()
+    (out.float() * cot.float()).sum().backward()
+    ga, gb = a.grad.clone(), b.grad.clone()
+    a.grad = b.grad = None
+    (ref.float() * cot.float()).sum().backward()
+    assert torch.equal(ga, a.grad) and torch.equal(gb, b.grad)
+    odd = rnd((B, 6, H, W), 4).cuda().contiguous(memory_format=torch.channels_last)          # fp32, width not a multiple of 4: scalar path
+    assert torch.equal(ops.cat_channels([odd, odd[:, 1:4]]), torch.cat([odd, odd[:, 1:4]], 1))
+
+
+def test_bn_channels_last_backward_reads_a_channel_slice(ops):
+    """The gradient of `torch.cat([bn_a(x), bn_b(y)], 1)` reaches each BatchNorm as a channel slice (row pitch 96 instead of 64 / 32):
+    tamtr_bncl_act_bwd reads it in place; same result as with packed gradients."""
+    import copy
+    import torch.nn as nn
+    N = 3000
+    xa, xb = rnd((N, 64), 1).bfloat16().cuda(), rnd((N, 32), 2).bfloat16().cuda()
+    bna, bnb = nn.BatchNorm1d(64, eps=1e-3, momentum=0.03).cuda(), nn.BatchNorm1d(32, eps=1e-3, momentum=0.03).cuda()
+    with torch.no_grad():
+        bna.weight.copy_(1 + 0.3 * rnd((64,), 3).cuda()); bnb.weight.copy_(1 + 0.3 * rnd((32,), 4).cuda())
+    cot = rnd((N, 96), 5).bfloat16().cuda()
+    res = []
+    for packed in (False, True):
+        a, b = xa.clone().requires_grad_(), xb.clone().requires_grad_()
+        m1, m2 = copy.deepcopy(bna), copy.deepcopy(bnb)
+        ya, yb = ops.bn_act(a, m1, True), ops.bn_act(b, m2, False)
+        if packed:
+            (ya.float() * cot[:, :64].float()).sum().backward()
+            (yb.float() * cot[:, 64:].float()).sum().backward()
+        else:
+            (torch.cat([ya, yb], 1).float() * cot.float()).sum().backward()
+        res.append((a.grad, b.grad, m1.weight.grad, m2.bias.grad))
+    for u, v in zip(*res):
+        assert_close(u.float(), v.float(), 1e-6, 1e-6, 'bncl backward, strided vs packed gy')
