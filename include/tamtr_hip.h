@@ -289,6 +289,11 @@ int tamtr_bncl_act_bwd(const void* gy, long long ldgy, const void* x, const floa
 int tamtr_relayout(const void* src, void* dst, int B, int C, int HW, int ld, int to_nhwc, int dtype, void* stream);
 /*      Channel-slice copy on channels-last maps: dst[r][0..C) = src[r][0..C), N = B*H*W rows, row pitches lds / ldd elements.
  *      Replaces the strided copies behind `torch.cat(y, 1)` / `x.chunk(2, 1)` (extra_modules/block.py:133,147,152) in NHWC. */
+/*      Nearest-neighbour x2 / x0.5 resampling of a packed NHWC map = nn.Upsample(scale_factor=2.0 | 0.5, mode='nearest') as TAMTR.yaml
+ *      uses it, forward and backward.  mode 0: dst [B,2H,2W,C] <- src [B,H,W,C] (up);  1: dst [B,H,W,C] <- src [B,2H,2W,C] (its
+ *      gradient: sum of the four);  2: dst [B,H/2,W/2,C] <- src [B,H,W,C] (down: every second pixel);  3: dst [B,H,W,C] <- src
+ *      [B,H/2,W/2,C] (its gradient: scattered, zeros elsewhere, one pass).  C % 8 == 0 (bf16) / C % 4 == 0 (f32). */
+int tamtr_resample2(const void* src, void* dst, int B, int H, int W, int C, int mode, int dtype, void* stream);
 int tamtr_copy_rows(const void* src, long long lds, void* dst, long long ldd, long long N, int C, int dtype, void* stream);
 
 /* ---- max pooling k x k / stride s / padding p (floor mode), NCHW (nhwc = 0) or NHWC (nhwc = 1) maps.  Replaces nn.MaxPool2d as

@@ -178,6 +178,11 @@ class Upsample(nn.Upsample):
 
     def forward(self, x):
         if self.mode == 'nearest' and x.dim() == 4 and self.size is None and isinstance(self.scale_factor, (int, float)):
+            if x.is_cuda and self.scale_factor in (0.5, 2.0):   # channels-last map: one kernel each way (csrc/layout.hip)
+                from . import ops
+                y = ops.resample2(x, self.scale_factor == 2.0)
+                if y is not None:
+                    return y
             if self.scale_factor == 0.5 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
                 return x[..., ::2, ::2]
             if self.scale_factor == 2.0:

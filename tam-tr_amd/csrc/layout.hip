@@ -66,7 +66,72 @@ __global__ __launch_bounds__(L_THREADS) void copy_rows_kernel(const V* __restric
   dst[r * ldd + c] = src[r * lds + c];
 }
 
+// nearest-neighbour x2 / x0.5 resampling of a packed NHWC map (nn.Upsample(scale_factor=2.0 | 0.5, mode='nearest'), TAMTR.yaml layers
+// 11/14/19/22/27/30), forward and backward, one 16-byte channel vector per thread:
+//   mode 0  up, forward    dst [B,2H,2W,C] <- src [B,H,W,C]:    dst[2h+i][2w+j] = src[h][w]
+//   mode 1  up, backward   dst [B,H,W,C]   <- src [B,2H,2W,C]:  dst[h][w] = sum of the four
+//   mode 2  down, forward  dst [B,H/2,W/2,C] <- src [B,H,W,C]:  dst[h][w] = src[2h][2w]
+//   mode 3  down, backward dst [B,H,W,C]   <- src [B,H/2,W/2,C]: dst[2h][2w] = src[h][w], zero elsewhere (one pass, no fill + scatter)
+// H, W are those of the map written [B,H,W,C] in the line of the mode.
+template <typename T, int V>
+__global__ __launch_bounds__(L_THREADS) void resample2_kernel(const T* __restrict__ src, T* __restrict__ dst, int H, int W, int cv, int mode,
+                                                              size_t n) {
+  const size_t i = (size_t)blockIdx.x * L_THREADS + threadIdx.x;   // one vector of the destination
+  if (i >= n) return;
+  const int c = (int)(i % cv);
+  size_t r = i / cv;
+  // destination geometry
+  const int dw_ = (mode == 0) ? 2 * W : (mode == 2) ? W / 2 : W, dh_ = (mode == 0) ? 2 * H : (mode == 2) ? H / 2 : H;
+  const int w = (int)(r % dw_); r /= dw_;
+  const int h = (int)(r % dh_);
+  const size_t b = r / dh_;
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+  const vec_t* s = reinterpret_cast<const vec_t*>(src);
+  vec_t* d = reinterpret_cast<vec_t*>(dst);
+  if (mode == 0) {
+    d[i] = s[((b * H + h / 2) * W + w / 2) * cv + c];
+  } else if (mode == 2) {
+    d[i] = s[((b * H + 2 * h) * W + 2 * w) * cv + c];
+  } else if (mode == 3) {
+    vec_t z;
+#pragma unroll
+    for (int u = 0; u < V; ++u) z[u] = 0;
+    d[i] = ((h | w) & 1) ? z : s[((b * (H / 2) + h / 2) * (W / 2) + w / 2) * cv + c];
+  } else {
+    float acc[V];
+#pragma unroll
+    for (int u = 0; u < V; ++u) acc[u] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const vec_t v = s[((b * 2 * H + 2 * h + q / 2) * (2 * W) + 2 * w + q % 2) * cv + c];
+#pragma unroll
+      for (int u = 0; u < V; ++u) acc[u] += sizeof(T) == 2 ? bf2f((bf16_t)v[u]) : __builtin_bit_cast(float, (uint32_t)v[u]);
+    }
+    vec_t o;
+#pragma unroll
+    for (int u = 0; u < V; ++u) o[u] = sizeof(T) == 2 ? (T)f2bf(acc[u]) : (T)__builtin_bit_cast(uint32_t, acc[u]);
+    d[i] = o;
+  }
+}
+
 }  // namespace
+
+// see resample2_kernel; [B,H,W,C] is the map the mode's comment names that way.  C % 8 == 0 (bf16) / C % 4 == 0 (f32), 16-byte aligned.
+extern "C" int tamtr_resample2(const void* src, void* dst, int B, int H, int W, int C, int mode, int dtype, void* stream) {
+  if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0 || mode < 0 || mode > 3) return TAMTR_EINVAL;
+  if (dtype != TAMTR_F32 && dtype != TAMTR_BF16) return TAMTR_EINVAL;
+  const int v = dtype == TAMTR_F32 ? 4 : 8;
+  if (C % v || ((uintptr_t)src | (uintptr_t)dst) % 16 || ((mode == 2 || mode == 3) && ((H | W) & 1))) return TAMTR_EUNSUP;
+  const size_t rows = mode == 0 ? (size_t)B * 2 * H * 2 * W : mode == 2 ? (size_t)B * (H / 2) * (W / 2) : (size_t)B * H * W;
+  const size_t n = rows * (C / v);
+  const unsigned blocks = (unsigned)((n + L_THREADS - 1) / L_THREADS);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == TAMTR_F32)
+    hipLaunchKernelGGL((resample2_kernel<uint32_t, 4>), dim3(blocks), dim3(L_THREADS), 0, s, (const uint32_t*)src, (uint32_t*)dst, H, W, C / v, mode, n);
+  else
+    hipLaunchKernelGGL((resample2_kernel<uint16_t, 8>), dim3(blocks), dim3(L_THREADS), 0, s, (const uint16_t*)src, (uint16_t*)dst, H, W, C / v, mode, n);
+  return tamtr_launch_status();
+}
 
 // N rows of C elements, source / destination row pitch lds / ldd elements (>= C).  T = f32 | bf16 (any 2- or 4-byte element).
 extern "C" int tamtr_copy_rows(const void* src, long long lds, void* dst, long long ldd, long long N, int C, int dtype, void* stream) {

@@ -122,6 +122,35 @@ def pack_channels(x):
     return x
 
 
+class _Resample2(torch.autograd.Function):
+    """nn.Upsample(scale_factor=2.0 | 0.5, mode='nearest') on a channels-last map - csrc/layout.hip tamtr_resample2."""
+
+    @staticmethod
+    def forward(ctx, x, up):
+        B, C, H, W = x.shape
+        ctx.cfg = (up, B, C, H, W)
+        Ho, Wo = (2 * H, 2 * W) if up else (H // 2, W // 2)
+        out = torch.empty((B, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        call('tamtr_resample2', ptr(x), ptr(out), B, H, W, C, 0 if up else 2, dtype_code(x), stream_ptr())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        up, B, C, H, W = ctx.cfg
+        g = g if _is_cl(g) else (pack_channels(g) if _cl_pitch(g) else g.contiguous(memory_format=torch.channels_last))
+        gx = torch.empty((B, C, H, W), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
+        call('tamtr_resample2', ptr(g), ptr(gx), B, H, W, C, 1 if up else 3, dtype_code(g), stream_ptr())
+        return gx, None
+
+
+def resample2(x, up):
+    """Nearest x2 (up) / x0.5 of a channels-last CUDA map whose channel count fills 16-byte vectors; None if the kernel does not apply."""
+    v = 8 if x.dtype == torch.bfloat16 else 4
+    if x.is_cuda and _is_cl(x) and x.dtype in (torch.float32, torch.bfloat16) and x.shape[1] % v == 0 and (up or (x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)):
+        return _Resample2.apply(x, bool(up))
+    return None
+
+
 def to_channels_last(x):
     if x.dim() != 4 or _is_cl(x):
         return x

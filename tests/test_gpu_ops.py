@@ -597,3 +597,22 @@ def test_bn_channels_last_backward_reads_a_channel_slice(ops):
         res.append((a.grad, b.grad, m1.weight.grad, m2.bias.grad))
     for u, v in zip(*res):
         assert_close(u.float(), v.float(), 1e-6, 1e-6, 'bncl backward, strided vs packed gy')
+
+
+@pytest.mark.parametrize('scale,dt', [(2.0, torch.bfloat16), (0.5, torch.bfloat16), (2.0, torch.float32), (0.5, torch.float32)])
+def test_nearest_resampling_channels_last(ops, scale, dt):
+    """nn.Upsample(scale_factor=2.0 | 0.5, mode='nearest') (TAMTR.yaml layers 11/14/19/22/27/30) on a channels-last map: values
+    identical to torch's, gradient = sum of the four copies / scatter to the even pixels."""
+    import torch.nn as nn
+    from tamtr_amd.backbone import Upsample
+    B, C, H, W = 2, 16, 6, 10
+    x = rnd((B, C, H, W), 21).to(dt)
+    xr = x.float().clone().requires_grad_()
+    ref = nn.Upsample(scale_factor=scale, mode='nearest')(xr)
+    cot = rnd(tuple(ref.shape), 22).to(dt).float()
+    (ref * cot).sum().backward()
+    xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_()
+    out = Upsample(scale_factor=scale, mode='nearest')(xd)
+    assert out.is_contiguous(memory_format=torch.channels_last) and torch.equal(out.float().cpu(), ref.detach())
+    (out.float() * cot.cuda()).sum().backward()
+    assert_close(xd.grad.float().cpu(), xr.grad, 1e-2 if dt == torch.bfloat16 else 1e-6, 1e-6, 'resample dx')
