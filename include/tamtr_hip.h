@@ -245,6 +245,12 @@ int tamtr_ln_gate_bwd(const void* gout, const float* x, const void* xz, long lon
                       const float* beta, const float* stats, float* gx, void* gxz, float* partials, long long ntok, int D, int dtype,
                       void* stream);
 
+/*      Gradient of the two stored cross-scan copies (SS2D backward): out[b, i] = g4[b, i] + g4[b, i + 2] + m_i[b], i = 0, 1.
+ *      g4 f32 [B, 4, n] = d/d(u) of the four directions as tamtr_selective_scan_dtproj_bwd writes them (un-reversed), m0 / m1 (T)
+ *      [B, n] = the x_proj backward products of the two copies (vmamba.py:962-970), out f32 [B, 2, n], n = D * L, n % 4 == 0.
+ */
+int tamtr_fold_add(const float* g4, const void* m0, const void* m1, float* out, int B, long long n, int dtype, void* stream);
+
 /*      tamtr_layernorm_* : LayerNorm over the channel axis of a token-major map, VSSBlock.norm / norm2
  *      (VManba/vmamba.py:1190,1222,1239-1254).  x, out, gout, gx (T) [ntok, D]; gamma, beta f32 [D]; stats f32 [ntok, 2];
  *      partials f32 [tamtr_ln_gate_blocks(ntok), 2, D] (per-workgroup d(gamma), d(beta) sums).  D in {32,...,1024} powers of two.

@@ -1,0 +1,39 @@
+// fold.hip - gradient of the two stored cross-scan copies, SS2D backward, gfx950.
+//
+// The scan backward returns d/d(u) per direction, un-reversed: g4 [B, 4, D, L].  Directions k and k + 2 read the same stored copy
+// (csms6s.py:4-14), and the x_proj products read it too, so d/d(u2)[b, i] = g4[b, i] + g4[b, i + 2] + m_i[b] with m_i = W_i^T gx_i
+// (vmamba.py:962-970 backward), i = 0, 1.  As separate torch ops that was a slice add, a bf16 -> fp32 cast of m and autograd's
+// accumulation: 5 reads + 3 writes of an 839 MB plane pair at level 0; here 3 reads + 1 write, 16 bytes per lane.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void fold_add_kernel(const float* __restrict__ g4, const T* __restrict__ m0, const T* __restrict__ m1,
+                                                       float* __restrict__ out, size_t plane4, int B) {
+  // plane4 = D * L / 4 float4 groups of one [D, L] plane; grid.y = 2 * B
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= plane4) return;
+  const int b = blockIdx.y / 2, c = blockIdx.y % 2;
+  const float4 a = reinterpret_cast<const float4*>(g4)[((size_t)b * 4 + c) * plane4 + i];
+  const float4 d = reinterpret_cast<const float4*>(g4)[((size_t)b * 4 + c + 2) * plane4 + i];
+  float mv[4];
+  Elt<T>::ld4((c ? m1 : m0) + ((size_t)b * plane4 + i) * 4, mv);
+  reinterpret_cast<float4*>(out)[((size_t)b * 2 + c) * plane4 + i] =
+      make_float4(a.x + d.x + mv[0], a.y + d.y + mv[1], a.z + d.z + mv[2], a.w + d.w + mv[3]);
+}
+
+}  // namespace
+
+// g4 f32 [B, 4, D*L]; m0, m1 (T) [B, D*L]; out f32 [B, 2, D*L];  n = D*L, n % 4 == 0
+extern "C" int tamtr_fold_add(const float* g4, const void* m0, const void* m1, float* out, int B, long long n, int dtype, void* stream) {
+  if (!g4 || !m0 || !m1 || !out || B <= 0 || n <= 0) return TAMTR_EINVAL;
+  if (dtype != TAMTR_F32 && dtype != TAMTR_BF16) return TAMTR_EINVAL;
+  if (n % 4 || 2 * B > 65535 || ((uintptr_t)m0 | (uintptr_t)m1) % 8) return TAMTR_EUNSUP;
+  const size_t plane4 = (size_t)n / 4;
+  const dim3 grid((unsigned)((plane4 + 255) / 256), 2 * B);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == TAMTR_F32) hipLaunchKernelGGL(fold_add_kernel<float>, grid, dim3(256), 0, s, g4, (const float*)m0, (const float*)m1, out, plane4, B);
+  else hipLaunchKernelGGL(fold_add_kernel<bf16_t>, grid, dim3(256), 0, s, g4, (const bf16_t*)m0, (const bf16_t*)m1, out, plane4, B);
+  return tamtr_launch_status();
+}

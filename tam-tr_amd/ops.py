@@ -796,6 +796,122 @@ def ln_gate(x, xz, gamma, beta, eps=1e-5):
     return _LNGate.apply(x, xz, gamma, beta, eps)
 
 
+class _SS2DCore(torch.autograd.Function):
+    """SS2D between in_proj and out_proj as ONE autograd node (vmamba.py:949-1008): depthwise 3x3 + SiLU + cross-scan layout ->
+    x_proj -> selective scan with the dt projection inside -> cross-merge -> out_norm x SiLU(z).  Same kernels and the same
+    arithmetic as dwconv_silu_cross / x_proj_cross / selective_scan_cross_merged / ln_gate chained; what the single node buys is
+    the backward's buffer plan, which autograd otherwise dictates:
+      * d/d(u2) = fold of the scan's four planes + the two x_proj products in one pass (csrc/fold.hip) instead of a slice add, a cast
+        and an accumulation (5 reads + 3 writes of an 839 MB plane pair at level 0 -> 3 + 1);
+      * d/d(xz): the gate kernel writes the z half and the depthwise-conv kernel the xi half of ONE buffer (before: two zero-filled
+        [B,H,W,2D] maps and their sum)."""
+
+    @staticmethod
+    def forward(ctx, xz, conv_w, conv_b, wx, Wdt, A, Ds, dbias, gamma, beta, eps, R, N):
+        require_gpu(xz, conv_w, wx, Wdt, A, Ds, dbias, gamma, beta)
+        xz = _c(xz)
+        B, H, W, C2 = xz.shape
+        D, L, K = C2 // 2, H * W, 4
+        # front end
+        cw = _c(conv_w.float().reshape(D, 9))
+        cb = _c(conv_b.float()) if conv_b is not None else None
+        u2 = torch.empty(B, 2, D, L, device=xz.device, dtype=torch.float32)
+        call('tamtr_dwconv_silu_cross_fwd', ptr(xz), C2, ptr(cw), ptr(cb), ptr(u2), B, D, H, W, dtype_code(xz), stream_ptr())
+        # x_proj on the two copies (directions k and k + 2 share one)
+        cdt = xz.dtype if xz.dtype == torch.bfloat16 else torch.float32
+        C = R + 2 * N
+        ub = u2.to(cdt)
+        wa, wb = torch.cat([wx[0], wx[2]], 0).to(cdt), torch.cat([wx[1], wx[3]], 0).to(cdt)
+        with torch.autocast('cuda', enabled=False):
+            xa, xb = torch.matmul(wa, ub[:, 0]), torch.matmul(wb, ub[:, 1])  # [B, 2C, L]
+        dtr, Bs, Cs = (torch.stack([xa[:, lo:lo + n], xb[:, lo:lo + n], xa[:, C + lo:C + lo + n], xb[:, C + lo:C + lo + n]], 1).float()
+                       for lo, n in ((0, R), (R, N), (R + N, N)))
+        # scan + cross-merge, token-major
+        Wdt32, A32, D32, db32 = (_c(t.float()) for t in (Wdt, A, Ds, dbias))
+        chunk = _lib.lib().tamtr_selective_scan_chunk()
+        y = torch.empty(B, K, D, L, device=xz.device, dtype=torch.float32)
+        hstate = torch.empty(B, K * D, (L + chunk - 1) // chunk, N, device=xz.device, dtype=torch.float32)
+        call('tamtr_selective_scan_dtproj_fwd', ptr(u2), ptr(dtr), ptr(Wdt32), ptr(A32), ptr(Bs), ptr(Cs), ptr(D32), ptr(db32), ptr(y),
+             ptr(hstate), B, K, D, N, R, L, 1, stream_ptr())
+        ymT = torch.empty(B, L, D, device=xz.device, dtype=torch.float32)
+        call('tamtr_cross_merge_fwd', ptr(y), ptr(ymT), B, D, H, W, stream_ptr())
+        del y
+        # out_norm x SiLU(z)
+        g32, b32 = _c(gamma.float()), _c(beta.float())
+        out = torch.empty(B, L, D, device=xz.device, dtype=xz.dtype)
+        stats = torch.empty(B * L, 2, device=xz.device, dtype=torch.float32)
+        call('tamtr_ln_gate_fwd', ptr(ymT), ptr(xz), C2, ptr(g32), ptr(b32), ptr(out), ptr(stats), B * L, D, float(eps), dtype_code(xz),
+             stream_ptr())
+        ctx.save_for_backward(xz, cw, cb if cb is not None else cw.new_empty(0), u2, ub, wa, wb, dtr, Bs, Cs, Wdt32, A32, D32, db32, hstate,
+                              ymT, g32, b32, stats)
+        ctx.cfg = (R, N, H, W, conv_w.shape, conv_w.dtype, None if conv_b is None else conv_b.dtype, wx.dtype, Wdt.dtype, A.dtype, Ds.dtype,
+                   dbias.dtype, gamma.dtype, beta.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (xz, cw, cb, u2, ub, wa, wb, dtr, Bs, Cs, Wdt32, A32, D32, db32, hstate, ymT, g32, b32, stats) = ctx.saved_tensors
+        R, N, H, W, cw_shape, cw_dt, cb_dt, wx_dt, wdt_dt, a_dt, d_dt, db_dt, ga_dt, be_dt = ctx.cfg
+        B, _, _, C2 = xz.shape
+        D, L, K, C = C2 // 2, H * W, 4, R + 2 * N
+        dev = xz.device
+        # gate: d/d(ymT), the z half of d/d(xz), d(gamma), d(beta)
+        gout = _c(gout.to(xz.dtype))
+        gy = torch.empty_like(ymT)
+        gxz = torch.empty_like(xz)   # z half from the gate kernel here, xi half from the depthwise-conv kernel below
+        nblk = _lib.lib().tamtr_ln_gate_blocks(B * L)
+        part = torch.empty(nblk, 2, D, device=dev, dtype=torch.float32)
+        call('tamtr_ln_gate_bwd', ptr(gout), ptr(ymT), ptr(xz), C2, ptr(g32), ptr(b32), ptr(stats), ptr(gy), ptr(gxz), ptr(part), B * L, D,
+             dtype_code(xz), stream_ptr())
+        gsum = part.sum(0)
+        # cross-merge and scan
+        g2 = torch.empty(B, 2, D, L, device=dev, dtype=torch.float32)
+        call('tamtr_cross_merge_bwd', ptr(gy), ptr(g2), B, D, H, W, stream_ptr())
+        del gy
+        gu = torch.empty(B, K * D, L, device=dev, dtype=torch.float32)
+        gdelta = torch.empty(B, K * D, L, device=dev, dtype=torch.float32)
+        gdtr = torch.empty_like(dtr)
+        gW, gA = torch.zeros_like(Wdt32), torch.zeros_like(A32)
+        gB, gC = torch.empty_like(Bs), torch.empty_like(Cs)
+        gD, gdb = torch.zeros_like(D32), torch.zeros_like(db32)
+        nslab = _lib.lib().tamtr_selective_scan_bwd_slabs(D)
+        ws = torch.empty(2 * nslab * Bs.numel(), device=dev, dtype=torch.float32)
+        call('tamtr_selective_scan_dtproj_bwd', ptr(g2), ptr(u2), ptr(dtr), ptr(Wdt32), ptr(A32), ptr(Bs), ptr(Cs), ptr(D32), ptr(db32),
+             ptr(hstate), ptr(gu), ptr(gdelta), ptr(gdtr), ptr(gW), ptr(gA), ptr(gB), ptr(gC), ptr(gD), ptr(gdb), ptr(ws), B, K, D, N, R, L,
+             3, stream_ptr())
+        del gdelta, ws, g2
+        # x_proj backward: per copy one [D, 2C] x [2C, L] product and the weight gradient as a batched GEMM over L slices
+        cdt = ub.dtype
+        S = _split_len(L)
+        gws, ms = [], []
+        with torch.autocast('cuda', enabled=False):
+            for i, w in ((0, wa), (1, wb)):
+                gx = torch.cat([gdtr[:, i], gB[:, i], gC[:, i], gdtr[:, i + 2], gB[:, i + 2], gC[:, i + 2]], 1).to(cdt)  # [B, 2C, L]
+                ms.append(torch.matmul(w.t(), gx))                                                                         # [B, D, L]
+                ga = gx.view(B, 2 * C, S, L // S).transpose(1, 2).reshape(B * S, 2 * C, L // S)
+                ua = ub[:, i].reshape(B, D, S, L // S).transpose(1, 2).reshape(B * S, D, L // S)
+                gws.append(torch.bmm(ga, ua.transpose(1, 2)).float().sum(0))  # [2C, D]
+        gwx = torch.stack([gws[0][:C], gws[1][:C], gws[0][C:], gws[1][C:]], 0).to(wx_dt)
+        gu2 = torch.empty(B, 2, D, L, device=dev, dtype=torch.float32)
+        call('tamtr_fold_add', ptr(gu), ptr(_c(ms[0])), ptr(_c(ms[1])), ptr(gu2), B, D * L, dtype_code(ms[0]), stream_ptr())
+        del gu, ms
+        # front end: the xi half of d/d(xz), d(conv weight), d(conv bias)
+        tiles = _lib.lib().tamtr_dwconv_tiles(H, W)
+        wsd = torch.empty(B, tiles, D, 10, device=dev, dtype=torch.float32)
+        call('tamtr_dwconv_silu_cross_bwd', ptr(gu2), ptr(xz), C2, ptr(cw), ptr(cb if cb_dt is not None else None), ptr(gxz), C2, ptr(wsd), B,
+             D, H, W, dtype_code(xz), stream_ptr())
+        gwb = wsd.sum((0, 1))
+        gcw = gwb[:, :9].reshape(cw_shape).to(cw_dt)
+        gcb = gwb[:, 9].to(cb_dt) if cb_dt is not None else None
+        return (gxz, gcw, gcb, gwx, gW.to(wdt_dt), gA.to(a_dt), gD.to(d_dt), gdb.to(db_dt), gsum[0].to(ga_dt), gsum[1].to(be_dt), None, None,
+                None)
+
+
+def ss2d_core(xz, conv_w, conv_b, x_proj_weight, Wdt, A, Ds, dt_bias, out_norm_weight, out_norm_bias, eps, R, N):
+    """xz [B,H,W,2D] (in_proj output) -> out_norm(cross-merged scan) * SiLU(z) as [B, H*W, D] in xz's dtype; see _SS2DCore."""
+    return _SS2DCore.apply(xz, conv_w, conv_b, x_proj_weight, Wdt, A, Ds, dt_bias, out_norm_weight, out_norm_bias, float(eps), int(R), int(N))
+
+
 def selective_scan_cross(u2, dtr, Wdt, A, Bm, Cm, D, delta_bias):
     """Cross-scan layout + fused dt projection: u2 [B,2,Dk,L] (row-major / column-major copies), dtr [B,4,R,L] low-rank dt
     factors, Wdt [4*Dk, R]; Bm, Cm [B,4,16,L]; everything stored UN-reversed (directions 2, 3 walk the buffers backwards).

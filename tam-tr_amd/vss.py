@@ -91,6 +91,13 @@ class SS2D(nn.Module):
         # Cross-scan WITHOUT materialising the four sequences (csms6s.py:4-14): directions 0/2 walk the row-major flattening
         # forwards/backwards, 1/3 the column-major one; the kernel reads the two stored copies and reverses on the fly, and all
         # per-direction operands are kept in the un-reversed order of their base copy.  The scan runs in fp32 (vmamba.py:980).
+        if fused_front and x.is_cuda and D in (64, 128, 256, 512, 1024) and os.environ.get('TAMTR_SS2D_SPLIT') != '1':
+            # the whole core as one autograd node (ops._SS2DCore): same kernels, planned backward buffers
+            As = -torch.exp(self.A_logs.float())
+            g = ops.ss2d_core(xz, self.conv2d.weight, self.conv2d.bias, self.x_proj_weight, self.dt_projs_weight.float().reshape(K * D, R), As,
+                              self.Ds.float(), self.dt_projs_bias.float().reshape(-1), self.out_norm.weight, self.out_norm.bias,
+                              self.out_norm.eps, R, N)
+            return self.out_proj(g.view(B, H, W, D))
         if _EINSUM_DT:
             xi = F.silu(xc).float()
             u2 = torch.stack([xi.flatten(2), xi.transpose(2, 3).flatten(2)], 1)  # [B,2,D,L]
