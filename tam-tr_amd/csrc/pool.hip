@@ -17,24 +17,39 @@ struct PoolGeom {
   int C, H, W, Ho, Wo, k, s, p, nhwc;
 };
 
-// element (b, c, h, w) of a map in either layout
-__device__ __forceinline__ size_t at(const PoolGeom& g, int b, int c, int h, int w, int HH, int WW) {
-  return g.nhwc ? (((size_t)b * HH + h) * WW + w) * g.C + c : (((size_t)b * g.C + c) * HH + h) * WW + w;
+// Thread -> element: NCHW: blockIdx.y = plane (b * C + c), the x axis runs over the plane's pixels (w fastest);
+//                    NHWC: blockIdx.y = pixel row (b * HH + h), the x axis runs over (w, c) with c fastest.  32-bit index math only.
+struct Where {
+  int c, h, w;
+  int unit;   // NCHW: plane index b * C + c; NHWC: image index b
+};
+__device__ __forceinline__ bool locate(const PoolGeom& g, int HH, int WW, Where& q) {
+  const int i = blockIdx.x * P_THREADS + threadIdx.x;
+  if (g.nhwc) {
+    if (i >= WW * g.C) return false;
+    q.c = i % g.C; q.w = i / g.C; q.h = blockIdx.y % HH;
+    q.unit = blockIdx.y / HH;
+  } else {
+    if (i >= HH * WW) return false;
+    q.w = i % WW; q.h = i / WW; q.c = 0;
+    q.unit = blockIdx.y;
+  }
+  return true;
 }
-// linear thread index -> (b, c, h, w) with the layout's contiguous axis fastest
-__device__ __forceinline__ void unflat(const PoolGeom& g, size_t i, int HH, int WW, int& b, int& c, int& h, int& w) {
-  if (g.nhwc) { c = (int)(i % g.C); i /= g.C; w = (int)(i % WW); i /= WW; h = (int)(i % HH); b = (int)(i / HH); }
-  else { w = (int)(i % WW); i /= WW; h = (int)(i % HH); i /= HH; c = (int)(i % g.C); b = (int)(i / g.C); }
+__device__ __forceinline__ size_t off(const PoolGeom& g, int WW, int c, int h, int w) {   // inside the plane (NCHW) / image (NHWC)
+  return g.nhwc ? ((size_t)h * WW + w) * g.C + c : (size_t)h * WW + w;
+}
+__device__ __forceinline__ size_t base(const PoolGeom& g, int unit, int HH, int WW) {      // of the plane (NCHW) / image (NHWC)
+  return (size_t)unit * HH * WW * (g.nhwc ? g.C : 1);
 }
 
 template <typename T>
 __global__ __launch_bounds__(P_THREADS) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ code,
-                                                                PoolGeom g, size_t n_out) {
-  const size_t i = (size_t)blockIdx.x * P_THREADS + threadIdx.x;
-  if (i >= n_out) return;
-  int b, c, oh, ow;
-  unflat(g, i, g.Ho, g.Wo, b, c, oh, ow);
-  const int h0 = oh * g.s - g.p, w0 = ow * g.s - g.p;
+                                                                PoolGeom g) {
+  Where q;
+  if (!locate(g, g.Ho, g.Wo, q)) return;
+  const T* xp = x + base(g, q.unit, g.H, g.W);
+  const int h0 = q.h * g.s - g.p, w0 = q.w * g.s - g.p;
   float best = -INFINITY;
   int win = max(0, -h0) * g.k + max(0, -w0);   // torch starts from the window's first real element
   for (int dh = 0; dh < g.k; ++dh) {
@@ -43,30 +58,34 @@ __global__ __launch_bounds__(P_THREADS) void maxpool_fwd_kernel(const T* __restr
     for (int dw = 0; dw < g.k; ++dw) {
       const int w = w0 + dw;
       if (w < 0 || w >= g.W) continue;
-      const float v = Elt<T>::ld(x + at(g, b, c, h, w, g.H, g.W));
+      const float v = Elt<T>::ld(xp + off(g, g.W, q.c, h, w));
       if (v > best || v != v) { best = v; win = dh * g.k + dw; }
     }
   }
-  Elt<T>::st(y + i, best);
-  code[i] = (uint8_t)win;
+  const size_t o = base(g, q.unit, g.Ho, g.Wo) + off(g, g.Wo, q.c, q.h, q.w);
+  Elt<T>::st(y + o, best);
+  code[o] = (uint8_t)win;
 }
 
 template <typename T>
 __global__ __launch_bounds__(P_THREADS) void maxpool_bwd_kernel(const T* __restrict__ gy, const uint8_t* __restrict__ code,
-                                                                const T* __restrict__ addend, T* __restrict__ gx, PoolGeom g, size_t n_in) {
-  const size_t i = (size_t)blockIdx.x * P_THREADS + threadIdx.x;
-  if (i >= n_in) return;
-  int b, c, h, w;
-  unflat(g, i, g.H, g.W, b, c, h, w);
+                                                                const T* __restrict__ addend, T* __restrict__ gx, PoolGeom g) {
+  Where q;
+  if (!locate(g, g.H, g.W, q)) return;
+  const size_t out_base = base(g, q.unit, g.Ho, g.Wo);
+  const T* gyp = gy + out_base;
+  const uint8_t* cp = code + out_base;
+  const int h = q.h, w = q.w;
   // windows oh with oh * s - p <= h <= oh * s - p + k - 1
   const int oh_lo = max(0, (h + g.p - g.k + g.s) / g.s), oh_hi = min(g.Ho - 1, (h + g.p) / g.s);
   const int ow_lo = max(0, (w + g.p - g.k + g.s) / g.s), ow_hi = min(g.Wo - 1, (w + g.p) / g.s);
+  const size_t i = base(g, q.unit, g.H, g.W) + off(g, g.W, q.c, h, w);
   float acc = addend ? Elt<T>::ld(addend + i) : 0.f;
   for (int oh = oh_lo; oh <= oh_hi; ++oh)
     for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-      const size_t o = at(g, b, c, oh, ow, g.Ho, g.Wo);
+      const size_t o = off(g, g.Wo, q.c, oh, ow);
       const int mine = (h - (oh * g.s - g.p)) * g.k + (w - (ow * g.s - g.p));
-      if (code[o] == mine) acc += Elt<T>::ld(gy + o);
+      if (cp[o] == mine) acc += Elt<T>::ld(gyp + o);
     }
   Elt<T>::st(gx + i, acc);
 }
@@ -76,6 +95,15 @@ int pool_geom(PoolGeom& g, int B, int C, int H, int W, int k, int s, int p, int 
   if (k > 15 || 2 * p > k || H + 2 * p < k || W + 2 * p < k) return TAMTR_EUNSUP;   // code fits a byte; every window holds a real element
   g = PoolGeom{C, H, W, (H + 2 * p - k) / s + 1, (W + 2 * p - k) / s + 1, k, s, p, nhwc ? 1 : 0};
   return TAMTR_OK;
+}
+
+// grid for a map of HH x WW elements per (image, channel): see locate()
+dim3 pool_grid(const PoolGeom& g, int B, int HH, int WW) {
+  const long long per = g.nhwc ? (long long)WW * g.C : (long long)HH * WW, rows = g.nhwc ? (long long)B * HH : (long long)B * g.C;
+  if (per > 0x7fffffffLL - P_THREADS || rows > 65535LL * 65535LL) return dim3(0);
+  // blockIdx.y is limited to 65535 on this launch path: fold the excess into z is not needed for the maps of this graph
+  if (rows > 65535) return dim3(0);
+  return dim3((unsigned)((per + P_THREADS - 1) / P_THREADS), (unsigned)rows);
 }
 
 }  // namespace
@@ -88,11 +116,11 @@ extern "C" int tamtr_maxpool_fwd(const void* x, void* y, uint8_t* code, int B, i
   const int rc = pool_geom(g, B, C, H, W, k, s, p, nhwc);
   if (rc) return rc;
   if (!x || !y || !code || (dtype != TAMTR_F32 && dtype != TAMTR_BF16)) return TAMTR_EINVAL;
-  const size_t n = (size_t)B * C * g.Ho * g.Wo;
-  const unsigned blocks = (unsigned)((n + P_THREADS - 1) / P_THREADS);
+  const dim3 grid = pool_grid(g, B, g.Ho, g.Wo);
+  if (!grid.x) return TAMTR_EUNSUP;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TAMTR_F32) hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(blocks), dim3(P_THREADS), 0, st, (const float*)x, (float*)y, code, g, n);
-  else hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(blocks), dim3(P_THREADS), 0, st, (const bf16_t*)x, (bf16_t*)y, code, g, n);
+  if (dtype == TAMTR_F32) hipLaunchKernelGGL(maxpool_fwd_kernel<float>, grid, dim3(P_THREADS), 0, st, (const float*)x, (float*)y, code, g);
+  else hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, grid, dim3(P_THREADS), 0, st, (const bf16_t*)x, (bf16_t*)y, code, g);
   return tamtr_launch_status();
 }
 
@@ -102,10 +130,10 @@ extern "C" int tamtr_maxpool_bwd(const void* gy, const uint8_t* code, const void
   const int rc = pool_geom(g, B, C, H, W, k, s, p, nhwc);
   if (rc) return rc;
   if (!gy || !gx || !code || (dtype != TAMTR_F32 && dtype != TAMTR_BF16)) return TAMTR_EINVAL;
-  const size_t n = (size_t)B * C * H * W;
-  const unsigned blocks = (unsigned)((n + P_THREADS - 1) / P_THREADS);
+  const dim3 grid = pool_grid(g, B, H, W);
+  if (!grid.x) return TAMTR_EUNSUP;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TAMTR_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(blocks), dim3(P_THREADS), 0, st, (const float*)gy, code, (const float*)addend, (float*)gx, g, n);
-  else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(blocks), dim3(P_THREADS), 0, st, (const bf16_t*)gy, code, (const bf16_t*)addend, (bf16_t*)gx, g, n);
+  if (dtype == TAMTR_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(P_THREADS), 0, st, (const float*)gy, code, (const float*)addend, (float*)gx, g);
+  else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, grid, dim3(P_THREADS), 0, st, (const bf16_t*)gy, code, (const bf16_t*)addend, (bf16_t*)gx, g);
   return tamtr_launch_status();
 }
