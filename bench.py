@@ -17,7 +17,8 @@ from the PMC passes committed under profiles/ (same kernel, same shape).  `cpu_b
 reference's own end-to-end path cannot run on CPU) on this box's host cores, bounded sample: 2 images, 1 warm-up +
 3 timed fwd+bwd steps.  `config.bf16_vs_fp32`: relative difference of the bf16-mode loss from the fp32-mode loss of the SAME
 model on the SAME batch, measured before the warm-up (the GPU parity suite holds the fp32 mode to the CPU oracle at 1e-3).
-`config.static_part`: "hip-graph" when the shape-static part of the step (trunk, VSS blocks, input projection: ~3/4 of the
+`config.conv_tuning`: how MIOpen picked the trunk's convolution kernels (tam-tr_amd/tuning.py: its own timed search, replayed from
+the tables shipped in the repo).  `config.static_part`: "hip-graph" when the shape-static part of the step (trunk, VSS blocks, input projection: ~3/4 of the
 launches) is replayed as two HIP graphs (model.capture_static_part), "eager" otherwise (--static-part eager).
 For N > 1 the process group must be RCCL (`nccl`): the line records backend and world size, anything else is refused.
 """
@@ -160,6 +161,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--static-part', default='graph', choices=['graph', 'eager'],
                     help='trunk + VSS blocks + input projection replayed as two HIP graphs (forward, backward) or launched kernel by kernel')
+    ap.add_argument('--conv-tuning', default='shipped', choices=['shipped', 'search', 'off'],
+                    help="MIOpen solver choice for the trunk's convolutions: its timed search backed by the tables shipped under "
+                         'tam-tr_amd/tuned/miopen (default), a fresh search (minutes), or its heuristic')
+    ap.add_argument('--conv-db', default=None, help='directory the search writes its tables to (--conv-tuning search)')
     ap.add_argument('--grad-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire (N > 1)')
     args = ap.parse_args()
 
@@ -177,6 +182,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
+    from tamtr_amd.tuning import use_tuned_convolutions
+    conv_tuning = use_tuned_convolutions(args.conv_tuning, args.conv_db)   # before the first convolution
     torch.set_num_threads(min(8, host_cores()))  # host side = launch issue + a few tiny CPU ops (dn RNG, scipy LSA): no 128-thread pools
     torch.manual_seed(0)
     model = RTDETRDetectionWorldModel(nc=10).to(dev).train()
@@ -268,7 +275,7 @@ def main():
                                    f'bs {args.batch}/GPU, 10 text prompts, 8 GT/img, full BTA-PAN+MEH HIP path',
                        'global_batch': world * args.batch, 'parallelism': f'dp{world}', 'final_loss': float(loss.detach()),
                        'bf16_vs_fp32': mode_err, 'dist_backend': backend, 'dist_world_size': world,
-                       'grad_bucket_dtype': (args.grad_dtype if world > 1 else None), 'static_part': static_part,
+                       'grad_bucket_dtype': (args.grad_dtype if world > 1 else None), 'static_part': static_part, 'conv_tuning': conv_tuning,
                        'hbm_GiB_peak': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
             'roofline': None if ks is None else {
                 'bound': 'mfma', 'kernel': 'linear_bf16_wstat_kernel<512> (MEH value_proj x3 + enc_output and their dX, M=%d N=K=512)'

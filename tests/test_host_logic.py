@@ -240,3 +240,17 @@ def test_detect_head_api_vs_reference_fixture(golden, tag, ch, sizes):
     assert_close(m.cv3[1][-1].bias, fx[f'{tag}.bias_cls'], 1e-6, 1e-6)
     with pytest.raises(ValueError):
         m([xs[0]] * (nl + 1))
+
+
+def test_shipped_convolution_tables_match_this_miopen_build():
+    """tam-tr_amd/tuning.py: the MIOpen find-db / perf-db shipped under tuned/miopen were written by this image's MIOpen and HIP (their
+    file names carry the version MIOpen looks for); a mismatch silently falls back to MIOpen's heuristic, which costs 10 ms per step."""
+    import glob
+    import os
+    from tamtr_amd import tuning
+    assert tuning.shipped_db_matches()
+    files = glob.glob(os.path.join(tuning._DIR, '*.ufdb.txt'))
+    assert len(files) == 1 and os.path.basename(files[0]).startswith('gfx950')
+    text = open(files[0]).read()
+    assert '3-640-640-3x3-64-320-320-16' in text and 'BF16' in text and 'FP32' in text   # first trunk layer at 640 px / 16 images, both modes
+    assert tuning.use_tuned_convolutions('off').startswith('off')

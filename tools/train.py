@@ -54,12 +54,17 @@ def main():
     ap.add_argument('--save-dir', default='runs/train/TAMTR')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--grad-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire (N > 1)')
+    ap.add_argument('--conv-tuning', default='shipped', choices=['shipped', 'search', 'off'], help='MIOpen solver choice (tam-tr_amd/tuning.py)')
     args = ap.parse_args()
 
     import tamtr_amd  # noqa: F401  (raises if the HIP library is missing)
     from tamtr_amd import data as D, dist as tdist, engine as E
     from tamtr_amd.model import RTDETRDetectionWorldModel
     rank, local, world = tdist.init_from_env()
+    from tamtr_amd.tuning import use_tuned_convolutions
+    conv_tuning = use_tuned_convolutions(args.conv_tuning)   # before the first convolution (tables cover 640 px / 16 images; other shapes are searched once)
+    if rank == 0:
+        print(f'convolution tuning: {conv_tuning}', flush=True)
     try:       # host side = kernel launches + a few tiny CPU ops: a thread pool sized for the whole host only adds wake-up latency
         torch.set_num_threads(min(8, len(os.sched_getaffinity(0))))
     except AttributeError:
