@@ -325,7 +325,7 @@ def fitness(metrics):
 
 def fit(model, train_loader, prepare, epochs, val_loader=None, lr0=1e-4, lrf=1.0, momentum=0.9, weight_decay=1e-4, optimizer='AdamW',
         warmup_iters=2000, warmup_bias_lr=0.1, warmup_momentum=0.8, close_mosaic=0, imgsz=640, reducer=None, rank=0, world=1,
-        save_dir=None, max_steps=None, log=None, resume=None):
+        save_dir=None, max_steps=None, log=None, resume=None, static_graph=False):
     """Train `model` for `epochs` passes over train_loader; defaults are the reference's shipped hyper-parameters
     (cfg/default.yaml:23,84-90; this fork sets nbs = batch, so there is no gradient accumulation and weight decay is unscaled, and
     reads warmup_epochs as an iteration count: trainer.py:263-265,294).
@@ -335,7 +335,8 @@ def fit(model, train_loader, prepare, epochs, val_loader=None, lr0=1e-4, lrf=1.0
     (trainer.py:346-347).  Rank 0 validates the EMA weights after every epoch and keeps last.pt / best.pt under save_dir.
     resume: a checkpoint dict written by an earlier fit() ({'epoch', 'model', 'ema', 'updates', 'optimizer'}; the caller has loaded
     'model'): EMA weights and update count, optimizer state and the epoch counter continue from it (trainer.py:560-583), so the
-    warm-up does not start over.  Returns the per-epoch records."""
+    warm-up does not start over.  static_graph: record trunk + VSS blocks + input projection as HIP graphs on the first batch
+    (model.capture_static_part; batches of another shape, and evaluation, run eagerly).  Returns the per-epoch records."""
     nb = len(train_loader)
     opt = build_optimizer(model, name=optimizer, lr=lr0, momentum=momentum, decay=weight_decay,
                           iterations=math.ceil(len(train_loader.dataset) / max(train_loader.batch_size or 1, 1)) * epochs)
@@ -373,6 +374,14 @@ def fit(model, train_loader, prepare, epochs, val_loader=None, lr0=1e-4, lrf=1.0
             i += 1
             warmup(opt, i + nb * epoch, warmup_iters, lf(epoch), warmup_bias_lr, warmup_momentum, momentum)
             batch = prepare(batch, True)
+            if static_graph and getattr(model, '_static', None) is None and batch['img'].is_cuda and hasattr(model, 'capture_static_part'):
+                static_graph = False   # one attempt
+                try:
+                    model.capture_static_part(batch['img'], batch['txt_feats'])
+                except Exception as e:  # noqa: BLE001 - training goes on eagerly; say so
+                    model.release_static_part()
+                    if log:
+                        log(f'static part not captured ({type(e).__name__}: {e}); running eagerly')
             if reducer is not None:
                 reducer.prepare()
             loss, items = model(batch)

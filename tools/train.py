@@ -15,6 +15,8 @@ import os
 import sys
 import tempfile
 
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')  # before the HIP runtime starts: see tam-tr_amd/graphs.py
+
 import numpy as np
 import torch
 import yaml
@@ -54,6 +56,7 @@ def main():
     ap.add_argument('--save-dir', default='runs/train/TAMTR')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--grad-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire (N > 1)')
+    ap.add_argument('--static-part', default='graph', choices=['graph', 'eager'], help='replay trunk + VSS + input projection as HIP graphs (model.capture_static_part)')
     ap.add_argument('--conv-tuning', default='shipped', choices=['shipped', 'search', 'off'], help='MIOpen solver choice (tam-tr_amd/tuning.py)')
     args = ap.parse_args()
 
@@ -113,7 +116,8 @@ def main():
     def log(rec):
         print(json.dumps({k: (round(v, 5) if isinstance(v, float) else v) for k, v in rec.items()}), flush=True)
     E.fit(model, tl, prepare, args.epochs, val_loader=vl, lr0=args.lr0, close_mosaic=args.close_mosaic, imgsz=args.imgsz, reducer=reducer,
-          rank=rank, world=world, save_dir=args.save_dir if rank == 0 else None, max_steps=args.max_steps, log=log, resume=resume)
+          rank=rank, world=world, save_dir=args.save_dir if rank == 0 else None, max_steps=args.max_steps, log=log, resume=resume,
+          static_graph=args.static_part == 'graph')
     if tmp is not None:
         tmp.cleanup()
 
