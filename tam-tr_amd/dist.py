@@ -44,7 +44,14 @@ def shard_batch(global_batch, rank, world):
 
 
 class GradReducer:
-    """Bucketed, overlapped all-reduce (SUM or MEAN) of the gradients of `params` that are known to receive one."""
+    """Bucketed all-reduce (SUM or MEAN) of the gradients of `params` that are known to receive one.
+
+    Each bucket is one flat buffer.  Autograd writes every gradient wherever it likes (for the graph-replayed part of the step these
+    are the graph's own output buffers, adopted by AccumulateGrad without a copy); when the last gradient of a bucket has arrived -
+    and every earlier bucket has been launched - the bucket is gathered with ONE multi-tensor copy, all-reduced asynchronously, and
+    the parameters' .grad are re-pointed at their slices of the flat buffer, so the optimizer reads reduced values without a copy
+    back.  (Round 1 pre-set .grad to the slices and let autograd accumulate into them: one add kernel per parameter per step plus a
+    zero fill of every bucket - ~700 launches.)"""
 
     def __init__(self, named_params, bucket_bytes=32 << 20, op='sum', grad_dtype=None, skip=lambda name: False,
                  late=lambda name: False):
@@ -54,7 +61,7 @@ class GradReducer:
         into the last bucket, so that a missing hook delays only that bucket's launch to finish()."""
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.op = op
-        self.buckets = []   # dicts: flat, params, pending, handle
+        self.buckets = []   # dicts: flat, params, views, pending, handle
         self._hooks = []
         self._next = 0      # index of the first bucket not yet handed to the collective (launch order == bucket order)
         params = [(n, p) for n, p in named_params if p.requires_grad and not skip(n)]
@@ -77,50 +84,60 @@ class GradReducer:
             off = 0
             bucket = {'flat': flat, 'params': g, 'pending': 0, 'handle': None, 'views': []}
             for _, p in g:
-                # same strides as the parameter (channels-last conv weights): autograd and the optimizer stay on their fast paths
+                # same strides as the parameter (channels-last conv weights): the optimizer stays on its fast path
                 v = flat[off:off + p.numel()].view_as(p) if p.is_contiguous() else torch.as_strided(flat, p.shape, p.stride(), off)
                 off += p.numel()
                 bucket['views'].append(v)
-                if dt == p.dtype:
-                    p.grad = v  # autograd accumulates straight into the bucket: no copy before the collective
             self.buckets.append(bucket)
-            for (_, p), v in zip(g, bucket['views']):
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bucket, p, v)))
+            for _, p in g:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bucket)))
         self.n_params = sum(len(b['params']) for b in self.buckets)
 
-    def _make_hook(self, bucket, p, view):
+    def _make_hook(self, bucket):
         def hook(param):
-            if param.grad is not view:  # dtype differs from the bucket (e.g. bf16 buckets) or grad was re-created
-                view.copy_(param.grad)
-                param.grad = view if view.dtype == param.dtype else None  # finish() hands back the reduced gradient
             bucket['pending'] -= 1
             if bucket['pending'] == 0:
                 self._launch_ready()
         return hook
+
+    def _gather(self, b):
+        """This backward's gradients of the bucket's parameters -> the flat buffer (one multi-tensor copy, casting if the wire
+        dtype differs); a parameter without a gradient on this rank contributes zeros."""
+        dst, src = [], []
+        for (_, p), v in zip(b['params'], b['views']):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        for (_, p), v in zip(b['params'], b['views']):
+            p.grad = v if v.dtype == p.dtype else None   # finish() hands back the reduced gradient of a narrower wire dtype
 
     def _launch_ready(self):
         """Launch, in index order, every complete bucket that directly follows the launched prefix.  A complete bucket
         behind an incomplete one waits (for that one's last hook, or for finish()): the issue order is rank-independent."""
         while self._next < len(self.buckets) and self.buckets[self._next]['pending'] == 0:
             b = self.buckets[self._next]
+            self._gather(b)
             if self.world > 1:
                 b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
             self._next += 1
 
     def prepare(self):
-        """Call before backward: arm the per-bucket counters and zero the flat buffers."""
+        """Call before backward: arm the per-bucket counters and detach .grad from the flat buffers (autograd must not accumulate
+        onto last step's reduced values; fresh gradients are gathered when their bucket completes)."""
         self._next = 0
         for b in self.buckets:
             b['pending'] = len(b['params'])
             b['handle'] = None
-            b['flat'].zero_()
-            for (_, p), v in zip(b['params'], b['views']):
-                if v.dtype != p.dtype:
-                    p.grad = None  # last step's reduced copy: autograd must not accumulate onto it
+            for _, p in b['params']:
+                p.grad = None
 
     def finish(self):
         """Call after backward: launch what is left in index order (a bucket with a parameter that got no gradient on this
-        rank stays zero-filled for it, and holds back the buckets behind it until here), then wait for all of them."""
+        rank holds zeros for it, and holds back the buckets behind it until here), then wait for all of them."""
         for b in self.buckets[self._next:]:
             b['pending'] = 0
         self._launch_ready()
