@@ -12,7 +12,9 @@ namespace {
 
 constexpr int CT_THREADS = 256;
 constexpr int CT_WAVES = CT_THREADS / WAVE;
-constexpr int CT_ROWS = 16;  // query rows per workgroup
+constexpr int CT_ROWS = 16;  // query rows per workgroup (forward)
+constexpr int CT_BROWS = 80; // backward: few workgroups per image, so that d(what) meets few global atomics per address
+constexpr int CT_KR = 16;    // text rows whose d(what) partial sums a wave keeps in registers (larger vocabularies: LDS atomics)
 
 template <typename ET>
 struct CV;  // per-lane vector width (elements per 16 bytes)
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(CT_THREADS) void contrastive_fwd_kernel(const ET* _
   }
 }
 
-template <typename ET, int NP>
+template <typename ET, int NP, bool REGS>
 __global__ __launch_bounds__(CT_THREADS) void contrastive_bwd_kernel(const float* __restrict__ g, const ET* __restrict__ x,
                                                                       const float* __restrict__ w,
                                                                       const float* __restrict__ logit_scale,
@@ -142,8 +144,15 @@ __global__ __launch_bounds__(CT_THREADS) void contrastive_bwd_kernel(const float
   stage_text(w + (size_t)b * K * C, s_w, s_winv, K, C);
   const float sc = __expf(*logit_scale);
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-  for (int r = wave; r < CT_ROWS; r += CT_WAVES) {
-    const int q = blockIdx.x * CT_ROWS + r;
+  float wacc[REGS ? CT_KR : 1][NP][V];   // this wave's sum over its rows of s g xhat, per text row (K <= CT_KR)
+#pragma unroll
+  for (int k = 0; k < (REGS ? CT_KR : 1); ++k)
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int i = 0; i < V; ++i) wacc[k][p][i] = 0.f;
+  for (int r = wave; r < CT_BROWS; r += CT_WAVES) {
+    const int q = blockIdx.x * CT_BROWS + r;
     if (q >= Q) break;
     const size_t row = (size_t)b * Q + q;
     const float xi = xinv[row];
@@ -155,17 +164,38 @@ __global__ __launch_bounds__(CT_THREADS) void contrastive_bwd_kernel(const float
 #pragma unroll
       for (int i = 0; i < V; ++i) { xh[p][i] = (c < C) ? xh[p][i] * xi : 0.f; dh[p][i] = 0.f; }
     }
-    for (int k = 0; k < K; ++k) {
-      const float gs = g[row * K + k] * sc;  // wave-uniform
-      const float wi = s_winv[k];
+    if (REGS) {
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int c = (p * WAVE + lane) * V;
-        if (c < C) {
+      for (int k = 0; k < CT_KR; ++k) {
+        if (k < K) {
+          const float gs = g[row * K + k] * sc;  // wave-uniform
+          const float wi = s_winv[k];
 #pragma unroll
-          for (int i = 0; i < V; ++i) {
-            dh[p][i] = fmaf(gs * wi, s_w[(size_t)k * C + c + i], dh[p][i]);   // d xhat += s g what
-            atomicAdd(&s_acc[(size_t)k * C + c + i], gs * xh[p][i]);           // d what += s g xhat
+          for (int p = 0; p < NP; ++p) {
+            const int c = (p * WAVE + lane) * V;
+            if (c < C) {
+#pragma unroll
+              for (int i = 0; i < V; ++i) {
+                dh[p][i] = fmaf(gs * wi, s_w[(size_t)k * C + c + i], dh[p][i]);   // d xhat += s g what
+                wacc[k][p][i] = fmaf(gs, xh[p][i], wacc[k][p][i]);                 // d what += s g xhat
+              }
+            }
+          }
+        }
+      }
+    } else {
+      for (int k = 0; k < K; ++k) {
+        const float gs = g[row * K + k] * sc;  // wave-uniform
+        const float wi = s_winv[k];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int c = (p * WAVE + lane) * V;
+          if (c < C) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+              dh[p][i] = fmaf(gs * wi, s_w[(size_t)k * C + c + i], dh[p][i]);   // d xhat += s g what
+              atomicAdd(&s_acc[(size_t)k * C + c + i], gs * xh[p][i]);           // d what += s g xhat
+            }
           }
         }
       }
@@ -186,6 +216,18 @@ __global__ __launch_bounds__(CT_THREADS) void contrastive_bwd_kernel(const float
         stv<ET>(dx + row * C + c, o);
       }
     }
+  }
+  if (REGS) {   // the four waves' register sums meet in LDS once
+#pragma unroll
+    for (int k = 0; k < CT_KR; ++k)
+      if (k < K)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int c = (p * WAVE + lane) * V;
+          if (c < C)
+#pragma unroll
+            for (int i = 0; i < V; ++i) atomicAdd(&s_acc[(size_t)k * C + c + i], wacc[k][p][i]);
+        }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < K * C; i += CT_THREADS) atomicAdd(dwhat + (size_t)b * K * C + i, s_acc[i]);
@@ -219,6 +261,7 @@ extern "C" int tamtr_contrastive_logits_fwd(const void* x, const float* w, const
   if (dtype == TAMTR_F32) { PICK(float) } else { PICK(bf16_t) }
 #undef PICK
 #undef GO
+#undef GO1
   return tamtr_launch_status();
 }
 
@@ -233,19 +276,21 @@ extern "C" int tamtr_contrastive_logits_bwd(const float* g, const void* x, const
   const size_t lds = ((size_t)2 * K * C + K) * sizeof(float);
   if (C % 8 || np == 0 || lds > 128 * 1024 || K > 128 || B > 65535) return TAMTR_EUNSUP;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((Q + CT_ROWS - 1) / CT_ROWS, B);
-#define GO(ET, NP)                                                                                              \
+  dim3 grid((Q + CT_BROWS - 1) / CT_BROWS, B);
+#define GO1(ET, NP, REGS)                                                                                       \
   {                                                                                                             \
     if (lds > 64 * 1024)                                                                                        \
-      (void)hipFuncSetAttribute((const void*)contrastive_bwd_kernel<ET, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+      (void)hipFuncSetAttribute((const void*)contrastive_bwd_kernel<ET, NP, REGS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                      \
-    hipLaunchKernelGGL((contrastive_bwd_kernel<ET, NP>), grid, dim3(CT_THREADS), lds, s, g, (const ET*)x, w, logit_scale, xinv, \
+    hipLaunchKernelGGL((contrastive_bwd_kernel<ET, NP, REGS>), grid, dim3(CT_THREADS), lds, s, g, (const ET*)x, w, logit_scale, xinv, \
                        (ET*)dx, dwhat, Q, K, C);                                                                \
   }
+#define GO(ET, NP) { if (K <= CT_KR) GO1(ET, NP, true) else GO1(ET, NP, false) }   /* register sums: up to 2 column groups per lane */
 #define PICK(ET) \
-  switch (np) { case 1: GO(ET, 1) break; case 2: GO(ET, 2) break; case 4: GO(ET, 4) break; default: GO(ET, 8) }
+  switch (np) { case 1: GO(ET, 1) break; case 2: GO(ET, 2) break; case 4: GO1(ET, 4, false) break; default: GO1(ET, 8, false) }
   if (dtype == TAMTR_F32) { PICK(float) } else { PICK(bf16_t) }
 #undef PICK
 #undef GO
+#undef GO1
   return tamtr_launch_status();
 }

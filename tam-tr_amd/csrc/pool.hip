@@ -43,9 +43,11 @@ __device__ __forceinline__ size_t base(const PoolGeom& g, int unit, int HH, int 
   return (size_t)unit * HH * WW * (g.nhwc ? g.C : 1);
 }
 
-template <typename T>
+// KS = 16 * k + s known at compile time for the two shapes of the graph (integer divisions by s become shifts), 0 = run-time values
+template <typename T, int KS>
 __global__ __launch_bounds__(P_THREADS) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ code,
                                                                 PoolGeom g) {
+  if (KS) { g.k = KS / 16; g.s = KS % 16; g.p = g.k / 2; }
   Where q;
   if (!locate(g, g.Ho, g.Wo, q)) return;
   const T* xp = x + base(g, q.unit, g.H, g.W);
@@ -67,9 +69,10 @@ __global__ __launch_bounds__(P_THREADS) void maxpool_fwd_kernel(const T* __restr
   code[o] = (uint8_t)win;
 }
 
-template <typename T>
+template <typename T, int KS>
 __global__ __launch_bounds__(P_THREADS) void maxpool_bwd_kernel(const T* __restrict__ gy, const uint8_t* __restrict__ code,
                                                                 const T* __restrict__ addend, T* __restrict__ gx, PoolGeom g) {
+  if (KS) { g.k = KS / 16; g.s = KS % 16; g.p = g.k / 2; }
   Where q;
   if (!locate(g, g.H, g.W, q)) return;
   const size_t out_base = base(g, q.unit, g.Ho, g.Wo);
@@ -119,8 +122,11 @@ extern "C" int tamtr_maxpool_fwd(const void* x, void* y, uint8_t* code, int B, i
   const dim3 grid = pool_grid(g, B, g.Ho, g.Wo);
   if (!grid.x) return TAMTR_EUNSUP;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TAMTR_F32) hipLaunchKernelGGL(maxpool_fwd_kernel<float>, grid, dim3(P_THREADS), 0, st, (const float*)x, (float*)y, code, g);
-  else hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, grid, dim3(P_THREADS), 0, st, (const bf16_t*)x, (bf16_t*)y, code, g);
+  const int ks = (p == k / 2 && ((k == 3 && s == 2) || (k == 5 && s == 1))) ? 16 * k + s : 0;
+#define FWD(T, KS) hipLaunchKernelGGL((maxpool_fwd_kernel<T, KS>), grid, dim3(P_THREADS), 0, st, (const T*)x, (T*)y, code, g)
+  if (dtype == TAMTR_F32) { if (ks == 50) FWD(float, 50); else if (ks == 81) FWD(float, 81); else FWD(float, 0); }
+  else { if (ks == 50) FWD(bf16_t, 50); else if (ks == 81) FWD(bf16_t, 81); else FWD(bf16_t, 0); }
+#undef FWD
   return tamtr_launch_status();
 }
 
@@ -133,7 +139,10 @@ extern "C" int tamtr_maxpool_bwd(const void* gy, const uint8_t* code, const void
   const dim3 grid = pool_grid(g, B, H, W);
   if (!grid.x) return TAMTR_EUNSUP;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TAMTR_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(P_THREADS), 0, st, (const float*)gy, code, (const float*)addend, (float*)gx, g);
-  else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, grid, dim3(P_THREADS), 0, st, (const bf16_t*)gy, code, (const bf16_t*)addend, (bf16_t*)gx, g);
+  const int ks = (p == k / 2 && ((k == 3 && s == 2) || (k == 5 && s == 1))) ? 16 * k + s : 0;
+#define BWD(T, KS) hipLaunchKernelGGL((maxpool_bwd_kernel<T, KS>), grid, dim3(P_THREADS), 0, st, (const T*)gy, code, (const T*)addend, (T*)gx, g)
+  if (dtype == TAMTR_F32) { if (ks == 50) BWD(float, 50); else if (ks == 81) BWD(float, 81); else BWD(float, 0); }
+  else { if (ks == 50) BWD(bf16_t, 50); else if (ks == 81) BWD(bf16_t, 81); else BWD(bf16_t, 0); }
+#undef BWD
   return tamtr_launch_status();
 }

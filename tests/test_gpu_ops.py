@@ -127,7 +127,7 @@ def test_contrastive_golden(ops, golden):
     check_param_grads(fx, '', {'bias': bi.grad, 'logit_scale': ls.grad}, 1e-3, 1e-3)
 
 
-@pytest.mark.parametrize('B,Q,K,C', [(1, 1, 1, 64), (3, 17, 80, 128), (2, 300, 10, 512), (1, 5, 3, 2048)])
+@pytest.mark.parametrize('B,Q,K,C', [(1, 1, 1, 64), (3, 17, 80, 128), (2, 300, 10, 512), (1, 5, 3, 2048), (2, 100, 16, 256), (2, 181, 17, 256)])
 def test_contrastive_shapes(ops, B, Q, K, C):
     x, w = rnd((B, Q, C), 1, 2.0), rnd((B, K, C), 2)
     P = O.View({'logit_scale': torch.tensor(2.3), 'bias': torch.tensor([-9.5])})
