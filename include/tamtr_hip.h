@@ -280,8 +280,21 @@ int tamtr_bn_act_bwd(const void* gy, const void* x, const float* gamma, const fl
  *      the gradient is a channel slice of the gradient of a `torch.cat(..., 1)`, so that no packing copy is needed).
  */
 int tamtr_bncl_blocks(long long N, int C, int dtype);
-int tamtr_bncl_act_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y,
-                       float* mean_rstd, float* partials, long long N, int C, float eps, float momentum, int act, int dtype, void* stream);
+int tamtr_bncl_act_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, const void* residual,
+                       void* y, float* mean_rstd, float* partials, long long N, int C, float eps, float momentum, int act, int dtype,
+                       void* stream);
+/*      residual (T [N, C], may be NULL): y = act(bn(x)) + residual - the shortcut of RepNBottleneck (`x + self.cv2(self.cv1(x))`,
+ *      extra_modules/block.py:100-102) joins in the apply pass; its gradient is gy itself (the caller passes it on).
+ *      tamtr_bncl2_act_*: y = act(bn1(x1) + bn2(x2)), both in training mode over the same shape - RepConvN's training form
+ *      `self.act(self.conv1(x) + self.conv2(x))` (block.py:66-69).  mean_rstd f32 [2][C][2]; partials 2 * C * S * 3 floats forward,
+ *      C * S * 3 + 3 * C backward.
+ */
+int tamtr_bncl2_act_fwd(const void* x1, const float* gamma1, const float* beta1, float* running_mean1, float* running_var1, const void* x2,
+                        const float* gamma2, const float* beta2, float* running_mean2, float* running_var2, void* y, float* mean_rstd,
+                        float* partials, long long N, int C, float eps, float momentum, int act, int dtype, void* stream);
+int tamtr_bncl2_act_bwd(const void* gy, long long ldgy, const void* x1, const void* x2, const float* gamma1, const float* beta1,
+                        const float* gamma2, const float* beta2, const float* mean_rstd, void* gx1, void* gx2, float* ggamma1, float* gbeta1,
+                        float* ggamma2, float* gbeta2, float* partials, long long N, int C, int act, int dtype, void* stream);
 int tamtr_bncl_act_bwd(const void* gy, long long ldgy, const void* x, const float* gamma, const float* beta, const float* mean_rstd,
                        void* gx, float* ggamma, float* gbeta, float* partials, long long N, int C, int act, int dtype, void* stream);
 

@@ -46,19 +46,35 @@ class Conv(nn.Module):
             self.conv = fold_bn(self.conv, self.bn)
             del self.bn
 
-    def forward(self, x):
-        y = self.conv(x)
+    def fusable(self, y):
+        """The BatchNorm (+ SiLU) of this block can run on csrc/bn.hip for the convolution output y."""
+        return ('bn' in self._modules and y.is_cuda and self.bn.training and self.bn.affine and type(self.act) in (nn.SiLU, nn.Identity)
+                and y.dtype in (torch.bfloat16, torch.float32))
+
+    def forward(self, x, residual=None):
+        """residual: added to the block's output (the shortcut of a bottleneck); on the channels-last kernel path it joins inside the
+        BatchNorm apply pass."""
+        return self.post(self.conv(x), residual)
+
+    def post(self, y, residual=None):
+        """Everything after the convolution: BatchNorm, activation, optional shortcut."""
         if 'bn' not in self._modules:
-            return self.act(y)
-        if y.is_cuda and self.bn.training and self.bn.affine and type(self.act) in (nn.SiLU, nn.Identity) \
-                and y.dtype in (torch.bfloat16, torch.float32):
+            y = self.act(y)
+            return y if residual is None else y + residual
+        if self.fusable(y):
             from . import ops
-            if y.dim() == 4 and not y.is_contiguous() and y.is_contiguous(memory_format=torch.channels_last) and ops.bn_cl_ok(y.shape[1], y.dtype):
+            if ops.is_cl(y) and ops.bn_cl_ok(y.shape[1], y.dtype):
                 B, C, H, W = y.shape  # channels-last map: the [B*H*W, C] kernels, result stays channels-last
-                o = ops.bn_act(y.permute(0, 2, 3, 1).reshape(B * H * W, C), self.bn, isinstance(self.act, nn.SiLU))
-                return o.view(B, H, W, C).permute(0, 3, 1, 2)
-            return ops.bn_act(y, self.bn, isinstance(self.act, nn.SiLU))  # BatchNorm (batch stats) + SiLU: csrc/bn.hip
-        return self.act(self.bn(y))
+                res = None
+                if residual is not None and ops.is_cl(residual) and residual.shape == y.shape:
+                    res, residual = residual.permute(0, 2, 3, 1).reshape(B * H * W, C), None
+                o = ops.bn_act(y.permute(0, 2, 3, 1).reshape(B * H * W, C), self.bn, isinstance(self.act, nn.SiLU), res)
+                o = o.view(B, H, W, C).permute(0, 3, 1, 2)
+                return o if residual is None else o + residual
+            y = ops.bn_act(y, self.bn, isinstance(self.act, nn.SiLU))  # BatchNorm (batch stats) + SiLU: csrc/bn.hip
+        else:
+            y = self.act(self.bn(y))
+        return y if residual is None else y + residual
 
 
 class RepConvN(nn.Module):
@@ -75,6 +91,17 @@ class RepConvN(nn.Module):
     def forward(self, x):
         if 'conv' in self._modules:
             return self.act(self.conv(x))
+        c1, c2 = self.conv1, self.conv2
+        if x.is_cuda and type(self.act) in (nn.SiLU, nn.Identity) and 'bn' in c1._modules and 'bn' in c2._modules:
+            from . import ops
+            y1, y2 = c1.conv(x), c2.conv(x)
+            if (c1.fusable(y1) and c2.fusable(y2) and ops.is_cl(y1) and ops.is_cl(y2) and ops.bn_cl_ok(y1.shape[1], y1.dtype)
+                    and c1.bn.track_running_stats and c2.bn.track_running_stats and c1.bn.eps == c2.bn.eps and c1.bn.momentum == c2.bn.momentum):
+                B, C, H, W = y1.shape   # both BatchNorms, the sum and the activation in one pass each way (csrc/bn.hip bncl2_*)
+                o = ops.bn2_act(y1.permute(0, 2, 3, 1).reshape(B * H * W, C), c1.bn, y2.permute(0, 2, 3, 1).reshape(B * H * W, C), c2.bn,
+                                isinstance(self.act, nn.SiLU))
+                return o.view(B, H, W, C).permute(0, 3, 1, 2)
+            return self.act(c1.post(y1) + c2.post(y2))
         return self.act(self.conv1(x) + self.conv2(x))
 
     @staticmethod
@@ -105,8 +132,9 @@ class RepNBottleneck(nn.Module):
         self.add = shortcut and c1 == c2
 
     def forward(self, x):
-        y = self.cv2(self.cv1(x))
-        return x + y if self.add else y
+        if self.add:
+            return self.cv2(self.cv1(x), residual=x)   # x + cv2(cv1(x)), the shortcut folded into cv2's BatchNorm pass
+        return self.cv2(self.cv1(x))
 
 
 class RepNCSP(nn.Module):

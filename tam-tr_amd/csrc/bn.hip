@@ -344,7 +344,8 @@ __global__ __launch_bounds__(BN_THREADS) void bncl_stats_kernel(const T* __restr
 template <typename T, int V>
 __global__ __launch_bounds__(BN_THREADS) void bncl_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean_rstd,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                 T* __restrict__ y, size_t total, int C, int iters, int act) {
+                                                                 const T* __restrict__ res, T* __restrict__ y, size_t total, int C, int iters,
+                                                                 int act) {
   const size_t piece = (size_t)BN_THREADS * V, start = (size_t)blockIdx.x * iters * piece, end = min(total, start + iters * piece);
   const int c0 = (threadIdx.x % (C / V)) * V;
   const size_t home = start + c0;   // first row of the chunk: where a load past the end is redirected
@@ -364,7 +365,156 @@ __global__ __launch_bounds__(BN_THREADS) void bncl_apply_kernel(const T* __restr
       const size_t e = e0 + (size_t)(it + u) * piece;
 #pragma unroll
       for (int j = 0; j < V; ++j) v[u][j] = act_fwd(fmaf(v[u][j] - mean[j], a[j], be[j]), act);
+      if (res && e < end) {   // x + Conv(...)(x) of a bottleneck: the shortcut joins here instead of in an add kernel
+        float r[V];
+        Vec<T, V>::ld(res + e, r);
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[u][j] += r[j];
+      }
       if (e < end) Vec<T, V>::st(y + e, v[u]);
+    }
+  }
+}
+
+// ---- two BatchNorms into one activation: y = act(bn1(x1) + bn2(x2)) - RepConvN's training form (3x3 branch + 1x1 branch,
+// extra_modules/block.py:66-69).  As separate ops that was two applies, an add and a SiLU forward (11 map passes) and a SiLU backward
+// plus two BatchNorm backwards (13); here 3 + 8.  Same chunking and register-resident column constants as the single kernels.
+template <typename T, int V>
+__global__ __launch_bounds__(BN_THREADS) void bncl2_apply_kernel(const T* __restrict__ x1, const T* __restrict__ x2,
+                                                                  const float* __restrict__ mr1, const float* __restrict__ mr2,
+                                                                  const float* __restrict__ g1, const float* __restrict__ b1,
+                                                                  const float* __restrict__ g2, const float* __restrict__ b2,
+                                                                  T* __restrict__ y, size_t total, int C, int iters, int act) {
+  const size_t piece = (size_t)BN_THREADS * V, start = (size_t)blockIdx.x * iters * piece, end = min(total, start + iters * piece);
+  const int c0 = (threadIdx.x % (C / V)) * V;
+  const size_t home = start + c0;
+  float m1[V], a1[V], m2[V], a2[V], be[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    m1[j] = mr1[2 * (c0 + j)]; a1[j] = mr1[2 * (c0 + j) + 1] * g1[c0 + j];
+    m2[j] = mr2[2 * (c0 + j)]; a2[j] = mr2[2 * (c0 + j) + 1] * g2[c0 + j];
+    be[j] = b1[c0 + j] + b2[c0 + j];
+  }
+  const size_t e0 = start + (size_t)threadIdx.x * V;
+  for (int it = 0; it < iters; it += CL_UNROLL) {
+    float v[CL_UNROLL][V], w[CL_UNROLL][V];
+#pragma unroll
+    for (int u = 0; u < CL_UNROLL; ++u) {
+      const size_t e = e0 + (size_t)(it + u) * piece, ee = e < end ? e : home;
+      Vec<T, V>::ld(x1 + ee, v[u]);
+      Vec<T, V>::ld(x2 + ee, w[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < CL_UNROLL; ++u) {
+      const size_t e = e0 + (size_t)(it + u) * piece;
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[u][j] = act_fwd(fmaf(w[u][j] - m2[j], a2[j], fmaf(v[u][j] - m1[j], a1[j], be[j])), act);
+      if (e < end) Vec<T, V>::st(y + e, v[u]);
+    }
+  }
+}
+
+// part[c][chunk][3] = sum dz, sum dz * xhat1, sum dz * xhat2 with dz = gy * act'(z1 + z2)
+template <typename T, int V>
+__global__ __launch_bounds__(BN_THREADS) void bncl2_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restrict__ x1, const T* __restrict__ x2,
+                                                                       const float* __restrict__ mr1, const float* __restrict__ mr2,
+                                                                       const float* __restrict__ g1, const float* __restrict__ b1,
+                                                                       const float* __restrict__ g2, const float* __restrict__ b2,
+                                                                       float* __restrict__ part, size_t total, int C, int iters, int act,
+                                                                       size_t ldgy, int cshift) {
+  __shared__ float s_acc[BN_THREADS * 3 * V];
+  __shared__ float s_col[3 * 1024];
+  const size_t piece = (size_t)BN_THREADS * V, start = (size_t)blockIdx.x * iters * piece, end = min(total, start + iters * piece);
+  const int cg = C / V, c0 = (threadIdx.x % cg) * V, S = gridDim.x;
+  const size_t home = start + c0;
+  float m1[V], r1[V], m2[V], r2[V], ga1[V], ga2[V], be[V], acc[3 * V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    m1[j] = mr1[2 * (c0 + j)]; r1[j] = mr1[2 * (c0 + j) + 1]; m2[j] = mr2[2 * (c0 + j)]; r2[j] = mr2[2 * (c0 + j) + 1];
+    ga1[j] = g1[c0 + j]; ga2[j] = g2[c0 + j]; be[j] = b1[c0 + j] + b2[c0 + j];
+    acc[j] = 0.f; acc[V + j] = 0.f; acc[2 * V + j] = 0.f;
+  }
+  const size_t e0 = start + (size_t)threadIdx.x * V;
+  for (int it = 0; it < iters; it += CL_UNROLL) {
+    float xa[CL_UNROLL][V], xb[CL_UNROLL][V], gv[CL_UNROLL][V];
+#pragma unroll
+    for (int u = 0; u < CL_UNROLL; ++u) {
+      const size_t e = e0 + (size_t)(it + u) * piece, ee = e < end ? e : home;
+      Vec<T, V>::ld(x1 + ee, xa[u]);
+      Vec<T, V>::ld(x2 + ee, xb[u]);
+      Vec<T, V>::ld(gy + (ee >> cshift) * ldgy + (ee & (size_t)(C - 1)), gv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < CL_UNROLL; ++u) {
+      const float live = e0 + (size_t)(it + u) * piece < end ? 1.f : 0.f;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float h1 = (xa[u][j] - m1[j]) * r1[j], h2 = (xb[u][j] - m2[j]) * r2[j];
+        const float dz = live * gv[u][j] * act_bwd(fmaf(h2, ga2[j], fmaf(h1, ga1[j], be[j])), act);
+        acc[j] += dz; acc[V + j] = fmaf(dz, h1, acc[V + j]); acc[2 * V + j] = fmaf(dz, h2, acc[2 * V + j]);
+      }
+    }
+  }
+  fold_row_lanes<3 * V>(acc, s_acc, s_col, cg);
+  for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+    float* o = part + ((size_t)c * S + blockIdx.x) * 3;
+    o[0] = s_col[(c / V) * 3 * V + c % V]; o[1] = s_col[(c / V) * 3 * V + V + c % V]; o[2] = s_col[(c / V) * 3 * V + 2 * V + c % V];
+  }
+}
+
+// sums[c][3] over the S chunks; d(beta) of both BatchNorms = sum dz, d(gamma_i) = sum dz * xhat_i
+__global__ __launch_bounds__(BN_THREADS) void bncl2_sum_kernel(const float* __restrict__ part, float* __restrict__ sums, float* __restrict__ gg1,
+                                                                float* __restrict__ gb1, float* __restrict__ gg2, float* __restrict__ gb2, int S) {
+  __shared__ float s_red[BN_THREADS / WAVE];
+  const int c = blockIdx.x;
+  float a = 0.f, b = 0.f, d = 0.f;
+  for (int s = threadIdx.x; s < S; s += BN_THREADS) {
+    const float* p = part + ((size_t)c * S + s) * 3;
+    a += p[0]; b += p[1]; d += p[2];
+  }
+  a = block_sum(a, s_red); b = block_sum(b, s_red); d = block_sum(d, s_red);
+  if (threadIdx.x == 0) { sums[3 * c] = a; sums[3 * c + 1] = b; sums[3 * c + 2] = d; gb1[c] = a; gb2[c] = a; gg1[c] = b; gg2[c] = d; }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(BN_THREADS) void bncl2_bwd_apply_kernel(const T* __restrict__ gy, const T* __restrict__ x1, const T* __restrict__ x2,
+                                                                      const float* __restrict__ mr1, const float* __restrict__ mr2,
+                                                                      const float* __restrict__ g1, const float* __restrict__ b1,
+                                                                      const float* __restrict__ g2, const float* __restrict__ b2,
+                                                                      const float* __restrict__ sums, T* __restrict__ gx1, T* __restrict__ gx2,
+                                                                      size_t total, int C, int iters, int act, float inv_count, size_t ldgy,
+                                                                      int cshift) {
+  const size_t piece = (size_t)BN_THREADS * V, start = (size_t)blockIdx.x * iters * piece, end = min(total, start + iters * piece);
+  const int c0 = (threadIdx.x % (C / V)) * V;
+  const size_t home = start + c0;
+  float m1[V], r1[V], m2[V], r2[V], ga1[V], ga2[V], be[V], k1[V], k2[V], k3[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    m1[j] = mr1[2 * (c0 + j)]; r1[j] = mr1[2 * (c0 + j) + 1]; m2[j] = mr2[2 * (c0 + j)]; r2[j] = mr2[2 * (c0 + j) + 1];
+    ga1[j] = g1[c0 + j]; ga2[j] = g2[c0 + j]; be[j] = b1[c0 + j] + b2[c0 + j];
+    k1[j] = sums[3 * (c0 + j)] * inv_count; k2[j] = sums[3 * (c0 + j) + 1] * inv_count; k3[j] = sums[3 * (c0 + j) + 2] * inv_count;
+  }
+  const size_t e0 = start + (size_t)threadIdx.x * V;
+  for (int it = 0; it < iters; it += CL_UNROLL / 2) {   // three streams in, two out: half the unroll keeps the registers in bounds
+    float xa[CL_UNROLL / 2][V], xb[CL_UNROLL / 2][V], gv[CL_UNROLL / 2][V];
+#pragma unroll
+    for (int u = 0; u < CL_UNROLL / 2; ++u) {
+      const size_t e = e0 + (size_t)(it + u) * piece, ee = e < end ? e : home;
+      Vec<T, V>::ld(x1 + ee, xa[u]);
+      Vec<T, V>::ld(x2 + ee, xb[u]);
+      Vec<T, V>::ld(gy + (ee >> cshift) * ldgy + (ee & (size_t)(C - 1)), gv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < CL_UNROLL / 2; ++u) {
+      const size_t e = e0 + (size_t)(it + u) * piece;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float h1 = (xa[u][j] - m1[j]) * r1[j], h2 = (xb[u][j] - m2[j]) * r2[j];
+        const float dz = gv[u][j] * act_bwd(fmaf(h2, ga2[j], fmaf(h1, ga1[j], be[j])), act);
+        xa[u][j] = ga1[j] * r1[j] * (dz - k1[j] - h1 * k2[j]);
+        xb[u][j] = ga2[j] * r2[j] * (dz - k1[j] - h2 * k3[j]);
+      }
+      if (e < end) { Vec<T, V>::st(gx1 + e, xa[u]); Vec<T, V>::st(gx2 + e, xb[u]); }
     }
   }
 }
@@ -543,12 +693,13 @@ static int bncl_check(const void* a, const void* b, long long N, int C, int dtyp
   return TAMTR_OK;
 }
 
-extern "C" int tamtr_bncl_act_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y,
-                                  float* mean_rstd, float* partials, long long N, int C, float eps, float momentum, int act, int dtype,
-                                  void* stream) {
+extern "C" int tamtr_bncl_act_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                  const void* residual, void* y, float* mean_rstd, float* partials, long long N, int C, float eps,
+                                  float momentum, int act, int dtype, void* stream) {
   const int rc = bncl_check(x, y, N, C, dtype, act);
   if (rc) return rc;
   if (!gamma || !beta || !mean_rstd || !partials) return TAMTR_EINVAL;
+  if (residual && (uintptr_t)residual % 16) return TAMTR_EUNSUP;
   const int S = tamtr_bncl_blocks(N, C, dtype), V = bncl_vec(C, dtype), iters = bncl_iters(N, C, dtype);
   const size_t total = (size_t)N * C;
   hipStream_t s = (hipStream_t)stream;
@@ -557,11 +708,11 @@ extern "C" int tamtr_bncl_act_fwd(const void* x, const float* gamma, const float
   else hipLaunchKernelGGL((bncl_stats_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)x, partials, total, C, iters);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_THREADS), 0, s, partials, mean_rstd, running_mean, running_var, S, eps, momentum);
   if (dtype == TAMTR_F32)
-    hipLaunchKernelGGL((bncl_apply_kernel<float, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const float*)x, mean_rstd, gamma, beta, (float*)y, total, C, iters, act);
+    hipLaunchKernelGGL((bncl_apply_kernel<float, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const float*)x, mean_rstd, gamma, beta, (const float*)residual, (float*)y, total, C, iters, act);
   else if (V == 8)
-    hipLaunchKernelGGL((bncl_apply_kernel<bf16_t, 8>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)x, mean_rstd, gamma, beta, (bf16_t*)y, total, C, iters, act);
+    hipLaunchKernelGGL((bncl_apply_kernel<bf16_t, 8>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)x, mean_rstd, gamma, beta, (const bf16_t*)residual, (bf16_t*)y, total, C, iters, act);
   else
-    hipLaunchKernelGGL((bncl_apply_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)x, mean_rstd, gamma, beta, (bf16_t*)y, total, C, iters, act);
+    hipLaunchKernelGGL((bncl_apply_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)x, mean_rstd, gamma, beta, (const bf16_t*)residual, (bf16_t*)y, total, C, iters, act);
   return tamtr_launch_status();
 }
 
@@ -592,5 +743,67 @@ extern "C" int tamtr_bncl_act_bwd(const void* gy, long long ldgy, const void* x,
     hipLaunchKernelGGL((bncl_bwd_apply_kernel<bf16_t, 8>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, sums, (bf16_t*)gx, total, C, iters, act, inv, (size_t)ldgy, cshift);
   else
     hipLaunchKernelGGL((bncl_bwd_apply_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, sums, (bf16_t*)gx, total, C, iters, act, inv, (size_t)ldgy, cshift);
+  return tamtr_launch_status();
+}
+
+// ---- y = act(bn1(x1) + bn2(x2)): both BatchNorms in training mode over the same [N, C] shape (RepConvN)
+extern "C" int tamtr_bncl2_act_fwd(const void* x1, const float* gamma1, const float* beta1, float* running_mean1, float* running_var1,
+                                   const void* x2, const float* gamma2, const float* beta2, float* running_mean2, float* running_var2,
+                                   void* y, float* mean_rstd, float* partials, long long N, int C, float eps, float momentum, int act,
+                                   int dtype, void* stream) {
+  int rc = bncl_check(x1, y, N, C, dtype, act);
+  if (!rc) rc = bncl_check(x2, y, N, C, dtype, act);
+  if (rc) return rc;
+  if (!gamma1 || !beta1 || !gamma2 || !beta2 || !mean_rstd || !partials) return TAMTR_EINVAL;
+  const int S = tamtr_bncl_blocks(N, C, dtype), V = bncl_vec(C, dtype), iters = bncl_iters(N, C, dtype);
+  const size_t total = (size_t)N * C;
+  hipStream_t s = (hipStream_t)stream;
+  float* mr2 = mean_rstd + 2 * (size_t)C;           // [2][C][2]
+  float* part2 = partials + (size_t)C * S * 3;      // [2][C][S][3]
+#define STATS(T, VV, X, P) hipLaunchKernelGGL((bncl_stats_kernel<T, VV>), dim3(S), dim3(BN_THREADS), 0, s, (const T*)X, P, total, C, iters)
+#define APPLY(T, VV)                                                                                                                   \
+  hipLaunchKernelGGL((bncl2_apply_kernel<T, VV>), dim3(S), dim3(BN_THREADS), 0, s, (const T*)x1, (const T*)x2, mean_rstd, mr2, gamma1, beta1, \
+                     gamma2, beta2, (T*)y, total, C, iters, act)
+  if (dtype == TAMTR_F32) { STATS(float, 4, x1, partials); STATS(float, 4, x2, part2); }
+  else if (V == 8) { STATS(bf16_t, 8, x1, partials); STATS(bf16_t, 8, x2, part2); }
+  else { STATS(bf16_t, 4, x1, partials); STATS(bf16_t, 4, x2, part2); }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_THREADS), 0, s, partials, mean_rstd, running_mean1, running_var1, S, eps, momentum);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_THREADS), 0, s, part2, mr2, running_mean2, running_var2, S, eps, momentum);
+  if (dtype == TAMTR_F32) APPLY(float, 4); else if (V == 8) APPLY(bf16_t, 8); else APPLY(bf16_t, 4);
+#undef STATS
+#undef APPLY
+  return tamtr_launch_status();
+}
+
+extern "C" int tamtr_bncl2_act_bwd(const void* gy, long long ldgy, const void* x1, const void* x2, const float* gamma1, const float* beta1,
+                                   const float* gamma2, const float* beta2, const float* mean_rstd, void* gx1, void* gx2, float* ggamma1,
+                                   float* gbeta1, float* ggamma2, float* gbeta2, float* partials, long long N, int C, int act, int dtype,
+                                   void* stream) {
+  int rc = bncl_check(gy, x1, N, C, dtype, act);
+  if (!rc) rc = bncl_check(x2, gx1, N, C, dtype, act);
+  if (rc) return rc;
+  if (!gamma1 || !beta1 || !gamma2 || !beta2 || !mean_rstd || !gx2 || !ggamma1 || !gbeta1 || !ggamma2 || !gbeta2 || !partials ||
+      (uintptr_t)gx2 % 16)
+    return TAMTR_EINVAL;
+  if (ldgy < C || ldgy % bncl_vec(C, dtype) || (C & (C - 1))) return TAMTR_EUNSUP;
+  int cshift = 0;
+  while ((1 << cshift) < C) ++cshift;
+  const int S = tamtr_bncl_blocks(N, C, dtype), V = bncl_vec(C, dtype), iters = bncl_iters(N, C, dtype);
+  const size_t total = (size_t)N * C;
+  hipStream_t s = (hipStream_t)stream;
+  const float* mr2 = mean_rstd + 2 * (size_t)C;
+  float* sums = partials + (size_t)C * S * 3;  // [C][3] after the per-chunk partials
+  const float inv = 1.f / (float)N;
+#define RED(T, VV)                                                                                                                       \
+  hipLaunchKernelGGL((bncl2_bwd_reduce_kernel<T, VV>), dim3(S), dim3(BN_THREADS), 0, s, (const T*)gy, (const T*)x1, (const T*)x2, mean_rstd, mr2, \
+                     gamma1, beta1, gamma2, beta2, partials, total, C, iters, act, (size_t)ldgy, cshift)
+#define APP(T, VV)                                                                                                                       \
+  hipLaunchKernelGGL((bncl2_bwd_apply_kernel<T, VV>), dim3(S), dim3(BN_THREADS), 0, s, (const T*)gy, (const T*)x1, (const T*)x2, mean_rstd, mr2,  \
+                     gamma1, beta1, gamma2, beta2, sums, (T*)gx1, (T*)gx2, total, C, iters, act, inv, (size_t)ldgy, cshift)
+  if (dtype == TAMTR_F32) RED(float, 4); else if (V == 8) RED(bf16_t, 8); else RED(bf16_t, 4);
+  hipLaunchKernelGGL(bncl2_sum_kernel, dim3(C), dim3(BN_THREADS), 0, s, partials, sums, ggamma1, gbeta1, ggamma2, gbeta2, S);
+  if (dtype == TAMTR_F32) APP(float, 4); else if (V == 8) APP(bf16_t, 8); else APP(bf16_t, 4);
+#undef RED
+#undef APP
   return tamtr_launch_status();
 }

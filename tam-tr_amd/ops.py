@@ -27,6 +27,10 @@ def _is_cl(t):
     return t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last)
 
 
+def is_cl(t):
+    return _is_cl(t)
+
+
 def _cl_pitch(t):
     """Pixel pitch ld if t [B,C,H,W] is a channels-last map or a channel slice of one (strides (H*W*ld, 1, W*ld, ld), ld >= C), else 0."""
     if t.dim() != 4:
@@ -1068,7 +1072,7 @@ class _BNActCL(torch.autograd.Function):
     """Same on a channels-last [N, C] map (token-major)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, silu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, silu, residual=None):
         require_gpu(x, gamma, beta)
         x = _c(x)
         N, C = x.shape
@@ -1076,27 +1080,69 @@ class _BNActCL(torch.autograd.Function):
         y = torch.empty_like(x)
         mr = torch.empty(C, 2, device=x.device, dtype=torch.float32)
         part = torch.empty(C * _lib.lib().tamtr_bncl_blocks(N, C, dtype_code(x)) * 3, device=x.device, dtype=torch.float32)
-        call('tamtr_bncl_act_fwd', ptr(x), ptr(g32), ptr(b32), ptr(running_mean), ptr(running_var), ptr(y), ptr(mr), ptr(part), N, C,
+        res = None if residual is None else _c(residual.to(x.dtype))
+        call('tamtr_bncl_act_fwd', ptr(x), ptr(g32), ptr(b32), ptr(running_mean), ptr(running_var), ptr(res), ptr(y), ptr(mr), ptr(part), N, C,
              float(eps), float(momentum), int(bool(silu)), dtype_code(x), stream_ptr())
         ctx.save_for_backward(x, g32, b32, mr)
-        ctx.cfg = (int(bool(silu)), gamma.dtype, beta.dtype)
+        ctx.cfg = (int(bool(silu)), gamma.dtype, beta.dtype, None if residual is None else residual.dtype)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, g32, b32, mr = ctx.saved_tensors
-        act, g_dt, b_dt = ctx.cfg
+        act, g_dt, b_dt, res_dt = ctx.cfg
         N, C = x.shape
-        gy = gy.to(x.dtype)
-        v = 8 if (x.dtype == torch.bfloat16 and C % 8 == 0) else 4
-        if not (gy.stride(1) == 1 and gy.stride(0) >= C and gy.stride(0) % v == 0 and gy.data_ptr() % 16 == 0 and (C & (C - 1)) == 0):
-            gy = gy.contiguous()   # (a channel slice of a concatenation's gradient is read in place through its row pitch)
+        g_res = None if res_dt is None else gy.to(res_dt)   # y = act(bn(x)) + residual: the shortcut's gradient is gy itself
+        gy = _gy_rows(gy, x)   # (a channel slice of a concatenation's gradient is read in place through its row pitch)
         gx = torch.empty_like(x)
         gg, gb = torch.empty(C, device=x.device, dtype=torch.float32), torch.empty(C, device=x.device, dtype=torch.float32)
         part = torch.empty(C * _lib.lib().tamtr_bncl_blocks(N, C, dtype_code(x)) * 2 + 2 * C, device=x.device, dtype=torch.float32)
         call('tamtr_bncl_act_bwd', ptr(gy), gy.stride(0), ptr(x), ptr(g32), ptr(b32), ptr(mr), ptr(gx), ptr(gg), ptr(gb), ptr(part), N, C, act,
              dtype_code(x), stream_ptr())
-        return gx, gg.to(g_dt), gb.to(b_dt), None, None, None, None, None
+        return gx, gg.to(g_dt), gb.to(b_dt), None, None, None, None, None, g_res
+
+
+def _gy_rows(gy, x):
+    """gy as the kernels take it: x's dtype, unit column stride, 16-byte aligned rows (a channel slice of a wider map is fine)."""
+    C = x.shape[1]
+    gy = gy.to(x.dtype)
+    v = 8 if (x.dtype == torch.bfloat16 and C % 8 == 0) else 4
+    if not (gy.stride(1) == 1 and gy.stride(0) >= C and gy.stride(0) % v == 0 and gy.data_ptr() % 16 == 0 and (C & (C - 1)) == 0):
+        gy = gy.contiguous()
+    return gy
+
+
+class _BN2ActCL(torch.autograd.Function):
+    """y = act(bn1(x1) + bn2(x2)) on channels-last [N, C] maps, both BatchNorms in training mode: RepConvN's training form
+    (extra_modules/block.py:66-69) in one apply pass and one backward pair (csrc/bn.hip tamtr_bncl2_act_*)."""
+
+    @staticmethod
+    def forward(ctx, x1, ga1, be1, rm1, rv1, x2, ga2, be2, rm2, rv2, eps, momentum, silu):
+        require_gpu(x1, x2, ga1, ga2)
+        x1, x2 = _c(x1), _c(x2)
+        N, C = x1.shape
+        p1 = [_c(t.float()) for t in (ga1, be1, ga2, be2)]
+        y = torch.empty_like(x1)
+        mr = torch.empty(2, C, 2, device=x1.device, dtype=torch.float32)
+        part = torch.empty(2 * C * _lib.lib().tamtr_bncl_blocks(N, C, dtype_code(x1)) * 3, device=x1.device, dtype=torch.float32)
+        call('tamtr_bncl2_act_fwd', ptr(x1), ptr(p1[0]), ptr(p1[1]), ptr(rm1), ptr(rv1), ptr(x2), ptr(p1[2]), ptr(p1[3]), ptr(rm2), ptr(rv2),
+             ptr(y), ptr(mr), ptr(part), N, C, float(eps), float(momentum), int(bool(silu)), dtype_code(x1), stream_ptr())
+        ctx.save_for_backward(x1, x2, *p1, mr)
+        ctx.cfg = (int(bool(silu)), ga1.dtype, be1.dtype, ga2.dtype, be2.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x1, x2, g1, b1, g2, b2, mr = ctx.saved_tensors
+        act, dt_g1, dt_b1, dt_g2, dt_b2 = ctx.cfg
+        N, C = x1.shape
+        gy = _gy_rows(gy, x1)
+        gx1, gx2 = torch.empty_like(x1), torch.empty_like(x2)
+        gg = torch.empty(4, C, device=x1.device, dtype=torch.float32)
+        part = torch.empty(C * _lib.lib().tamtr_bncl_blocks(N, C, dtype_code(x1)) * 3 + 3 * C, device=x1.device, dtype=torch.float32)
+        call('tamtr_bncl2_act_bwd', ptr(gy), gy.stride(0), ptr(x1), ptr(x2), ptr(g1), ptr(b1), ptr(g2), ptr(b2), ptr(mr), ptr(gx1), ptr(gx2),
+             gg[0].data_ptr(), gg[1].data_ptr(), gg[2].data_ptr(), gg[3].data_ptr(), ptr(part), N, C, act, dtype_code(x1), stream_ptr())
+        return (gx1, gg[0].to(dt_g1), gg[1].to(dt_b1), None, None, gx2, gg[2].to(dt_g2), gg[3].to(dt_b2), None, None, None, None, None)
 
 
 _BN_COUNTERS = None
@@ -1122,14 +1168,32 @@ def bn_cl_ok(C, dtype):
     return C % 4 == 0 and C <= 1024 and C // v <= 256 and 256 % (C // v) == 0
 
 
-def bn_act(x, bn, silu):
-    """act(bn(x)) for an nn.BatchNorm2d in training mode (batch statistics; running stats and num_batches_tracked updated)."""
+def _bn_tick(bn):
+    """num_batches_tracked += 1 (deferred to one multi-tensor kernel inside a counter batch) and the momentum of this call."""
     if bn.track_running_stats:
         if _BN_COUNTERS is not None and bn.momentum is not None:
             _BN_COUNTERS.append(bn.num_batches_tracked)
         else:
             bn.num_batches_tracked += 1
-    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-    fn = _BNActCL if x.dim() == 2 else _BNAct   # [N, C] token-major map vs NCHW
-    return fn.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
-                    bn.running_var if bn.track_running_stats else None, bn.eps, mom, silu)
+    return bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+
+
+def bn_act(x, bn, silu, residual=None):
+    """act(bn(x)) [+ residual] for an nn.BatchNorm2d in training mode (batch statistics; running stats and num_batches_tracked
+    updated).  residual: only with the channels-last [N, C] form."""
+    mom = _bn_tick(bn)
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    if x.dim() == 2:   # [N, C] token-major / channels-last map
+        return _BNActCL.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, mom, silu, residual)
+    y = _BNAct.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, mom, silu)
+    return y if residual is None else y + residual
+
+
+def bn2_act(x1, bn1, x2, bn2, silu):
+    """act(bn1(x1) + bn2(x2)) on channels-last [N, C] maps, both BatchNorm2d in training mode with running statistics."""
+    if bn1.eps != bn2.eps or bn1.momentum != bn2.momentum or not (bn1.track_running_stats and bn2.track_running_stats):
+        raise _lib.TamtrHipError('bn2_act: the two BatchNorms must share eps / momentum and track running statistics')
+    mom = _bn_tick(bn1)
+    _bn_tick(bn2)
+    return _BN2ActCL.apply(x1, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, x2, bn2.weight, bn2.bias, bn2.running_mean,
+                           bn2.running_var, bn1.eps, mom, silu)

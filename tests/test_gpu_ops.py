@@ -616,3 +616,50 @@ def test_nearest_resampling_channels_last(ops, scale, dt):
     assert out.is_contiguous(memory_format=torch.channels_last) and torch.equal(out.float().cpu(), ref.detach())
     (out.float() * cot.cuda()).sum().backward()
     assert_close(xd.grad.float().cpu(), xr.grad, 1e-2 if dt == torch.bfloat16 else 1e-6, 1e-6, 'resample dx')
+
+
+# ------------------------------------------------------------------------------------------------ RepConvN / bottleneck forms of BatchNorm
+@pytest.mark.parametrize('N,C,dt,silu', [(3000, 64, torch.bfloat16, True), (777, 32, torch.float32, True), (4100, 128, torch.float32, False)])
+def test_bn_pair_and_shortcut_vs_torch(ops, N, C, dt, silu):
+    """tamtr_bncl2_act_*: y = act(bn1(x1) + bn2(x2)) (RepConvN, extra_modules/block.py:66-69) and tamtr_bncl_act_fwd's residual input
+    (x + cv2(cv1(x)), block.py:100-102) against nn.BatchNorm1d / SiLU / add on the CPU: outputs, running statistics, all gradients."""
+    import copy
+    import torch.nn as nn
+    x1, x2, r = ((rnd((N, C), s_) * 1.3 + 0.2 * s_).to(dt).float() for s_ in (1, 2, 3))
+    cot = rnd((N, C), 4).to(dt).float()
+    ref1, ref2 = nn.BatchNorm1d(C, eps=1e-3, momentum=0.03), nn.BatchNorm1d(C, eps=1e-3, momentum=0.03)
+    with torch.no_grad():
+        ref1.weight.copy_(1 + 0.3 * rnd((C,), 5)); ref1.bias.copy_(0.2 * rnd((C,), 6))
+        ref2.weight.copy_(1 - 0.2 * rnd((C,), 7)); ref2.bias.copy_(0.1 * rnd((C,), 8))
+    d1, d2 = copy.deepcopy(ref1).cuda(), copy.deepcopy(ref2).cuda()
+    act = torch.nn.functional.silu if silu else (lambda t: t)
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    # pair
+    a, b = x1.clone().requires_grad_(), x2.clone().requires_grad_()
+    ref = act(ref1(a) + ref2(b))
+    (ref * cot).sum().backward()
+    ad, bd = dev(x1, dt).requires_grad_(), dev(x2, dt).requires_grad_()
+    out = ops.bn2_act(ad, d1, bd, d2, silu)
+    (out.float() * dev(cot)).sum().backward()
+    assert_close(out.float(), ref, tol, tol, 'pair out')
+    for m_d, m_r in ((d1, ref1), (d2, ref2)):
+        assert_close(m_d.running_mean, m_r.running_mean, 1e-5, 1e-6, 'running_mean')
+        assert_close(m_d.running_var, m_r.running_var, 1e-5, 1e-6, 'running_var')
+        assert int(m_d.num_batches_tracked) == 1
+        assert_close(m_d.weight.grad, m_r.weight.grad, 10 * tol, 10 * tol * N ** 0.5, 'pair dgamma')
+        assert_close(m_d.bias.grad, m_r.bias.grad, 10 * tol, 10 * tol * N ** 0.5, 'pair dbeta')
+    assert_close(ad.grad.float(), a.grad, 10 * tol, 10 * tol, 'pair dx1')
+    assert_close(bd.grad.float(), b.grad, 10 * tol, 10 * tol, 'pair dx2')
+    # shortcut
+    for m in (ref1, d1):
+        m.zero_grad(set_to_none=True)
+    a, rr = x1.clone().requires_grad_(), r.clone().requires_grad_()
+    ref = act(ref1(a)) + rr
+    (ref * cot).sum().backward()
+    ad, rd = dev(x1, dt).requires_grad_(), dev(r, dt).requires_grad_()
+    out = ops.bn_act(ad, d1, silu, rd)
+    (out.float() * dev(cot)).sum().backward()
+    assert_close(out.float(), ref, tol, tol, 'shortcut out')
+    assert_close(ad.grad.float(), a.grad, 10 * tol, 10 * tol, 'shortcut dx')
+    assert_close(rd.grad.float(), rr.grad, tol, tol, 'shortcut dres')
+    assert_close(d1.weight.grad, ref1.weight.grad, 10 * tol, 10 * tol * N ** 0.5, 'shortcut dgamma')
