@@ -30,7 +30,8 @@ class GraphedPart:
         if not all(isinstance(a, torch.Tensor) and a.is_cuda for a in sample_args):
             raise ValueError('sample_args must be CUDA tensors')
         from . import GRAPH_REPLAY_SAFE
-        if os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') != '0' or not GRAPH_REPLAY_SAFE:
+        if (os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') != '0' or not GRAPH_REPLAY_SAFE) and os.environ.get('TAMTR_GRAPH_TIMING_ONLY') != '1':
+            # (TAMTR_GRAPH_TIMING_ONLY=1: timing experiments with the runtime's packet capture on - gradients may be garbage)
             raise RuntimeError('GraphedPart needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before the HIP runtime starts (see the module docstring)')
         self.module = module
         self.names, self.params = zip(*[(n, p) for n, p in module.named_parameters()])

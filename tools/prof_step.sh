@@ -6,6 +6,7 @@ rm -rf gpurun_out/prof_step
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_step -o st --output-format csv -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_step_bench.json 2> gpurun_out/prof_step_bench.err
 ms=$(python3 -c "import json; print(json.load(open('gpurun_out/prof_step_bench.json'))['ms_per_step'])")
 python3 tools/prof_summary.py gpurun_out/prof_step/st_kernel_trace.csv 10 $ms 70 > gpurun_out/prof_step_$tag.txt
+python3 tools/gemm_launches.py gpurun_out/prof_step/st_kernel_trace.csv 10 $ms > gpurun_out/prof_step_${tag}_gemm_launches.txt
 cp gpurun_out/prof_step/st_kernel_stats.csv gpurun_out/prof_step_${tag}_kernel_stats.csv
 rm -rf gpurun_out/prof_step
 head -75 gpurun_out/prof_step_$tag.txt
