@@ -254,3 +254,43 @@ def test_shipped_convolution_tables_match_this_miopen_build():
     text = open(files[0]).read()
     assert '3-640-640-3x3-64-320-320-16' in text and 'BF16' in text and 'FP32' in text   # first trunk layer at 640 px / 16 images, both modes
     assert tuning.use_tuned_convolutions('off').startswith('off')
+
+
+def test_trunk_glue_falls_back_to_torch_on_cpu():
+    """The NHWC glue ops (ops.cat_channels / pack_channels / max_pool2d / to_nchw / to_channels_last, backbone.Upsample) only take their
+    HIP kernels for CUDA maps; CPU tensors (the CPU suite, the oracle-side tests) go through torch with identical results."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from tamtr_amd import ops
+    from tamtr_amd.backbone import Upsample
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(2, 8, 6, 10, generator=g).contiguous(memory_format=torch.channels_last)
+    h0, h1 = a.chunk(2, 1)
+    assert torch.equal(ops.cat_channels([h0, h1, a]), torch.cat([h0, h1, a], 1))
+    assert ops.pack_channels(h1) is h1
+    assert torch.equal(ops.max_pool2d(a, 5, 1, 2), F.max_pool2d(a, 5, 1, 2))
+    assert torch.equal(ops.to_nchw(a), a) and ops.to_nchw(a).is_contiguous()
+    assert torch.equal(ops.to_channels_last(a.contiguous()), a)
+    for scale in (2.0, 0.5):
+        assert torch.equal(Upsample(scale_factor=scale, mode='nearest')(a), nn.Upsample(scale_factor=scale, mode='nearest')(a))
+    assert ops._cl_pitch(h1) == 8 and ops._cl_pitch(a) == 8 and ops._cl_pitch(a.contiguous()) == 0 and ops._cl_pitch(a[..., ::2, ::2]) == 0
+
+
+def test_bottleneck_shortcut_and_repconvn_on_cpu_match_their_definition():
+    """RepNBottleneck passes its shortcut into cv2 (Conv.forward(x, residual=x)) and RepConvN evaluates both branches' convolutions
+    before their BatchNorms; on CPU these are plain torch ops and must equal x + cv2(cv1(x)) / act(bn(conv3(x)) + bn(conv1(x)))
+    (extra_modules/block.py:66-69,100-102)."""
+    from tamtr_amd.backbone import RepConvN, RepNBottleneck
+    torch.manual_seed(0)
+    blk = RepNBottleneck(16, 16).train()
+    x = torch.randn(2, 16, 9, 7)
+    ref_state = {k: v.clone() for k, v in blk.state_dict().items()}
+    y = blk(x)
+    blk.load_state_dict(ref_state)   # BatchNorm statistics moved: same starting point for the by-hand evaluation
+    r = blk.cv1
+    by_hand = r.act(r.conv1.bn(r.conv1.conv(x)) + r.conv2.bn(r.conv2.conv(x)))
+    by_hand = x + blk.cv2.act(blk.cv2.bn(blk.cv2.conv(by_hand)))
+    assert torch.allclose(y, by_hand, rtol=1e-6, atol=1e-6)
+    assert int(blk.cv2.bn.num_batches_tracked) == 1 and int(r.conv1.bn.num_batches_tracked) == 1
+    plain = RepNBottleneck(16, 8).train()   # no shortcut when the widths differ
+    assert plain(x).shape == (2, 8, 9, 7) and not plain.add
