@@ -59,6 +59,17 @@ int tamtr_maxsigmoid_gate_fwd(const void* x, const float* gk, const float* bias,
 int tamtr_maxsigmoid_gate_bwd(const void* dout, const void* x, const float* gk, const void* v, const float* aw,
                               const int32_t* arg, void* dx, void* dv, float* dlogit, int B, int nh, int hc, int HW, int T,
                               float scale, int dtype, void* stream);
+/*      Channels-last forward with the branches' BatchNorm folded into the load (`self.proj_conv` = Conv3x3 + BN,
+ *      block.py:205,223; `self.ec`, block.py:203): e (T) [B*HW, C] with row pitch ld_e elements (embed; a channel slice of a wider
+ *      NHWC map is fine), v (T) [B*HW, C] packed = the RAW convolution output of the value branch; mean_rstd_* f32 [C][2] (batch mean,
+ *      1/sqrt(var + eps), as tamtr_bncl_stats writes them), gamma_* / beta_* f32 [C]; a NULL mean_rstd_* means "already normalised /
+ *      no BatchNorm" for that operand.  out (T) [B*HW, C] packed; aw / arg as above or NULL when no backward will follow.
+ *      C = nh*hc <= 512, C/8 and hc/8 powers of two.
+ */
+int tamtr_maxsigmoid_gate_cl_fwd(const void* e, long long ld_e, const float* mean_rstd_e, const float* gamma_e, const float* beta_e,
+                                 const void* v, const float* mean_rstd_v, const float* gamma_v, const float* beta_v, const float* gk,
+                                 const float* bias, void* out, float* aw, int32_t* arg, int B, int nh, int hc, int HW, int T, float scale,
+                                 int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * a-6  Multi-scale deformable attention core.  Replaces multi_scale_deformable_attn_pytorch,
@@ -289,6 +300,8 @@ int tamtr_bncl_act_fwd(const void* x, const float* gamma, const float* beta, flo
  *      `self.act(self.conv1(x) + self.conv2(x))` (block.py:66-69).  mean_rstd f32 [2][C][2]; partials 2 * C * S * 3 floats forward,
  *      C * S * 3 + 3 * C backward.
  */
+int tamtr_bncl_stats(const void* x, float* running_mean, float* running_var, float* mean_rstd, float* partials, long long N, int C, float eps,
+                     float momentum, int dtype, void* stream);   /* batch statistics + running update only: mean_rstd f32 [C][2] */
 int tamtr_bncl2_act_fwd(const void* x1, const float* gamma1, const float* beta1, float* running_mean1, float* running_var1, const void* x2,
                         const float* gamma2, const float* beta2, float* running_mean2, float* running_var2, void* y, float* mean_rstd,
                         float* partials, long long N, int C, float eps, float momentum, int act, int dtype, void* stream);

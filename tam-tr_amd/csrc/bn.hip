@@ -807,3 +807,20 @@ extern "C" int tamtr_bncl2_act_bwd(const void* gy, long long ldgy, const void* x
 #undef APP
   return tamtr_launch_status();
 }
+
+// ---- batch statistics only (for a consumer that applies the normalisation itself: the channels-last gate, gate.hip):
+// mean_rstd f32 [C][2] of x [N, C] plus the running-statistics update; partials as for tamtr_bncl_act_fwd
+extern "C" int tamtr_bncl_stats(const void* x, float* running_mean, float* running_var, float* mean_rstd, float* partials, long long N, int C,
+                                float eps, float momentum, int dtype, void* stream) {
+  const int rc = bncl_check(x, mean_rstd, N, C, dtype, 0);
+  if (rc) return rc;
+  if (!partials) return TAMTR_EINVAL;
+  const int S = tamtr_bncl_blocks(N, C, dtype), V = bncl_vec(C, dtype), iters = bncl_iters(N, C, dtype);
+  const size_t total = (size_t)N * C;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == TAMTR_F32) hipLaunchKernelGGL((bncl_stats_kernel<float, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const float*)x, partials, total, C, iters);
+  else if (V == 8) hipLaunchKernelGGL((bncl_stats_kernel<bf16_t, 8>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)x, partials, total, C, iters);
+  else hipLaunchKernelGGL((bncl_stats_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)x, partials, total, C, iters);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_THREADS), 0, s, partials, mean_rstd, running_mean, running_var, S, eps, momentum);
+  return tamtr_launch_status();
+}

@@ -160,6 +160,71 @@ inline bool gate_args_ok(int B, int nh, int hc, int HW, int T) {
   return B > 0 && nh > 0 && hc > 0 && HW > 0 && T > 0 && nh <= 65535 && B <= 65535;
 }
 
+
+// ---- channels-last forward with the value branch's BatchNorm folded into the load (second half).
+// Reference: `self.proj_conv(x)` = Conv3x3 + BatchNorm (block.py:205,223) feeding `x * aw` (block.py:224-226); the embed branch
+// (`self.ec`, block.py:203) likewise when it exists (it is None in every TAM-TR instance: embed = x).  With the NHWC trunk both
+// operands arrive pixel-major; as separate ops the value branch cost a BatchNorm apply pass and each operand a transpose to the NCHW
+// planes of gate_fwd_kernel.  Here: e and the RAW convolution output v are read once ([B*HW, C], e possibly a channel slice of a wider
+// map through its row pitch), each lane owns 8 channels and applies its per-channel affine (a = rstd * gamma, b = beta - mean * a,
+// built from the batch statistics) in registers; a head's hc channels sit in hc / 8 adjacent lanes, so the T text dot products are
+// 8 FMAs per lane plus a butterfly over those lanes; max / sigmoid / scale and one 16-byte store.  Text tile [T, C] in LDS.
+template <typename ET>
+__global__ __launch_bounds__(GATE_THREADS) void gate_cl_fwd_kernel(const ET* __restrict__ e, size_t ld_e, const float* __restrict__ mr_e,
+                                                                    const float* __restrict__ ga_e, const float* __restrict__ be_e,
+                                                                    const ET* __restrict__ v, const float* __restrict__ mr_v,
+                                                                    const float* __restrict__ ga_v, const float* __restrict__ be_v,
+                                                                    const float* __restrict__ gk, const float* __restrict__ bias,
+                                                                    ET* __restrict__ out, float* __restrict__ aw_out,
+                                                                    int32_t* __restrict__ arg_out, int C, int hc, int HW, int T, float scale,
+                                                                    int rows_per_wg) {
+  extern __shared__ float s_gk[];  // [T][C]
+  const int b = blockIdx.y, nh = C / hc;
+  for (int i = threadIdx.x; i < T * C; i += GATE_THREADS) s_gk[i] = gk[(size_t)b * T * C + i];
+  __syncthreads();
+  const int lpr = C / 8, rpw = WAVE / lpr;           // lanes per pixel row, rows per wave
+  const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+  const int c0 = (lane % lpr) * 8, rl = lane / lpr, head = c0 / hc, lph = hc / 8;
+  float ae[8], be[8], av[8], bv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ae[j] = 1.f; be[j] = 0.f; av[j] = 1.f; bv[j] = 0.f;
+    if (mr_e) { ae[j] = mr_e[2 * (c0 + j) + 1] * ga_e[c0 + j]; be[j] = be_e[c0 + j] - mr_e[2 * (c0 + j)] * ae[j]; }
+    if (mr_v) { av[j] = mr_v[2 * (c0 + j) + 1] * ga_v[c0 + j]; bv[j] = be_v[c0 + j] - mr_v[2 * (c0 + j)] * av[j]; }
+  }
+  const float rs = rsqrtf((float)hc), bm = bias[head];
+  const int row0 = blockIdx.x * rows_per_wg, row1 = min(row0 + rows_per_wg, HW);
+  for (int r = row0 + wave * rpw + rl; r < row1; r += (GATE_THREADS / WAVE) * rpw) {
+    const size_t row = (size_t)b * HW + r;
+    float ev[8], vv[8];
+    Elt<ET>::ld4(e + row * ld_e + c0, *reinterpret_cast<float(*)[4]>(ev));
+    Elt<ET>::ld4(e + row * ld_e + c0 + 4, *reinterpret_cast<float(*)[4]>(ev + 4));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ev[j] = fmaf(ev[j], ae[j], be[j]);
+    float best = -INFINITY;
+    int besti = 0;
+    for (int t = 0; t < T; ++t) {
+      const float4 g0 = *reinterpret_cast<const float4*>(s_gk + (size_t)t * C + c0), g1 = *reinterpret_cast<const float4*>(s_gk + (size_t)t * C + c0 + 4);
+      float d = ev[0] * g0.x;
+      d = fmaf(ev[1], g0.y, d); d = fmaf(ev[2], g0.z, d); d = fmaf(ev[3], g0.w, d);
+      d = fmaf(ev[4], g1.x, d); d = fmaf(ev[5], g1.y, d); d = fmaf(ev[6], g1.z, d); d = fmaf(ev[7], g1.w, d);
+      for (int o = 1; o < lph; o <<= 1) d += __shfl_xor(d, o, WAVE);
+      if (d > best) { best = d; besti = t; }
+    }
+    const float a = 1.f / (1.f + __expf(-(best * rs + bm)));
+    Elt<ET>::ld4(v + row * C + c0, *reinterpret_cast<float(*)[4]>(vv));
+    Elt<ET>::ld4(v + row * C + c0 + 4, *reinterpret_cast<float(*)[4]>(vv + 4));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vv[j] = fmaf(vv[j], av[j], bv[j]) * (a * scale);
+    Elt<ET>::st4(out + row * C + c0, *reinterpret_cast<float(*)[4]>(vv));
+    Elt<ET>::st4(out + row * C + c0 + 4, *reinterpret_cast<float(*)[4]>(vv + 4));
+    if (aw_out && c0 % hc == 0) {
+      aw_out[((size_t)b * nh + head) * HW + r] = a;
+      if (arg_out) arg_out[((size_t)b * nh + head) * HW + r] = besti;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int tamtr_maxsigmoid_gate_fwd(const void* x, const float* gk, const float* bias, const void* v, void* out,
@@ -200,5 +265,30 @@ extern "C" int tamtr_maxsigmoid_gate_bwd(const void* dout, const void* x, const 
   else if (dtype == TAMTR_BF16) { if (vec) GO(bf16_t, 4); else GO(bf16_t, 1); }
   else return TAMTR_EINVAL;
 #undef GO
+  return tamtr_launch_status();
+}
+
+/* channels-last forward, per-channel affines (BatchNorm of the value / embed branch) applied in the load: see gate_cl_fwd_kernel */
+extern "C" int tamtr_maxsigmoid_gate_cl_fwd(const void* e, long long ld_e, const float* mean_rstd_e, const float* gamma_e, const float* beta_e,
+                                            const void* v, const float* mean_rstd_v, const float* gamma_v, const float* beta_v,
+                                            const float* gk, const float* bias, void* out, float* aw, int32_t* arg, int B, int nh, int hc,
+                                            int HW, int T, float scale, int dtype, void* stream) {
+  if (!e || !v || !gk || !bias || !out || !gate_args_ok(B, nh, hc, HW, T)) return TAMTR_EINVAL;
+  if ((mean_rstd_e && (!gamma_e || !beta_e)) || (mean_rstd_v && (!gamma_v || !beta_v)) || (arg && !aw)) return TAMTR_EINVAL;
+  if (dtype != TAMTR_F32 && dtype != TAMTR_BF16) return TAMTR_EINVAL;
+  const int C = nh * hc, lpr = C / 8, al = dtype == TAMTR_F32 ? 16 : 8;
+  if (C % 8 || hc % 8 || lpr > WAVE || (lpr & (lpr - 1)) || ((hc / 8) & (hc / 8 - 1)) || ld_e < C || ld_e % 4 ||
+      ((uintptr_t)e | (uintptr_t)v | (uintptr_t)out) % al || (size_t)T * C * sizeof(float) > 60 * 1024 || B > 65535)
+    return TAMTR_EUNSUP;
+  const int rows_per_wg = 128;
+  const dim3 grid((HW + rows_per_wg - 1) / rows_per_wg, B);
+  const size_t lds = (size_t)T * C * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == TAMTR_F32)
+    hipLaunchKernelGGL(gate_cl_fwd_kernel<float>, grid, dim3(GATE_THREADS), lds, s, (const float*)e, (size_t)ld_e, mean_rstd_e, gamma_e, beta_e,
+                       (const float*)v, mean_rstd_v, gamma_v, beta_v, gk, bias, (float*)out, aw, arg, C, hc, HW, T, scale, rows_per_wg);
+  else
+    hipLaunchKernelGGL(gate_cl_fwd_kernel<bf16_t>, grid, dim3(GATE_THREADS), lds, s, (const bf16_t*)e, (size_t)ld_e, mean_rstd_e, gamma_e, beta_e,
+                       (const bf16_t*)v, mean_rstd_v, gamma_v, beta_v, gk, bias, (bf16_t*)out, aw, arg, C, hc, HW, T, scale, rows_per_wg);
   return tamtr_launch_status();
 }

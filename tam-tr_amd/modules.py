@@ -39,6 +39,17 @@ class MaxSigmoidAttnBlock(nn.Module):
     def forward(self, x, guide):
         bs, _, h, w = x.shape
         gk = self.gl(guide)  # [B,T,ec]
+        pc = self.proj_conv
+        if (self.ec is None and not torch.is_grad_enabled() and not isinstance(self.scale, torch.Tensor) and 'bn' in pc._modules
+                and pc.bn.training and pc.bn.affine and isinstance(pc.act, nn.Identity) and ops.gate_cl_ok(x, x.shape[1], self.nh)):
+            # NHWC trunk, nothing to differentiate (TIAGELAN's discarded evaluation): the BatchNorm of proj_conv is applied
+            # inside the gate kernel's load of the raw convolution output - no apply pass, no NCHW repacking (next-3)
+            v_raw = pc.conv(x)
+            if ops.is_cl(v_raw) and v_raw.dtype == x.dtype and ops.bn_cl_ok(v_raw.shape[1], v_raw.dtype):
+                stats = ops.bn_stats_cl(v_raw.permute(0, 2, 3, 1).reshape(bs * h * w, -1), pc.bn)
+                return ops.maxsigmoid_gate_cl(x, gk, self.bias, v_raw, stats, pc.bn, self.nh, 1.0)
+            v = pc.post(v_raw)
+            return ops.maxsigmoid_gate(x if x.dtype == v.dtype else x.to(v.dtype), gk, self.bias, v, self.nh, 1.0)
         embed = self.ec(x) if self.ec is not None else x
         v = self.proj_conv(x)
         if embed.dtype != v.dtype:

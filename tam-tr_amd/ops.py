@@ -239,6 +239,46 @@ class _MaxSigmoidGate(torch.autograd.Function):
         return dx, dgk.to(gk_dt), dbias.to(b_dt), dv, None, None
 
 
+def gate_cl_ok(x, C, nh):
+    """Shapes / layouts tamtr_maxsigmoid_gate_cl_fwd takes: x a channels-last CUDA map (or a channel slice of one), C = nh * hc with
+    C / 8 and hc / 8 powers of two, C <= 512."""
+    hc = C // nh if nh else 0
+    lpr, lph = C // 8, hc // 8
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and _cl_pitch(x) and nh * hc == C and C % 8 == 0 and hc % 8 == 0
+            and 0 < lpr <= 64 and lpr & (lpr - 1) == 0 and lph & (lph - 1) == 0 and _cl_pitch(x) % 4 == 0)
+
+
+@torch.no_grad()
+def bn_stats_cl(x2d, bn):
+    """Batch statistics of a channels-last [N, C] map for a consumer that normalises in its own load: mean_rstd f32 [C, 2]; updates the
+    BatchNorm's running statistics and counter like a training-mode forward."""
+    require_gpu(x2d)
+    x2d = _c(x2d)
+    N, C = x2d.shape
+    mom = _bn_tick(bn)
+    mr = torch.empty(C, 2, device=x2d.device, dtype=torch.float32)
+    part = torch.empty(C * _lib.lib().tamtr_bncl_blocks(N, C, dtype_code(x2d)) * 3, device=x2d.device, dtype=torch.float32)
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    call('tamtr_bncl_stats', ptr(x2d), ptr(rm), ptr(rv), ptr(mr), ptr(part), N, C, float(bn.eps), float(mom), dtype_code(x2d), stream_ptr())
+    return mr
+
+
+@torch.no_grad()
+def maxsigmoid_gate_cl(e, gk, bias, v_raw, v_stats, v_bn, nh, scale=1.0):
+    """Forward-only gate on channels-last operands with the value branch's BatchNorm (batch statistics v_stats from bn_stats_cl, affine
+    of v_bn) applied inside the kernel: e [B,C,H,W] channels-last or a channel slice of such, v_raw [B,C,H,W] channels-last = the raw
+    proj_conv output.  Returns out [B,C,H,W] channels-last.  (The differentiable path is maxsigmoid_gate.)"""
+    require_gpu(e, gk, bias, v_raw)
+    B, C, H, W = e.shape
+    v_raw = v_raw if _is_cl(v_raw) else v_raw.contiguous(memory_format=torch.channels_last)
+    out = torch.empty((B, C, H, W), dtype=e.dtype, device=e.device, memory_format=torch.channels_last)
+    gk32, b32 = _c(gk.float()), _c(bias.float())
+    ga, be = _c(v_bn.weight.float()), _c(v_bn.bias.float())
+    call('tamtr_maxsigmoid_gate_cl_fwd', ptr(e), _cl_pitch(e), None, None, None, ptr(v_raw), ptr(v_stats), ptr(ga), ptr(be), ptr(gk32), ptr(b32),
+         ptr(out), None, None, B, nh, C // nh, H * W, gk.shape[1], _F(scale), dtype_code(e), stream_ptr())
+    return out
+
+
 def maxsigmoid_gate(x, gk, bias, v, nh, scale=1.0):
     """x, v: [B,C,H,W] (f32|bf16); gk: [B,T,C] guide after `gl`; bias: [nh]."""
     return _MaxSigmoidGate.apply(x, gk, bias, v, int(nh), float(scale))

@@ -613,3 +613,34 @@ def test_fused_eval_graph_vs_reference_fixture(pkg, golden):
         model.autocast_dtype = torch.bfloat16
         yb, _ = model(img, txt_feats=txt)
     assert torch.isfinite(yb).all()
+
+
+@pytest.mark.parametrize('c,nh,hw,dt', [(64, 8, 40, torch.float32), (128, 8, 24, torch.bfloat16), (256, 8, 12, torch.bfloat16)])
+def test_gate_with_batchnorm_folded_in_equals_the_separate_path(pkg, c, nh, hw, dt):
+    """next-3: on the NHWC trunk the discarded evaluation of MaxSigmoidAttnBlock (TIAGELAN) reads the raw proj_conv output and
+    applies its BatchNorm inside the gate kernel (tamtr_bncl_stats + tamtr_maxsigmoid_gate_cl_fwd).  Same block, same weights, the
+    separate path (BatchNorm kernels -> NCHW gate kernel) on an NCHW copy of the input: outputs and the BatchNorm side effects agree."""
+    import copy
+    torch.manual_seed(3)
+    blk = pkg.modules.MaxSigmoidAttnBlock(c, c, nh=nh, ec=c).cuda().train()
+    with torch.no_grad():
+        blk.bias.copy_(0.3 * torch.randn(nh)); blk.proj_conv.bn.weight.copy_(1 + 0.2 * torch.randn(c)); blk.proj_conv.bn.bias.copy_(0.1 * torch.randn(c))
+    twin = copy.deepcopy(blk)
+    wide = (rnd((2, 2 * c, hw, hw), 1) * 1.5).to(dt).cuda().contiguous(memory_format=torch.channels_last)
+    x = wide.chunk(2, 1)[1]                       # a channel slice of a wider channels-last map, as TIAGELAN passes it
+    guide = rnd((2, 10, 512), 2).cuda()
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+        assert pkg.ops.gate_cl_ok(x, c, nh)
+        out = blk(x, guide)
+        ref = twin(x.contiguous(), guide)         # NCHW-contiguous input: the separate kernels
+    assert out.is_contiguous(memory_format=torch.channels_last) and ref.is_contiguous()
+    tol = 1e-5 if dt == torch.float32 else 3e-2   # (the separate path rounds BatchNorm's output to bf16 before the gate multiplies it)
+    assert_close(out.float(), ref.float(), tol, tol, 'gate out')
+    assert_close(blk.proj_conv.bn.running_mean, twin.proj_conv.bn.running_mean, 1e-5, 1e-6, 'running_mean')
+    assert_close(blk.proj_conv.bn.running_var, twin.proj_conv.bn.running_var, 1e-4, 1e-6, 'running_var')
+    assert int(blk.proj_conv.bn.num_batches_tracked) == int(twin.proj_conv.bn.num_batches_tracked) == 1
+    # with gradients enabled the differentiable path is taken
+    xg = x.detach().clone().requires_grad_()
+    with torch.autocast('cuda', dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+        blk(xg, guide).float().sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
