@@ -81,6 +81,7 @@ class ManbaWorldDecoder(nn.Module):
                 out.append(torch.cat([xy, torch.full_like(xy, grid_size * 2.0 ** i)], -1).view(1, h * w, 4))
             a = torch.cat(out, 1)
             valid = ((a > eps) & (a < 1 - eps)).all(-1, keepdim=True)
+            self._invalid_rows = (~valid.view(-1)).nonzero().view(-1)   # positions along L (cached with the anchors: no per-step sync)
             a = torch.log(a / (1 - a)).masked_fill(~valid, float('inf'))
             self._anchor_cache = {key: (a, valid)}
         a, valid = self._anchor_cache[key]
@@ -115,10 +116,14 @@ class ManbaWorldDecoder(nn.Module):
     def _get_decoder_input(self, feats, shapes, dn_embed=None, dn_bbox=None, text=None):
         bs = feats.shape[0]
         anchors, valid = self._generate_anchors(shapes, dtype=torch.float32, device=feats.device)
-        x = valid.to(feats.dtype) * feats
         lin, norm = self.enc_output[0], self.enc_output[1]
-        # same [B*L, 512] x [512, 512] contraction as the value projection: bf16 activations take the MFMA kernel
-        memory = VSSBlock._ln(norm, ops.linear_bf16(x, lin.weight, lin.bias) if x.dtype == torch.bfloat16 else lin(x))  # LayerNorm kernel in the activation dtype
+        if feats.is_cuda and feats.dtype == torch.bfloat16:
+            # same [B*L, 512] x [512, 512] contraction as the value projection on the MFMA kernel; `valid * feats` (head.py:1213) is not
+            # materialised: the invalid-anchor rows of the product are set to the bias instead (two 550 MB multiply passes saved)
+            y = ops.linear_bf16_zero_rows(feats, lin.weight, lin.bias, self._invalid_rows)
+        else:
+            y = lin(valid.to(feats.dtype) * feats)
+        memory = VSSBlock._ln(norm, y)  # LayerNorm kernel in the activation dtype
         scores = self.enc_score_head(memory)
         top = torch.topk(scores.max(-1).values, self.num_queries, dim=1).indices
         bi = torch.arange(bs, device=feats.device).unsqueeze(-1)

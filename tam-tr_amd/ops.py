@@ -471,6 +471,54 @@ class _LinearBF16(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _LinearBF16ZeroRows(torch.autograd.Function):
+    """y = (x with the rows `idx` of every image zeroed) W^T + b, without materialising the masked x: y = x W^T + b on the MFMA
+    kernel, then the few masked rows of y are set to b.  Backward: dX = dY W with those rows zeroed, dW = dY^T X minus the masked
+    rows' contribution (a small GEMM), db = column sums of dY over ALL rows.  x [B, L, K] bf16, idx int64 [n] positions along L
+    (the invalid anchors of the MEH token memory, head.py:1210-1213: 1 580 of 33 600 at 640 px)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, idx):
+        require_gpu(x, weight, bias)
+        B, L, K = x.shape
+        N = weight.shape[0]
+        x2 = _c(x.reshape(-1, K))
+        w16 = _c(weight.to(torch.bfloat16))
+        b32 = _c(bias.float())
+        y = torch.empty(B, L, N, device=x.device, dtype=torch.bfloat16)
+        call('tamtr_linear_bf16', ptr(x2), ptr(w16), ptr(b32), ptr(y), B * L, N, K, stream_ptr())
+        if idx.numel():
+            y[:, idx] = b32.to(torch.bfloat16)
+        ctx.save_for_backward(x2, w16, idx)
+        ctx.cfg = (x.shape, weight.dtype, bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w16, idx = ctx.saved_tensors
+        (B, L, K), w_dt, b_dt = ctx.cfg
+        N = w16.shape[0]
+        g3 = _c(gy.to(torch.bfloat16))
+        g2 = g3.view(-1, N)
+        gx = torch.empty(B, L, K, device=g2.device, dtype=torch.bfloat16)
+        if K % 128 == 0 and N % 64 == 0:
+            call('tamtr_linear_bf16', ptr(g2), ptr(_c(w16.t())), None, ptr(gx), B * L, K, N, stream_ptr())
+        else:
+            gx = (g2 @ w16).view(B, L, K)
+        gw = dw_splitk(g2, x2)
+        if idx.numel():
+            gx[:, idx] = 0
+            gi, xi = g3[:, idx].reshape(-1, N), x2.view(B, L, K)[:, idx].reshape(-1, K)
+            gw = gw - (gi.t() @ xi).float()
+        gb = g2.sum(0, dtype=torch.float32).to(b_dt)
+        return gx, gw.to(w_dt), gb, None
+
+
+def linear_bf16_zero_rows(x, weight, bias, idx):
+    """linear_bf16 of x [B, L, K] with the rows idx (along L) treated as zero; see _LinearBF16ZeroRows."""
+    return _LinearBF16ZeroRows.apply(x, weight, bias, idx)
+
+
 def linear_bf16(x, weight, bias=None):
     """x [..., K] bf16, weight [N, K], bias [N] -> [..., N] bf16 (transformer.py:273 value_proj)."""
     return _LinearBF16.apply(x, weight, bias)

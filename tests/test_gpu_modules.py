@@ -644,3 +644,28 @@ def test_gate_with_batchnorm_folded_in_equals_the_separate_path(pkg, c, nh, hw, 
     with torch.autocast('cuda', dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
         blk(xg, guide).float().sum().backward()
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
+def test_linear_with_zeroed_rows_equals_masked_input(pkg):
+    """ops.linear_bf16_zero_rows (enc_output on `valid * feats`, head.py:1213-1214, without the multiply) against the masked input
+    through an fp32 matmul of the same bf16 values: output rows, dX (zero on the masked rows), dW (without them), db (with them)."""
+    B, L, K, N = 3, 700, 512, 512
+    x = rnd((B, L, K), 1).bfloat16()
+    w, b = rnd((N, K), 2, K ** -0.5), rnd((N,), 3)
+    idx = torch.tensor([0, 1, 17, 350, 698, 699])
+    mask = torch.ones(L)
+    mask[idx] = 0
+    xr = x.float().clone().requires_grad_()
+    wr, br = w.bfloat16().float().clone().requires_grad_(), b.clone().requires_grad_()
+    ref = (xr * mask[None, :, None]) @ wr.t() + br
+    cot = rnd((B, L, N), 4).bfloat16().float()
+    (ref * cot).sum().backward()
+    xd, wd, bd = dev(x).requires_grad_(), dev(w).requires_grad_(), dev(b).requires_grad_()
+    out = pkg.ops.linear_bf16_zero_rows(xd, wd, bd, dev(idx))
+    (out.float() * dev(cot)).sum().backward()
+    assert_close(out.float(), ref.detach(), 1e-2, 1e-2, 'out')
+    assert torch.equal(out[:, dev(idx)].float().cpu(), b.bfloat16().float().expand(B, len(idx), N))
+    assert_close(xd.grad.float(), xr.grad, 1e-2, 1e-2 * float(xr.grad.abs().max()), 'dx')
+    assert float(xd.grad[:, dev(idx)].abs().max()) == 0.0
+    assert_close(wd.grad, wr.grad, 1e-2, 1e-2 * float(wr.grad.abs().max()), 'dW')
+    assert_close(bd.grad, br.grad, 1e-2, 1e-2 * float(br.grad.abs().max()), 'db')
