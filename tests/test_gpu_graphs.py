@@ -108,7 +108,7 @@ def test_capture_after_eager_steps_then_train(pkg):
     none = [k for k, p in model.named_parameters() if p.grad is None]
     assert len(none) == 30 and all('.attn.' in k for k in none)
     # DropPath draws differ between a replayed and an eager step (the graph has its own Philox offsets): trajectories, not bits
-    assert abs(graphed[-1] - eager[-1]) / eager[-1] < 0.1, (graphed, eager)
+    assert abs(graphed[-1] - eager[-1]) / eager[-1] < 0.15, (graphed, eager)
     assert graphed[-1] < graphed[0]
     # accumulating onto the adopted static buffers would double the gradient: refused
     model.zero_grad(set_to_none=False)
