@@ -486,7 +486,14 @@ class _LinearBF16ZeroRows(torch.autograd.Function):
         w16 = _c(weight.to(torch.bfloat16))
         b32 = _c(bias.float())
         y = torch.empty(B, L, N, device=x.device, dtype=torch.bfloat16)
+        rec = KERNEL_EVENTS.get('tamtr_linear_bf16')
+        if rec is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         call('tamtr_linear_bf16', ptr(x2), ptr(w16), ptr(b32), ptr(y), B * L, N, K, stream_ptr())
+        if rec is not None:
+            e1.record()
+            rec.append((e0, e1, 2.0 * B * L * N * K))
         if idx.numel():
             y[:, idx] = b32.to(torch.bfloat16)
         ctx.save_for_backward(x2, w16, idx)
