@@ -209,3 +209,29 @@ def test_two_rank_fit_shards_images_and_keeps_ranks_in_step(tmp_path):
         assert len(a) == 4 and len(b) == 4 and not (a & b)
     assert r0['hist'][-1]['steps'] == 4 and 'mAP50' in r0['hist'][-1] and 'mAP50' not in r1['hist'][-1]
     assert (tmp_path / 'run' / 'last.pt').exists()
+
+
+def test_reducer_buckets_keep_channels_last_strides_single_process():
+    """World size 1 (no process group): the reducer still gathers gradients into its flat buckets; the slice of a channels-last conv
+    weight (NHWC trunk) carries the parameter's strides, so .grad and the parameter stay layout-compatible for the fused optimizer,
+    and the values equal plain autograd's."""
+    from tamtr_amd.dist import GradReducer
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(4, 8, 3, padding=1)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    x = torch.randn(2, 4, 6, 6)
+    conv(x).pow(2).sum().backward()
+    want = {k: p.grad.clone() for k, p in conv.named_parameters()}
+    conv.zero_grad(set_to_none=True)
+    red = GradReducer(conv.named_parameters(), bucket_bytes=64)
+    for _ in range(2):
+        red.prepare()
+        assert conv.weight.grad is None
+        conv(x).pow(2).sum().backward()
+        red.finish()
+        assert conv.weight.grad.stride() == conv.weight.stride() and not conv.weight.grad.is_contiguous()
+        for k, p in conv.named_parameters():
+            assert torch.allclose(p.grad, want[k], rtol=1e-6, atol=1e-6), k
+            flat = [b['flat'] for b in red.buckets if any(q is p for _, q in b['params'])][0]
+            assert flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + flat.numel() * flat.element_size()
+    red.remove()

@@ -669,3 +669,27 @@ def test_linear_with_zeroed_rows_equals_masked_input(pkg):
     assert float(xd.grad[:, dev(idx)].abs().max()) == 0.0
     assert_close(wd.grad, wr.grad, 1e-2, 1e-2 * float(wr.grad.abs().max()), 'dW')
     assert_close(bd.grad, br.grad, 1e-2, 1e-2 * float(br.grad.abs().max()), 'db')
+
+
+def test_ss2d_core_node_equals_the_chained_nodes(pkg, monkeypatch):
+    """ops._SS2DCore (one autograd node between in_proj and out_proj) against the same kernels chained as separate nodes
+    (TAMTR_SS2D_SPLIT=1: dwconv_silu_cross -> x_proj_cross -> selective_scan_cross_merged -> ln_gate): output and every gradient."""
+    torch.manual_seed(1)
+    blk = pkg.vss.VSSBlock(hidden_dim=128, drop_path=0.0).cuda().train()
+    x = (rnd((2, 20, 24, 128), 3)).cuda().bfloat16()
+    cot = rnd((2, 20, 24, 128), 4).cuda()
+    res = []
+    for split in ('0', '1'):
+        monkeypatch.setenv('TAMTR_SS2D_SPLIT', split)
+        blk.zero_grad(set_to_none=True)
+        xd = x.clone().requires_grad_()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out = blk(xd)
+        (out.float() * cot).sum().backward()
+        res.append((out.detach().float(), xd.grad.float(), {k: p.grad.clone() for k, p in blk.named_parameters()}))
+    (o0, g0, p0), (o1, g1, p1) = res
+    assert_close(o0, o1, 1e-6, 1e-6, 'ss2d out')                 # same kernels, same order: identical forward
+    assert_close(g0, g1, 2e-2, 2e-2 * float(g1.abs().max()), 'ss2d dx')   # d(xz) halves meet in one bf16 buffer instead of an fp32-free sum
+    assert set(p0) == set(p1)
+    for k in p1:
+        assert_close(p0[k].float(), p1[k].float(), 2e-2, 2e-2 * max(1e-6, float(p1[k].abs().max())), 'ss2d grad ' + k)
