@@ -93,6 +93,35 @@ __global__ __launch_bounds__(P_THREADS) void maxpool_bwd_kernel(const T* __restr
   Elt<T>::st(gx + i, acc);
 }
 
+// NCHW, W % 4 == 0: a thread owns 4 consecutive pixels of a row (one 8-byte (bf16) / 16-byte (f32) load of the addend and store of gx
+// instead of four 2-byte ones; the window codes and output gradients around them come from the same few cache lines)
+template <typename T, int KS>
+__global__ __launch_bounds__(P_THREADS) void maxpool_bwd4_kernel(const T* __restrict__ gy, const uint8_t* __restrict__ code,
+                                                                 const T* __restrict__ addend, T* __restrict__ gx, PoolGeom g) {
+  if (KS) { g.k = KS / 16; g.s = KS % 16; g.p = g.k / 2; }
+  const int i4 = blockIdx.x * P_THREADS + threadIdx.x, w4 = g.W / 4;
+  if (i4 >= g.H * w4) return;
+  const int h = i4 / w4, wb = (i4 - h * w4) * 4;
+  const size_t in_base = (size_t)blockIdx.y * g.H * g.W, out_base = (size_t)blockIdx.y * g.Ho * g.Wo;
+  const T* gyp = gy + out_base;
+  const uint8_t* cp = code + out_base;
+  const int oh_lo = max(0, (h + g.p - g.k + g.s) / g.s), oh_hi = min(g.Ho - 1, (h + g.p) / g.s);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (addend) Elt<T>::ld4(addend + in_base + (size_t)h * g.W + wb, acc);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int w = wb + j;
+    const int ow_lo = max(0, (w + g.p - g.k + g.s) / g.s), ow_hi = min(g.Wo - 1, (w + g.p) / g.s);
+    for (int oh = oh_lo; oh <= oh_hi; ++oh)
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        const size_t o = (size_t)oh * g.Wo + ow;
+        const int mine = (h - (oh * g.s - g.p)) * g.k + (w - (ow * g.s - g.p));
+        if (cp[o] == mine) acc[j] += Elt<T>::ld(gyp + o);
+      }
+  }
+  Elt<T>::st4(gx + in_base + (size_t)h * g.W + wb, acc);
+}
+
 int pool_geom(PoolGeom& g, int B, int C, int H, int W, int k, int s, int p, int nhwc) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || s <= 0 || p < 0) return TAMTR_EINVAL;
   if (k > 15 || 2 * p > k || H + 2 * p < k || W + 2 * p < k) return TAMTR_EUNSUP;   // code fits a byte; every window holds a real element
@@ -140,6 +169,15 @@ extern "C" int tamtr_maxpool_bwd(const void* gy, const uint8_t* code, const void
   if (!grid.x) return TAMTR_EUNSUP;
   hipStream_t st = (hipStream_t)stream;
   const int ks = (p == k / 2 && ((k == 3 && s == 2) || (k == 5 && s == 1))) ? 16 * k + s : 0;
+  const int al = dtype == TAMTR_F32 ? 16 : 8;
+  if (!g.nhwc && W % 4 == 0 && ((uintptr_t)gx % al) == 0 && (!addend || ((uintptr_t)addend % al) == 0) && (long long)B * C <= 65535) {
+    const dim3 g4((unsigned)(((long long)H * (W / 4) + P_THREADS - 1) / P_THREADS), (unsigned)(B * C));
+#define BWD4(T, KS) hipLaunchKernelGGL((maxpool_bwd4_kernel<T, KS>), g4, dim3(P_THREADS), 0, st, (const T*)gy, code, (const T*)addend, (T*)gx, g)
+    if (dtype == TAMTR_F32) { if (ks == 50) BWD4(float, 50); else if (ks == 81) BWD4(float, 81); else BWD4(float, 0); }
+    else { if (ks == 50) BWD4(bf16_t, 50); else if (ks == 81) BWD4(bf16_t, 81); else BWD4(bf16_t, 0); }
+#undef BWD4
+    return tamtr_launch_status();
+  }
 #define BWD(T, KS) hipLaunchKernelGGL((maxpool_bwd_kernel<T, KS>), grid, dim3(P_THREADS), 0, st, (const T*)gy, code, (const T*)addend, (T*)gx, g)
   if (dtype == TAMTR_F32) { if (ks == 50) BWD(float, 50); else if (ks == 81) BWD(float, 81); else BWD(float, 0); }
   else { if (ks == 50) BWD(bf16_t, 50); else if (ks == 81) BWD(bf16_t, 81); else BWD(bf16_t, 0); }

@@ -532,7 +532,8 @@ def test_relayout_is_a_pure_permutation(ops, B, C, H, W, dt):
 # ------------------------------------------------------------------------------------------------ max pooling (csrc/pool.hip)
 @pytest.mark.parametrize('B,C,H,W,k,s,p,dt,cl', [(2, 16, 20, 20, 5, 1, 2, torch.bfloat16, True), (2, 8, 17, 23, 3, 2, 1, torch.float32, False),
                                                  (1, 32, 40, 40, 3, 2, 1, torch.bfloat16, False), (2, 6, 9, 9, 5, 1, 2, torch.float32, True),
-                                                 (1, 4, 8, 10, 2, 2, 0, torch.float32, False)])
+                                                 (1, 4, 8, 10, 2, 2, 0, torch.float32, False), (2, 8, 12, 16, 5, 1, 2, torch.float32, False),
+                                                 (2, 6, 10, 8, 2, 2, 0, torch.bfloat16, False)])
 def test_max_pool_vs_torch(ops, B, C, H, W, k, s, p, dt, cl):
     """SPPELAN's 5/1/2 pools (block.py:255-268) and CPAM's 3/2/1 pool (block.py:274) against F.max_pool2d on the CPU: values
     bit-identical, gradients routed to the same winners (bf16 inputs tie often: the first maximum in window order must win)."""
