@@ -327,6 +327,11 @@ int tamtr_relayout(const void* src, void* dst, int B, int C, int HW, int ld, int
  *      [B,H/2,W/2,C] (its gradient: scattered, zeros elsewhere, one pass).  C % 8 == 0 (bf16) / C % 4 == 0 (f32). */
 int tamtr_resample2(const void* src, void* dst, int B, int H, int W, int C, int mode, int dtype, void* stream);
 int tamtr_copy_rows(const void* src, long long lds, void* dst, long long ldd, long long N, int C, int dtype, void* stream);
+/*      The whole `torch.cat(y, 1)` of up to four channels-last maps in one launch: dst[r][off_k .. off_k + C[k]) = src[k][r][0 .. C[k]),
+ *      off_k = C[0] + ... + C[k-1]; src / lds / C are HOST arrays of n <= 4 entries (pointers are device pointers); widths, pitches
+ *      and pointers 16-byte granular, else TAMTR_EUNSUP (then copy input by input). */
+int tamtr_cat_rows(const void* const* src, const long long* lds, const int* C, int n, void* dst, long long ldd, long long N, int dtype,
+                   void* stream);
 
 /* ---- max pooling k x k / stride s / padding p (floor mode), NCHW (nhwc = 0) or NHWC (nhwc = 1) maps.  Replaces nn.MaxPool2d as
  *      used by SPPELAN (5/1/2, three chained: ultralytics/nn/extra_modules/block.py:255-268) and by CPAM's channel gate (3/2/1,

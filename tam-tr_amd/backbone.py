@@ -163,7 +163,7 @@ class RepNCSPELAN4(nn.Module):
 
     def branches(self, x):
         from . import ops
-        y = list(self.cv1(x).chunk(2, 1))
+        y = list(ops.chunk2_channels(self.cv1(x)))
         y.append(self.cv2(ops.pack_channels(y[-1])))   # one packed copy of the half for the two convolutions that read it
         y.append(self.cv3(y[-1]))
         return y

@@ -133,6 +133,49 @@ extern "C" int tamtr_resample2(const void* src, void* dst, int B, int H, int W, 
   return tamtr_launch_status();
 }
 
+namespace {
+
+// up to four row-copies into column slices of one destination in one launch (blockIdx.y = which): the inputs of a torch.cat(..., 1)
+struct CatArgs {
+  const void* src[4];
+  unsigned long long lds[4];   // source row pitch, in 16-byte vectors
+  unsigned int per_row[4];     // vectors per row
+  unsigned int off[4];         // first destination vector of the slice
+};
+__global__ __launch_bounds__(L_THREADS) void cat_rows_kernel(CatArgs a, uint4* __restrict__ dst, size_t ldd, size_t N) {
+  const int k = blockIdx.y;
+  const size_t i = (size_t)blockIdx.x * L_THREADS + threadIdx.x, per = a.per_row[k];
+  if (i >= N * per) return;
+  const size_t r = i / per, c = i - r * per;
+  dst[r * ldd + a.off[k] + c] = reinterpret_cast<const uint4*>(a.src[k])[r * a.lds[k] + c];
+}
+
+}  // namespace
+
+// dst[r][off_k .. off_k + C_k) = src_k[r][0 .. C_k) for k < n <= 4 inputs: N rows, dst row pitch ldd elements, source pitches lds[k];
+// all widths, pitches and offsets multiples of 16 bytes, 16-byte aligned pointers (else TAMTR_EUNSUP: use tamtr_copy_rows per input)
+extern "C" int tamtr_cat_rows(const void* const* src, const long long* lds, const int* C, int n, void* dst, long long ldd, long long N, int dtype,
+                              void* stream) {
+  if (!src || !lds || !C || !dst || n < 1 || n > 4 || N <= 0) return TAMTR_EINVAL;
+  if (dtype != TAMTR_F32 && dtype != TAMTR_BF16) return TAMTR_EINVAL;
+  const int v = dtype == TAMTR_F32 ? 4 : 8;
+  CatArgs a;
+  unsigned off = 0, widest = 0;
+  if (ldd % v || (uintptr_t)dst % 16) return TAMTR_EUNSUP;
+  for (int k = 0; k < 4; ++k) {
+    const int kk = k < n ? k : 0;
+    if (k < n && (!src[k] || C[k] <= 0 || lds[k] < C[k])) return TAMTR_EINVAL;
+    if (k < n && (C[k] % v || lds[k] % v || (uintptr_t)src[k] % 16)) return TAMTR_EUNSUP;
+    a.src[k] = src[kk]; a.lds[k] = (unsigned long long)(lds[kk] / v); a.per_row[k] = k < n ? (unsigned)(C[k] / v) : 0u; a.off[k] = off;
+    if (k < n) { off += (unsigned)(C[k] / v); widest = a.per_row[k] > widest ? a.per_row[k] : widest; }
+  }
+  if ((long long)off * v > ldd) return TAMTR_EINVAL;
+  const size_t items = (size_t)N * widest;
+  hipLaunchKernelGGL(cat_rows_kernel, dim3((unsigned)((items + L_THREADS - 1) / L_THREADS), n), dim3(L_THREADS), 0, (hipStream_t)stream, a,
+                     (uint4*)dst, (size_t)ldd / v, (size_t)N);
+  return tamtr_launch_status();
+}
+
 // N rows of C elements, source / destination row pitch lds / ldd elements (>= C).  T = f32 | bf16 (any 2- or 4-byte element).
 extern "C" int tamtr_copy_rows(const void* src, long long lds, void* dst, long long ldd, long long N, int C, int dtype, void* stream) {
   if (!src || !dst || N <= 0 || C <= 0 || lds < C || ldd < C) return TAMTR_EINVAL;

@@ -83,10 +83,23 @@ class _CatChannels(torch.autograd.Function):
         B, _, H, W = maps[0].shape
         widths = [m.shape[1] for m in maps]
         out = torch.empty((B, sum(widths), H, W), dtype=maps[0].dtype, device=maps[0].device, memory_format=torch.channels_last)
-        ct, off, e = sum(widths), 0, maps[0].element_size()
-        for m, c in zip(maps, widths):
-            call('tamtr_copy_rows', ptr(m), _cl_pitch(m), out.data_ptr() + off * e, ct, B * H * W, c, dtype_code(m), stream_ptr())
-            off += c
+        ct, e, v = sum(widths), maps[0].element_size(), 16 // maps[0].element_size()
+        N = B * H * W
+        pitches = [_cl_pitch(m) for m in maps]
+        if all(c % v == 0 and ld % v == 0 and m.data_ptr() % 16 == 0 for m, c, ld in zip(maps, widths, pitches)):
+            for i in range(0, len(maps), 4):   # up to four inputs per launch
+                grp = list(range(i, min(i + 4, len(maps))))
+                n = len(grp)
+                src = (ctypes.c_void_p * n)(*[maps[j].data_ptr() for j in grp])
+                lds = (ctypes.c_longlong * n)(*[pitches[j] for j in grp])
+                cs = (ctypes.c_int * n)(*[widths[j] for j in grp])
+                call('tamtr_cat_rows', ctypes.cast(src, ctypes.c_void_p), ctypes.cast(lds, ctypes.c_void_p), ctypes.cast(cs, ctypes.c_void_p), n,
+                     out.data_ptr() + sum(widths[:i]) * e, ct, N, dtype_code(maps[0]), stream_ptr())
+        else:
+            off = 0
+            for m, c, ld in zip(maps, widths, pitches):
+                call('tamtr_copy_rows', ptr(m), ld, out.data_ptr() + off * e, ct, N, c, dtype_code(m), stream_ptr())
+                off += c
         ctx.widths = widths
         return out
 
@@ -103,6 +116,27 @@ def cat_channels(maps):
                              for m in maps):
         return _CatChannels.apply(*maps)
     return torch.cat(maps, 1)
+
+
+class _ChunkChannels(torch.autograd.Function):
+    """x.chunk(2, 1) of a channels-last map with the backward on the row-copy kernel: autograd's own backward of `chunk` concatenates
+    the two gradients - one of them a channel slice of a wider gradient - through torch's generic strided copy."""
+
+    @staticmethod
+    def forward(ctx, x):
+        h = x.shape[1] // 2
+        return x[:, :h], x[:, h:]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        return cat_channels([g0, g1])
+
+
+def chunk2_channels(x):
+    """x.chunk(2, 1); channels-last CUDA maps get the kernel-backed backward."""
+    if x.is_cuda and _is_cl(x) and x.shape[1] % 2 == 0 and x.dtype in (torch.float32, torch.bfloat16) and x.requires_grad:
+        return _ChunkChannels.apply(x)
+    return x.chunk(2, 1)
 
 
 class _PackChannels(torch.autograd.Function):

@@ -664,3 +664,22 @@ def test_bn_pair_and_shortcut_vs_torch(ops, N, C, dt, silu):
     assert_close(ad.grad.float(), a.grad, 10 * tol, 10 * tol, 'shortcut dx')
     assert_close(rd.grad.float(), rr.grad, tol, tol, 'shortcut dres')
     assert_close(d1.weight.grad, ref1.weight.grad, 10 * tol, 10 * tol * N ** 0.5, 'shortcut dgamma')
+
+
+def test_chunk_and_multi_input_cat_kernels(ops):
+    """ops.chunk2_channels (kernel-backed backward) and the one-launch concatenation of four inputs (tamtr_cat_rows) - the pattern of
+    RepNCSPELAN4.forward (extra_modules/block.py:147-152) - against torch.chunk / torch.cat, forward and backward."""
+    B, C, H, W = 2, 64, 10, 12
+    base = rnd((B, C, H, W), 1).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    extra = [rnd((B, c, H, W), 2 + i).bfloat16().cuda().contiguous(memory_format=torch.channels_last) for i, c in enumerate((32, 16))]
+    cot = rnd((B, C + 48, H, W), 9).bfloat16().cuda()
+    grads = []
+    for mine in (True, False):
+        x = base.clone().requires_grad_()
+        es = [e.clone().requires_grad_() for e in extra]
+        y0, y1 = ops.chunk2_channels(x) if mine else x.chunk(2, 1)
+        out = (ops.cat_channels if mine else (lambda t: torch.cat(t, 1)))([y0, y1 * 2, es[0], es[1]])
+        (out.float() * cot.float()).sum().backward()
+        grads.append((out.detach(), x.grad, es[0].grad, es[1].grad))
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
