@@ -57,17 +57,30 @@ struct Vec16<bf16_t> {
 template <typename T, int CB, int HALO, int PITCH>
 __device__ __forceinline__ void stage_tile(const T* __restrict__ x, size_t xs, int b, int d0, int h0, int w0, int H, int W,
                                            float (*s)[TS + 2 * HALO][PITCH]) {
-  constexpr int SIDE = TS + 2 * HALO, VN = Vec16<T>::N, GROUPS = CB / VN;
-  for (int it = threadIdx.x; it < SIDE * SIDE * GROUPS; it += DW_THREADS) {
+  constexpr int SIDE = TS + 2 * HALO, VN = Vec16<T>::N, GROUPS = CB / VN, TOTAL = SIDE * SIDE * GROUPS;
+  constexpr int N_IT = (TOTAL + DW_THREADS - 1) / DW_THREADS;
+  // all of a thread's 16-byte loads first (clamped addresses; pixels outside the image are zeroed afterwards): a load inside a
+  // conditional block is followed by s_waitcnt vmcnt(0), i.e. one memory round trip per iteration
+  float v[N_IT][VN];
+#pragma unroll
+  for (int k = 0; k < N_IT; ++k) {
+    const int it = min((int)threadIdx.x + k * DW_THREADS, TOTAL - 1);
     const int pix = it / GROUPS, gq = it - pix * GROUPS;
     const int py = pix / SIDE, px = pix - py * SIDE;
-    const int h = h0 + py - HALO, w = w0 + px - HALO;
-    float v[VN];
+    const int h = min(max(h0 + py - HALO, 0), H - 1), w = min(max(w0 + px - HALO, 0), W - 1);
+    Vec16<T>::ld(x + ((size_t)(b * H + h) * W + w) * xs + d0 + gq * VN, v[k]);
+  }
 #pragma unroll
-    for (int j = 0; j < VN; ++j) v[j] = 0.f;
-    if (h >= 0 && h < H && w >= 0 && w < W) Vec16<T>::ld(x + ((size_t)(b * H + h) * W + w) * xs + d0 + gq * VN, v);
+  for (int k = 0; k < N_IT; ++k) {
+    const int it = threadIdx.x + k * DW_THREADS;
+    if (it < TOTAL) {
+      const int pix = it / GROUPS, gq = it - pix * GROUPS;
+      const int py = pix / SIDE, px = pix - py * SIDE;
+      const int h = h0 + py - HALO, w = w0 + px - HALO;
+      const float keep = (h >= 0 && h < H && w >= 0 && w < W) ? 1.f : 0.f;
 #pragma unroll
-    for (int j = 0; j < VN; ++j) s[gq * VN + j][py][px] = v[j];
+      for (int j = 0; j < VN; ++j) s[gq * VN + j][py][px] = v[k][j] * keep;
+    }
   }
 }
 
@@ -123,14 +136,62 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_cross_bwd_kernel(const floa
     s_w[c][k] = k < 9 ? wgt[(size_t)(d0 + c) * 9 + k] : (bias ? bias[d0 + c] : 0.f);
   }
   stage_tile<T, CB, 2, XP>(x, xs, b, d0, h0, w0, H, W, s_x);
-  // gradient of the row-major plane, lanes along x
-  for (int it = threadIdx.x; it < CB * GS * GS; it += DW_THREADS) {
-    const int c = it / (GS * GS), r = it - c * (GS * GS), py = r / GS, px = r - py * GS;
-    const int h = h0 + py - 1, w = w0 + px - 1;
-    s_g[c][py][px] = (h >= 0 && h < H && w >= 0 && w < W) ? g2[((size_t)(b * 2) * D + d0 + c) * L + (size_t)h * W + w] : 0.f;
+  // gradient tile = row-major plane (lanes along x) + column-major plane (lanes along y: its contiguous axis).  Loads go out in
+  // batches of 7 with clamped addresses and a 0/1 factor instead of a branch: hipcc ends a conditional block that contains a load with
+  // s_waitcnt vmcnt(0), which made a thread's 21 loads per plane 21 serial round trips (71 % of the wave cycles were waits, round 2 PMC).
+  {
+    constexpr int N_IT = (CB * GS * GS + DW_THREADS - 1) / DW_THREADS, GB = 7;
+    static_assert(N_IT % GB == 0, "batches cover the tile");
+    const float* gp = g2 + ((size_t)(b * 2 + 0) * D + d0) * L;
+#pragma unroll 1
+    for (int k0 = 0; k0 < N_IT; k0 += GB) {
+      float v[GB];
+#pragma unroll
+      for (int k = 0; k < GB; ++k) {
+        const int it = min((int)threadIdx.x + (k0 + k) * DW_THREADS, CB * GS * GS - 1);
+        const int c = it / (GS * GS), r = it - c * (GS * GS), py = r / GS, px = r - py * GS;
+        const int h = h0 + py - 1, w = w0 + px - 1;
+        const bool ok = h >= 0 && h < H && w >= 0 && w < W;
+        v[k] = gp[(size_t)c * L + (size_t)min(max(h, 0), H - 1) * W + min(max(w, 0), W - 1)] * (ok ? 1.f : 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < GB; ++k) {
+        const int it = threadIdx.x + (k0 + k) * DW_THREADS;
+        if (it < CB * GS * GS) {
+          const int c = it / (GS * GS), r = it - c * (GS * GS), py = r / GS, px = r - py * GS;
+          s_g[c][py][px] = v[k];
+        }
+      }
+    }
   }
   __syncthreads();
-  // + gradient of the column-major plane (lanes along y), times SiLU'(conv) with the conv recomputed from the staged input.
+  {
+    constexpr int N_IT = (CB * GS * GS + DW_THREADS - 1) / DW_THREADS, GB = 7;
+    static_assert(N_IT % GB == 0, "batches cover the tile");
+    const float* gp = g2 + ((size_t)(b * 2 + 1) * D + d0) * L;
+#pragma unroll 1
+    for (int k0 = 0; k0 < N_IT; k0 += GB) {
+      float v[GB];
+#pragma unroll
+      for (int k = 0; k < GB; ++k) {
+        const int it = min((int)threadIdx.x + (k0 + k) * DW_THREADS, CB * GS * GS - 1);
+        const int c = it / (GS * GS), r = it - c * (GS * GS), px = r / GS, py = r - px * GS;
+        const int h = h0 + py - 1, w = w0 + px - 1;
+        const bool ok = h >= 0 && h < H && w >= 0 && w < W;
+        v[k] = gp[(size_t)c * L + (size_t)min(max(w, 0), W - 1) * H + min(max(h, 0), H - 1)] * (ok ? 1.f : 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < GB; ++k) {
+        const int it = threadIdx.x + (k0 + k) * DW_THREADS;
+        if (it < CB * GS * GS) {
+          const int c = it / (GS * GS), r = it - c * (GS * GS), px = r / GS, py = r - px * GS;
+          s_g[c][py][px] += v[k];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // times SiLU'(conv) with the conv recomputed from the staged input.
   // 16 threads per channel walk its 18 x 18 halo pixels: the nine inputs loaded for the conv are exactly the factors of
   // d(weight) for that pixel, so the per-(channel, tap) sums ride along in registers (core pixels only) and are combined over
   // the 16 threads at the end - no separate pass over the tile.
@@ -147,7 +208,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_cross_bwd_kernel(const floa
       const int h = h0 + py - 1, w = w0 + px - 1;
       float g = 0.f;
       if (h >= 0 && h < H && w >= 0 && w < W) {
-        g = s_g[c][py][px] + g2[((size_t)(b * 2 + 1) * D + d0 + c) * L + (size_t)w * H + h];
+        g = s_g[c][py][px];
         float xin[9], acc = bc;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
