@@ -124,16 +124,24 @@ __global__ __launch_bounds__(MSDA_THREADS) void msda_bwd_kernel(const ET* __rest
       for (int d = gl; d < D; d += LPG) {
         const float g = Elt<ET>::ld(gout + (size_t)gid * D + d);
         float vc[4];
+        size_t oc[4];
+        bool okc[4];
+        // the four corner loads go out together (clamped addresses, zeroed afterwards): a load inside `if (ok)` is followed by
+        // s_waitcnt vmcnt(0), i.e. four serial round trips per sampling point
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int xi = x0 + (c & 1), yi = y0 + (c >> 1);
-          const bool ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H);
-          vc[c] = 0.f;
-          if (ok) {
-            const size_t o = lb + (size_t)(yi * W + xi) * tok + d;
-            vc[c] = Elt<ET>::ld(value + o);
+          okc[c] = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H);
+          oc[c] = lb + (size_t)(min(max(yi, 0), H - 1) * W + min(max(xi, 0), W - 1)) * tok + d;
+          vc[c] = Elt<ET>::ld(value + oc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (okc[c]) {  // group-uniform
             const float w = ((c & 1) ? fx : 1.f - fx) * ((c >> 1) ? fy : 1.f - fy);
-            atomicAdd(gvalue + o, w * a * g);
+            atomicAdd(gvalue + oc[c], w * a * g);
+          } else {
+            vc[c] = 0.f;
           }
         }
         // v(x,y) = (1-fy)((1-fx) v00 + fx v01) + fy((1-fx) v10 + fx v11);  vc = {v00, v01, v10, v11}
