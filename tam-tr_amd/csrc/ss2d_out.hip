@@ -55,12 +55,24 @@ __global__ __launch_bounds__(MT_THREADS) void cross_merge_bwd_kernel(const float
   const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
   const int d0 = blockIdx.y * CB, b = blockIdx.z, h0 = th * TS, w0 = tw * TS;
   const size_t L = (size_t)H * W;
-  for (int it = threadIdx.x; it < TS * TS * (CB / 4); it += MT_THREADS) {
-    const int pix = it / (CB / 4), g = it - pix * (CB / 4), py = pix / TS, px = pix - py * TS;
-    const int h = h0 + py, w = w0 + px;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (h < H && w < W) v = *reinterpret_cast<const float4*>(gT + ((size_t)b * L + (size_t)h * W + w) * D + d0 + g * 4);
-    s[g * 4][py][px] = v.x; s[g * 4 + 1][py][px] = v.y; s[g * 4 + 2][py][px] = v.z; s[g * 4 + 3][py][px] = v.w;
+  {  // all of a thread's 16-byte loads first (clamped addresses): a load inside `if (in image)` ends in s_waitcnt vmcnt(0), i.e. one
+     // round trip per iteration; tiles outside the image keep their (unused) clamped values
+    constexpr int N_IT = TS * TS * (CB / 4) / MT_THREADS;
+    static_assert(TS * TS * (CB / 4) % MT_THREADS == 0, "whole iterations");
+    float4 v[N_IT];
+#pragma unroll
+    for (int k = 0; k < N_IT; ++k) {
+      const int it = threadIdx.x + k * MT_THREADS;
+      const int pix = it / (CB / 4), g = it - pix * (CB / 4), py = pix / TS, px = pix - py * TS;
+      const int h = min(h0 + py, H - 1), w = min(w0 + px, W - 1);
+      v[k] = *reinterpret_cast<const float4*>(gT + ((size_t)b * L + (size_t)h * W + w) * D + d0 + g * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < N_IT; ++k) {
+      const int it = threadIdx.x + k * MT_THREADS;
+      const int pix = it / (CB / 4), g = it - pix * (CB / 4), py = pix / TS, px = pix - py * TS;
+      s[g * 4][py][px] = v[k].x; s[g * 4 + 1][py][px] = v[k].y; s[g * 4 + 2][py][px] = v[k].z; s[g * 4 + 3][py][px] = v[k].w;
+    }
   }
   __syncthreads();
   float* gb = g2 + (size_t)b * 2 * D * L;
