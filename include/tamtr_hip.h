@@ -260,6 +260,10 @@ int tamtr_ln_gate_bwd(const void* gout, const float* x, const void* xz, long lon
  *      g4 f32 [B, 4, n] = d/d(u) of the four directions as tamtr_selective_scan_dtproj_bwd writes them (un-reversed), m0 / m1 (T)
  *      [B, n] = the x_proj backward products of the two copies (vmamba.py:962-970), out f32 [B, 2, n], n = D * L, n % 4 == 0.
  */
+/*      out = src[0] + ... + src[n-1] (n <= 8 tensors of n_elems elements, T; src: HOST array of device pointers): the gradient of a
+ *      tensor with several consumers - the MEH token memory feeds enc_output and every decoder layer's value_proj (head.py:1152-1160,
+ *      transformer.py:273) - in one pass instead of autograd's n - 1 pairwise adds. */
+int tamtr_sum_n(const void* const* src, int n, void* out, long long n_elems, int dtype, void* stream);
 int tamtr_fold_add(const float* g4, const void* m0, const void* m1, float* out, int B, long long n, int dtype, void* stream);
 
 /*      tamtr_layernorm_* : LayerNorm over the channel axis of a token-major map, VSSBlock.norm / norm2

@@ -23,7 +23,47 @@ __global__ __launch_bounds__(256) void fold_add_kernel(const float* __restrict__
       make_float4(a.x + d.x + mv[0], a.y + d.y + mv[1], a.z + d.z + mv[2], a.w + d.w + mv[3]);
 }
 
+// out = a0 + a1 + ... + a(n-1), n <= 8 tensors of one shape (the gradients that reach a tensor with several consumers: autograd adds
+// them pairwise, n - 1 kernels of 2 reads + 1 write each; here n reads + 1 write)
+struct SumArgs {
+  const void* p[8];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void sum_n_kernel(SumArgs a, int n, T* __restrict__ out, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < n) {   // uniform
+      float v[4];
+      Elt<T>::ld4(reinterpret_cast<const T*>(a.p[k]) + i * 4, v);
+      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+  }
+  Elt<T>::st4(out + i * 4, acc);
+}
+
 }  // namespace
+
+// out (T) [n_elems] = sum of the n <= 8 tensors src[k] (T, same length; src is a HOST array of device pointers); n_elems % 4 == 0
+extern "C" int tamtr_sum_n(const void* const* src, int n, void* out, long long n_elems, int dtype, void* stream) {
+  if (!src || !out || n < 1 || n > 8 || n_elems <= 0) return TAMTR_EINVAL;
+  if (dtype != TAMTR_F32 && dtype != TAMTR_BF16) return TAMTR_EINVAL;
+  const int al = dtype == TAMTR_F32 ? 16 : 8;
+  if (n_elems % 4 || (uintptr_t)out % al) return TAMTR_EUNSUP;
+  SumArgs a;
+  for (int k = 0; k < 8; ++k) {
+    a.p[k] = src[k < n ? k : 0];
+    if (k < n && (!src[k] || (uintptr_t)src[k] % al)) return src[k] ? TAMTR_EUNSUP : TAMTR_EINVAL;
+  }
+  const size_t n4 = (size_t)n_elems / 4;
+  const dim3 grid((unsigned)((n4 + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == TAMTR_F32) hipLaunchKernelGGL(sum_n_kernel<float>, grid, dim3(256), 0, s, a, n, (float*)out, n4);
+  else hipLaunchKernelGGL(sum_n_kernel<bf16_t>, grid, dim3(256), 0, s, a, n, (bf16_t*)out, n4);
+  return tamtr_launch_status();
+}
 
 // g4 f32 [B, 4, D*L]; m0, m1 (T) [B, D*L]; out f32 [B, 2, D*L];  n = D*L, n % 4 == 0
 extern "C" int tamtr_fold_add(const float* g4, const void* m0, const void* m1, float* out, int B, long long n, int dtype, void* stream) {

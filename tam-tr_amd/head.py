@@ -60,8 +60,11 @@ class ManbaWorldDecoder(nn.Module):
         dn_embed, dn_bbox, attn_mask, dn_meta = get_cdn_group(batch, self.nc, self.num_queries,
                                                               self.denoising_class_embed.weight, self.num_denoising,
                                                               self.label_noise_ratio, self.box_noise_scale, self.training)
-        embed, refer_bbox, enc_bboxes, enc_scores = self._get_decoder_input(feats, shapes, dn_embed, dn_bbox)
-        dec_bboxes, dec_scores = self.decoder(embed, refer_bbox, feats, shapes, text, self.dec_bbox_head, self.dec_score_head,
+        # the token memory has 1 + num_layers heavy consumers (enc_output, every layer's value_proj): their gradients are added in one
+        # pass instead of pairwise by autograd
+        f_enc, *f_dec = ops.fanout(feats, 1 + self.decoder.num_layers) if self.training else (feats,) * (1 + self.decoder.num_layers)
+        embed, refer_bbox, enc_bboxes, enc_scores = self._get_decoder_input(f_enc, shapes, dn_embed, dn_bbox)
+        dec_bboxes, dec_scores = self.decoder(embed, refer_bbox, f_dec, shapes, text, self.dec_bbox_head, self.dec_score_head,
                                               self.query_pos_head, attn_mask=attn_mask)
         x = dec_bboxes, dec_scores, enc_bboxes, enc_scores, dn_meta
         if self.training:

@@ -246,7 +246,8 @@ class TextDeformableTransformerDecoder(nn.Module):
         output, dec_bboxes, dec_cls, last_refined = embed, [], [], None
         refer_bbox = refer_bbox.sigmoid()
         for i, layer in enumerate(self.layers):
-            output = layer(output, refer_bbox, feats, shapes, padding_mask, attn_mask, pos_mlp(refer_bbox))
+            f_i = feats[i] if isinstance(feats, (list, tuple)) else feats   # per-layer handle on the token memory (ops.fanout)
+            output = layer(output, refer_bbox, f_i, shapes, padding_mask, attn_mask, pos_mlp(refer_bbox))
             bbox = bbox_head[i](output)
             refined = torch.sigmoid(bbox + inverse_sigmoid(refer_bbox))
             if self.training:

@@ -560,6 +560,40 @@ def linear_bf16_zero_rows(x, weight, bias, idx):
     return _LinearBF16ZeroRows.apply(x, weight, bias, idx)
 
 
+class _Fanout(torch.autograd.Function):
+    """n handles on one tensor for n consumers; the backward adds their n gradients in ONE pass (csrc/fold.hip tamtr_sum_n) instead of
+    autograd's n - 1 pairwise accumulations (three 2-read-1-write passes over the 550 MB token memory gradient per step)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [g for g in gs if g is not None]
+        if len(live) == 1:
+            return live[0], None
+        g0 = live[0]
+        if (g0.is_cuda and g0.dtype in (torch.float32, torch.bfloat16) and g0.numel() % 4 == 0 and len(live) <= 8
+                and all(g.dtype == g0.dtype and g.shape == g0.shape for g in live)):
+            live = [_c(g) for g in live]
+            out = torch.empty_like(live[0])
+            src = (ctypes.c_void_p * len(live))(*[g.data_ptr() for g in live])
+            call('tamtr_sum_n', ctypes.cast(src, ctypes.c_void_p), len(live), ptr(out), out.numel(), dtype_code(out), stream_ptr())
+            return out, None
+        acc = live[0].clone()
+        for g in live[1:]:
+            acc += g
+        return acc, None
+
+
+def fanout(x, n):
+    """x -> n tensors with x's values (views), whose gradients are summed in one kernel; for tensors that feed several heavy consumers."""
+    if n <= 1 or not (x.requires_grad and torch.is_grad_enabled()):
+        return (x,) * max(n, 1)
+    return _Fanout.apply(x, int(n))
+
+
 def linear_bf16(x, weight, bias=None):
     """x [..., K] bf16, weight [N, K], bias [N] -> [..., N] bf16 (transformer.py:273 value_proj)."""
     return _LinearBF16.apply(x, weight, bias)

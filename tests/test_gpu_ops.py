@@ -683,3 +683,19 @@ def test_chunk_and_multi_input_cat_kernels(ops):
         grads.append((out.detach(), x.grad, es[0].grad, es[1].grad))
     for a, b in zip(*grads):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('dt,n', [(torch.bfloat16, 4), (torch.float32, 3), (torch.bfloat16, 2)])
+def test_fanout_sums_consumer_gradients_in_one_pass(ops, dt, n):
+    """ops.fanout: n handles on one tensor whose n gradients are added by tamtr_sum_n (the MEH token memory feeds enc_output and every
+    decoder layer's value_proj) - same total gradient as letting autograd accumulate them."""
+    x = rnd((5, 37, 64), 1).to(dt).cuda()
+    ws = [rnd((5, 37, 64), 2 + i).to(dt).cuda() for i in range(n)]
+    a = x.clone().requires_grad_()
+    hs = ops.fanout(a, n)
+    assert len(hs) == n and all(torch.equal(h, a) for h in hs)
+    sum((h * w).float().sum() for h, w in zip(hs, ws)).backward()
+    b = x.clone().requires_grad_()
+    sum((b * w).float().sum() for w in ws).backward()
+    tol = 1e-6 if dt == torch.float32 else 2e-2
+    assert_close(a.grad.float(), b.grad.float(), tol, tol * float(b.grad.abs().max()), 'fanout grad')
