@@ -2,7 +2,10 @@
 """bench.py - images/sec of one TAM-TR training step (fwd + 12-term RIOU loss + bwd + AdamW) at 640x640, bs 16 per GPU.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--no-cpu-baseline]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+    N > 1: either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py
+    --gpus N ...: RANK / WORLD_SIZE in the environment) or plainly as `python bench.py --gpus N`: with no WORLD_SIZE in the environment
+    the script starts its own N ranks as a CHILD `torch.distributed.run` (before anything touches the GPU), relays their output and
+    exits with their code - what the reference's trainer does for device='0,1,..' (engine/trainer.py:161-189, utils/dist.py:50-62).
 
 Workload = BASELINE.json configs[1]/[2] ("TAM-TR-s" := the reference's only graph, TAMTR.yaml, 42.1 M params - SURVEY D3):
 synthetic images rand(B,3,640,640), unit-norm 10x512 text features, 8 GT boxes per image (=> 192 denoising + 100 queries).
@@ -14,9 +17,15 @@ One JSON line on rank 0.  `roofline`: the MEH value-projection GEMM (tamtr_linea
 the head: M = 16*33600, N = K = 512; value_proj x 3 layers + enc_output forward, and their dX products), timed live with
 events on the launch stream inside the timed steps, priced against the dense bf16 MFMA peak; `traffic` = HBM bytes per launch
 from the PMC passes committed under profiles/ (same kernel, same shape).  `cpu_baseline`: the CPU oracle (oracle/, a port - the
-reference's own end-to-end path cannot run on CPU) on this box's host cores, bounded sample: 2 images, 1 warm-up +
-3 timed fwd+bwd steps.  `config.bf16_vs_fp32`: relative difference of the bf16-mode loss from the fp32-mode loss of the SAME
+reference's own end-to-end path cannot run on CPU) on this box's host cores, bounded sample: configs[0]'s 8 images, one
+warm-up step on 2 of them + 1 timed fwd+bwd step on all 8.  `config.bf16_vs_fp32`: relative difference of the bf16-mode loss from the fp32-mode loss of the SAME
 model on the SAME batch, measured before the warm-up (the GPU parity suite holds the fp32 mode to the CPU oracle at 1e-3).
+`config.graph_vs_eager`: after the timed steps, ONE more forward + backward through the replayed graphs and one executed kernel by
+kernel on the same weights, batch and seeds: relative difference of the loss and of the whole gradient (L2), next to the same
+figure between two eager passes (`eager_noise_*`: MIOpen's split-K / atomic solvers are not bitwise reproducible).
+`config.static_part_check`: the capture-time check (GraphedPart.verify: token memory and all 552 parameter gradients of a replay
+against eager execution).  `host_cpu_ms_per_step`: process CPU time (user + system, all threads of the rank) per timed step, max and
+per rank - the share of a step the host spends issuing work, which is what N ranks on one host compete for.
 `config.conv_tuning`: how MIOpen picked the trunk's convolution kernels (tam-tr_amd/tuning.py: its own timed search, replayed from
 the tables shipped in the repo).  `config.static_part`: "hip-graph" when the shape-static part of the step (trunk, VSS blocks, input projection: ~3/4 of the
 launches) is replayed as two HIP graphs (model.capture_static_part), "eager" otherwise (--static-part eager).
@@ -115,9 +124,10 @@ def host_cores():
     return max(1, min(n, 32))
 
 
-def cpu_baseline(n_img=2, S=640, repeats=3):
-    """The CPU oracle (port) on this box's host cores: fwd+bwd of the same graph on n_img images; one untimed warm-up step at
-    full size, then `repeats` timed steps (mean and spread reported)."""
+def cpu_baseline(n_img=8, S=640, repeats=1):
+    """The CPU oracle (port) on this box's host cores: fwd+bwd of the same graph on n_img images (BASELINE configs[0]: 8).  Bounded
+    sample: one untimed warm-up step on 2 images (thread pools, allocator, the C scan twin's library), then `repeats` timed steps
+    on the n_img-image batch (about 40 s each on 16 cores)."""
     cores = host_cores()
     os.environ['OMP_NUM_THREADS'] = str(cores)  # the C scan twin's OpenMP runtime (loaded lazily below)
     torch.set_num_threads(cores)
@@ -129,25 +139,61 @@ def cpu_baseline(n_img=2, S=640, repeats=3):
     for k, v in st.items():
         if v.dtype.is_floating_point and not k.endswith(('running_mean', 'running_var')):
             v.requires_grad_()
-    b = synth_batch(max(n_img, 2), S, 1, 'cpu')  # BatchNorm in train mode needs > 1 value per channel at the deepest maps
-    keep = b['batch_idx'] < n_img
-    b = {'img': b['img'][:n_img], 'txt_feats': b['txt_feats'][:n_img], 'cls': b['cls'][keep], 'bboxes': b['bboxes'][keep],
-         'batch_idx': b['batch_idx'][keep]}
+    full = synth_batch(max(n_img, 2), S, 1, 'cpu')  # BatchNorm in train mode needs > 1 value per channel at the deepest maps
+
+    def cut(n):
+        keep = full['batch_idx'] < n
+        return {'img': full['img'][:n], 'txt_feats': full['txt_feats'][:n], 'cls': full['cls'][keep], 'bboxes': full['bboxes'][keep],
+                'batch_idx': full['batch_idx'][keep]}
     times = []
     for it in range(1 + repeats):
         for v in st.values():
             v.grad = None
+        b = cut(min(2, n_img) if it == 0 else n_img)
         t0 = time.time()
         torch.manual_seed(0)
         O.tamtr_loss(st, b, True, scan_fn=selscan_c.scan)[0].backward()
         dt = time.time() - t0
-        print(f'[bench] cpu_baseline: {"warm-up" if it == 0 else "timed"} step {dt:.1f} s', file=sys.stderr, flush=True)
+        print(f'[bench] cpu_baseline: {"warm-up (2 images)" if it == 0 else "timed"} step {dt:.1f} s', file=sys.stderr, flush=True)
         if it:
             times.append(dt)
     mean = sum(times) / len(times)
     return {'value': n_img / mean, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'{n_img} image(s) {S}x{S}, fp32 CPU oracle (torch CPU ops + C scan twin): 1 warm-up + {repeats} timed fwd+bwd steps, '
-                      f'mean {mean:.1f} s (min {min(times):.1f}, max {max(times):.1f})'}
+            'sample': f'{n_img} image(s) {S}x{S} (BASELINE configs[0]), fp32 CPU oracle (torch CPU ops + C scan twin): warm-up step on 2 images, '
+                      f'then {repeats} timed fwd+bwd step(s) on {n_img}, mean {mean:.1f} s (min {min(times):.1f}, max {max(times):.1f})'}
+
+
+def graph_vs_eager(model, batch, seed=4321):
+    """One forward + backward of the training objective through the replayed graphs and one kernel by kernel: same weights, batch,
+    denoising draw and DropPath draw.  BatchNorm statistics are put back; parameters' .grad is not touched."""
+    saved = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    params = [p for p in model.parameters() if p.requires_grad]
+    held = model._static
+
+    def run(use_graph):
+        model._static = held if use_graph else None
+        try:
+            torch.manual_seed(seed)
+            loss, _ = model(batch)
+            gr = torch.autograd.grad(loss, params, allow_unused=True)
+            flat = torch.cat([g.detach().float().reshape(-1) for g in gr if g is not None])
+        finally:
+            model._static = held
+            model.load_state_dict(saved)
+        return float(loss.detach()), flat
+    lg, gg = run(True)
+    le, ge = run(False)
+    le2, ge2 = run(False)
+    n = float(ge.norm())
+    return {'loss_graph': lg, 'loss_eager': le, 'loss_rel': abs(lg - le) / abs(le), 'grad_l2_rel': float((gg - ge).norm()) / n,
+            'eager_noise_loss_rel': abs(le2 - le) / abs(le), 'eager_noise_grad_l2_rel': float((ge2 - ge).norm()) / n,
+            'finite': bool(torch.isfinite(gg).all())}
+
+
+def _brief(chk):
+    if not chk:
+        return None
+    return {k: chk[k] for k in ('ok', 'grads', 'out_rel_max', 'grad_rel_max', 'eager_noise_out', 'eager_noise_grad_max', 'bound')}
 
 
 def main():
@@ -166,10 +212,14 @@ def main():
                          'tam-tr_amd/tuned/miopen (default), a fresh search (minutes), or its heuristic')
     ap.add_argument('--conv-db', default=None, help='directory the search writes its tables to (--conv-tuning search)')
     ap.add_argument('--grad-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire (N > 1)')
+    ap.add_argument('--cpu-baseline-images', type=int, default=8, help='images of the CPU-oracle sample (BASELINE configs[0]: 8)')
     args = ap.parse_args()
 
-    import tamtr_amd  # noqa: F401  (raises if the HIP library is missing)
+    import tamtr_amd  # noqa: F401  (raises if the HIP library is missing; loading it does not touch the GPU)
     from tamtr_amd import dist as tdist
+    plan = tdist.launch_plan(args.gpus, os.environ, sys.argv[1:], __file__)
+    if plan is not None:     # `python bench.py --gpus N`: become the launcher of N ranks; nothing below runs in this process
+        raise SystemExit(tdist.self_launch(plan))
     from tamtr_amd.model import RTDETRDetectionWorldModel
     rank, local, world = tdist.init_from_env()
     if world != args.gpus:
@@ -238,7 +288,7 @@ def main():
     if args.static_part == 'graph':
         try:
             t1 = time.perf_counter()
-            model.capture_static_part(batch['img'], batch['txt_feats'])
+            model.capture_static_part(batch['img'], batch['txt_feats'], log=note)   # raises when a replay does not reproduce eager
             static_part = 'hip-graph'
             note(f'static part captured in {time.perf_counter() - t1:.1f} s (includes MIOpen kernel selection)')
         except Exception as e:  # noqa: BLE001 - report and run eagerly; the JSON line says which it was
@@ -253,17 +303,34 @@ def main():
         note(f'warm-up step {i}: {time.perf_counter() - t1:.2f} s')
     fence()
     timer.enabled = True
+    c0 = time.process_time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    host_ms = (time.process_time() - c0) / args.steps * 1e3   # CPU time of this rank's process (all threads) per step
     timer.enabled = False
+    host_all = [host_ms]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
-    note(f'timed {args.steps} steps: {dt / args.steps * 1e3:.1f} ms/step')
+        h = torch.zeros(world, device=dev, dtype=torch.float64)
+        h[rank] = host_ms
+        torch.distributed.all_reduce(h)
+        host_all = h.tolist()
+    note(f'timed {args.steps} steps: {dt / args.steps * 1e3:.1f} ms/step (host CPU {max(host_all):.1f} ms/step)')
+    gve = None
+    if static_part == 'hip-graph':   # the replayed path against kernel-by-kernel execution, at the end of the run (every rank: same work)
+        if reducer is None:
+            opt.zero_grad(set_to_none=True)
+        try:
+            gve = graph_vs_eager(model, batch)
+        except Exception as e:  # noqa: BLE001 - the measurement stands; the line says the check did not run
+            gve = {'error': f'{type(e).__name__}: {e}'[:200]}
+        note(f'graph vs eager: {gve}')
+        fence()
     if rank == 0:
         ks = timer.summary()
         peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == 'bf16' else MFMA_F32_PEAK_TFLOPS
@@ -271,11 +338,13 @@ def main():
             'metric': f'images/sec fwd+bwd @{args.imgsz}x{args.imgsz} bs={args.batch}/GPU', 'value': world * args.batch * args.steps / dt, 'unit': 'images/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'host_cpu_ms_per_step': {'max': max(host_all), 'per_rank': [round(v, 2) for v in host_all], 'host_cores': host_cores()},
             'config': {'workload': f'TAM-TR (TAMTR.yaml graph, 42.1M params) train step fwd+loss+bwd+AdamW, {args.imgsz}x{args.imgsz}, '
                                    f'bs {args.batch}/GPU, 10 text prompts, 8 GT/img, full BTA-PAN+MEH HIP path',
                        'global_batch': world * args.batch, 'parallelism': f'dp{world}', 'final_loss': float(loss.detach()),
                        'bf16_vs_fp32': mode_err, 'dist_backend': backend, 'dist_world_size': world,
-                       'grad_bucket_dtype': (args.grad_dtype if world > 1 else None), 'static_part': static_part, 'conv_tuning': conv_tuning,
+                       'grad_bucket_dtype': (args.grad_dtype if world > 1 else None), 'static_part': static_part,
+                       'static_part_check': _brief(getattr(model, 'static_part_check', None)), 'graph_vs_eager': gve, 'conv_tuning': conv_tuning,
                        'hbm_GiB_peak': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
             'roofline': None if ks is None else {
                 'bound': 'mfma', 'kernel': 'linear_bf16_wstat_kernel<512> (MEH value_proj x3 + enc_output and their dX, M=%d N=K=512)'
@@ -284,7 +353,7 @@ def main():
                 'avg_ms': ks['avg_ms'], 'launches': ks['launches']},
         }
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(args.cpu_baseline_images, args.imgsz)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))

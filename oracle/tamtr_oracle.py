@@ -348,6 +348,12 @@ def box_iou_xywh(b1, b2, riou=False, eps=1e-7):
     return iou - (rho2 / c2 + v * alpha)
 
 
+# Test hook: when a dict, meh_head stores the selected anchor indices under 'top' (one entry per call) and _layer_loss appends every
+# Hungarian assignment it computes under 'matches' (call order of _detr_loss: last layer first, then the aux layers 0..n-2), so a test
+# can hand the SAME discrete choices to the implementation under test and compare everything downstream of them elementwise.
+TRACE = None
+
+
 def hungarian_match(pred_bboxes, pred_scores, gt_bboxes, gt_cls, gt_groups, alpha=0.25, gamma=2.0,
                     gain=(2.0, 5.0, 2.0)):
     """HungarianMatcher.forward (models/utils/ops.py:48-119) with the matcher gains DETRLoss installs
@@ -392,6 +398,8 @@ def _layer_loss(pb, ps, gt_bboxes, gt_cls, gt_groups, nc, match=None, gains=(1.0
     """DETRLoss._get_loss (models/utils/loss.py:282-326) for one decoder layer -> (class, bbox, giou)."""
     if match is None:
         match = hungarian_match(pb, ps, gt_bboxes, gt_cls, gt_groups)
+        if TRACE is not None:
+            TRACE.setdefault('matches', []).append(match)
     bi = torch.cat([torch.full_like(s, i) for i, (s, _) in enumerate(match)])
     si = torch.cat([s for s, _ in match])
     gi = torch.cat([g for _, g in match])
@@ -529,6 +537,8 @@ def meh_head(xs, text, targets, P, nh, nq, ndl, nc, train, vss='real', scan_fn=N
     memory = _ln(F.linear(valid * feats, P['enc_output.0.weight'], P['enc_output.0.bias']), P.sub('enc_output.1.'))
     scores = F.linear(memory, P['enc_score_head.weight'], P['enc_score_head.bias'])
     top = torch.topk(scores.max(-1).values, nq, dim=1).indices  # [B,nq]
+    if TRACE is not None:
+        TRACE.setdefault('top', []).append(top)
     bi = torch.arange(B).unsqueeze(-1)
     top_feat = memory[bi, top]
     refer = mlp(top_feat, P.sub('enc_bbox_head.'), 3) + anchors[0][top]

@@ -35,6 +35,32 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
+def launch_plan(gpus, environ, argv, script):
+    """The command with which a script started as plain `python script.py --gpus N ...` becomes the launcher of its own N ranks - what
+    the reference's trainer does for device='0,1,..' (engine/trainer.py:161-189 -> utils/dist.py:50-62: subprocess.run of
+    `python -m torch.distributed.run --nproc_per_node N ... file`).  None when there is nothing to start: one GPU, or RANK / WORLD_SIZE
+    already in the environment (some launcher did it).  A pure function of its arguments (tests/test_host_logic.py) apart from the
+    free rendezvous port it picks on 127.0.0.1."""
+    import socket
+    import sys
+    if gpus <= 1 or 'WORLD_SIZE' in environ or 'RANK' in environ:
+        return None
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus), '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(script), *argv]
+
+
+def self_launch(cmd, environ=None):
+    """Run the ranks as a CHILD process (never an exec of this one), with stdout / stderr passed through; returns their exit code.
+    Must be called before this process touches the GPU: it only waits."""
+    import subprocess
+    import sys
+    print(f'[launch] {" ".join(cmd)}', file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=dict(os.environ if environ is None else environ)).returncode
+
+
 def shard_batch(global_batch, rank, world):
     """Contiguous image shard [lo, hi) of rank (DistributedSampler-style equal split; global_batch % world == 0)."""
     if global_batch % world:

@@ -333,9 +333,10 @@ def fit(model, train_loader, prepare, epochs, val_loader=None, lr0=1e-4, lrf=1.0
     prepare(batch, training) -> batch on the device (data.preprocess_batch with the prompt table bound).  reducer: dist.GradReducer for
     world > 1 - gradients are SUMMED over ranks, which is the reference's mean-reduce of a loss pre-multiplied by world_size
     (trainer.py:346-347).  Rank 0 validates the EMA weights after every epoch and keeps last.pt / best.pt under save_dir.
-    resume: a checkpoint dict written by an earlier fit() ({'epoch', 'model', 'ema', 'updates', 'optimizer'}; the caller has loaded
-    'model'): EMA weights and update count, optimizer state and the epoch counter continue from it (trainer.py:560-583), so the
-    warm-up does not start over.  static_graph: record trunk + VSS blocks + input projection as HIP graphs on the first batch
+    resume: a checkpoint dict written by an earlier fit() ({'epoch', 'best_fitness', 'model', 'ema', 'updates', 'optimizer'}; the caller
+    has loaded 'model'): EMA weights and update count, optimizer state, the best fitness so far and the epoch counter continue from it
+    (trainer.py:593-615), so the warm-up does not start over, best.pt is only replaced by a better epoch, and a run that resumes inside
+    its last `close_mosaic` epochs starts with mosaic already closed.  static_graph: record trunk + VSS blocks + input projection as HIP graphs on the first batch
     (model.capture_static_part; batches of another shape, and evaluation, run eagerly).  Returns the per-epoch records."""
     nb = len(train_loader)
     opt = build_optimizer(model, name=optimizer, lr=lr0, momentum=momentum, decay=weight_decay,
@@ -351,17 +352,26 @@ def fit(model, train_loader, prepare, epochs, val_loader=None, lr0=1e-4, lrf=1.0
         if ema is not None and 'ema' in resume:
             ema.ema.load_state_dict(resume['ema'])
             ema.updates = int(resume.get('updates', 0))
-        best = resume.get('metrics', {}).get('fitness')
+        best = resume.get('best_fitness', resume.get('metrics', {}).get('fitness'))  # (second form: checkpoints written before round 3)
         for _ in range(start):
             sched.step()
+    mosaic_open = bool(close_mosaic) and hasattr(train_loader.dataset, 'close_mosaic')
+
+    def shut_mosaic():
+        train_loader.dataset.close_mosaic()
+        from .data import reset_workers
+        reset_workers(train_loader)     # persistent workers keep their own copy of the dataset
+
+    if mosaic_open and start > epochs - close_mosaic:   # resumed past the switch-over epoch (trainer.py:611-615)
+        shut_mosaic()
+        mosaic_open = False
     for epoch in range(start, epochs):
         model.train()
         if hasattr(train_loader.sampler, 'set_epoch'):
             train_loader.sampler.set_epoch(epoch)
-        if close_mosaic and epoch == epochs - close_mosaic and hasattr(train_loader.dataset, 'close_mosaic'):
-            train_loader.dataset.close_mosaic()
-            from .data import reset_workers
-            reset_workers(train_loader)     # persistent workers keep their own copy of the dataset
+        if mosaic_open and epoch >= epochs - close_mosaic:
+            shut_mosaic()
+            mosaic_open = False
         t0, mean_items, waited, i = time.time(), None, 0.0, -1
         opt.zero_grad(set_to_none=True)
         batches = iter(train_loader)
@@ -377,7 +387,7 @@ def fit(model, train_loader, prepare, epochs, val_loader=None, lr0=1e-4, lrf=1.0
             if static_graph and getattr(model, '_static', None) is None and batch['img'].is_cuda and hasattr(model, 'capture_static_part'):
                 static_graph = False   # one attempt
                 try:
-                    model.capture_static_part(batch['img'], batch['txt_feats'])
+                    model.capture_static_part(batch['img'], batch['txt_feats'], log=log)   # replays are checked against eager execution
                 except Exception as e:  # noqa: BLE001 - training goes on eagerly; say so
                     model.release_static_part()
                     if log:
@@ -408,11 +418,13 @@ def fit(model, train_loader, prepare, epochs, val_loader=None, lr0=1e-4, lrf=1.0
                 rec['fitness'] = fitness(rec)
             if save_dir is not None:
                 os.makedirs(save_dir, exist_ok=True)
-                ckpt = {'epoch': epoch, 'model': model.state_dict(), 'ema': ema.ema.state_dict(), 'updates': ema.updates,
+                is_best = val_loader is not None and (best is None or rec['fitness'] >= best)
+                if is_best:
+                    best = rec['fitness']
+                ckpt = {'epoch': epoch, 'best_fitness': best, 'model': model.state_dict(), 'ema': ema.ema.state_dict(), 'updates': ema.updates,
                         'optimizer': opt.state_dict(), 'metrics': {k: v for k, v in rec.items() if isinstance(v, float)}}
                 torch.save(ckpt, os.path.join(save_dir, 'last.pt'))
-                if val_loader is not None and (best is None or rec['fitness'] >= best):
-                    best = rec['fitness']
+                if is_best:
                     torch.save(ckpt, os.path.join(save_dir, 'best.pt'))
             if log:
                 log(rec)

@@ -19,6 +19,10 @@ import os
 import torch
 
 
+# torch.version.hip prefixes the replay path (packet capture off + GraphedPart.verify) was exercised on
+VALIDATED_HIP = ('7.0', '7.2')
+
+
 class GraphedPart:
     """fn = GraphedPart(module, sample_args);  out = fn(*args) replays the recorded forward, out.backward() the recorded backward.
 
@@ -64,6 +68,7 @@ class GraphedPart:
         self.n_live = sum(g is not None for g in self.static_grads)
         self._probe = next(((p, g) for p, g in zip(self.params, self.static_grads) if g is not None), None)
         part = self
+        self.n_replays = 0   # forward replays made through __call__ (tests check that a step really took the recorded path)
 
         class _Replay(torch.autograd.Function):
             @staticmethod
@@ -72,6 +77,7 @@ class GraphedPart:
                     if dst.data_ptr() != src.data_ptr():
                         dst.copy_(src)
                 part.fwd.replay()
+                part.n_replays += 1
                 return part.static_out.detach()
 
             @staticmethod
@@ -85,6 +91,71 @@ class GraphedPart:
                 return (None,) * len(part.static_in) + tuple(g.detach() if g is not None else None for g in part.static_grads)
 
         self._fn = _Replay
+
+    @torch.no_grad()
+    def _snapshot_buffers(self):
+        return [b.detach().clone() for b in self.module.buffers()]
+
+    @torch.no_grad()
+    def _restore_buffers(self, saved):
+        for b, v in zip(self.module.buffers(), saved):
+            b.copy_(v)
+
+    def verify(self, replays=1, tol=2e-2, noise_factor=8.0, junk_between=True):
+        """Replay the two recorded graphs on the capture inputs and hold them to an EAGER forward + backward of the same module on the
+        same inputs and the same cotangent: output and every live parameter gradient, as max |difference| / max |reference| per tensor.
+        The eager pass runs twice, so the result carries the eager run-to-run level (`eager_noise`: MIOpen's split-K / atomic solvers
+        are not bitwise reproducible) next to the replay error.  Buffers the module updates in place (BatchNorm statistics) are
+        restored afterwards; no global RNG is consumed (the module must be a function of its inputs: DropPath factors are inputs).
+        Returns a dict; `ok` is False when anything is non-finite or off by more than max(tol, noise_factor * eager_noise) - a replay
+        that went wrong is off by > 1e-1 or NaN (profiles/r02_graph_capture_findings.txt)."""
+        saved = self._snapshot_buffers()
+        live = [i for i, g in enumerate(self.static_grads) if g is not None]
+        gen = torch.Generator(device=self.static_out.device).manual_seed(20261004)
+        cot = torch.randn(self.static_out.shape, generator=gen, device=self.static_out.device, dtype=torch.float32).to(self.static_out.dtype)
+
+        def eager():
+            self._restore_buffers(saved)
+            with torch.enable_grad():
+                out = self.module(*self.static_in)
+                gr = torch.autograd.grad(out, [self.params[i] for i in live], cot, allow_unused=True)
+            return out.detach().float().clone(), [None if g is None else g.detach().float().clone() for g in gr]
+
+        def rel(a, b):
+            if a is None or b is None:
+                return 0.0 if a is b else float('inf')
+            d = float((a.float() - b).abs().max())
+            return d / max(float(b.abs().max()), 1e-12) if d == d else float('nan')
+
+        o1, g1 = eager()
+        o2, g2 = eager()
+        noise_out = rel(o2, o1)
+        noise = [rel(a, b) for a, b in zip(g2, g1)]
+        worst_noise = max([noise_out] + noise)
+        res = {'grads': len(live), 'eager_noise_out': noise_out, 'eager_noise_grad_max': max(noise) if noise else 0.0, 'replays': []}
+        ok = True
+        bound = max(tol, noise_factor * worst_noise)
+        for rep in range(replays):
+            self._restore_buffers(saved)
+            self.static_gout.copy_(cot)
+            self.fwd.replay()
+            if junk_between:  # eager allocations and kernels between the two replays, as the decoder and the loss make them in a step
+                junk = torch.full((1 << 22,), float('nan'), device=cot.device)
+                del junk
+            self.bwd.replay()
+            e_out = rel(self.static_out, o1)
+            errs = [rel(self.static_grads[i], g) for i, g in zip(live, g1)]
+            nonfinite = sum(1 for i in live if not bool(torch.isfinite(self.static_grads[i]).all()))
+            w = max(range(len(errs)), key=lambda j: (errs[j] != errs[j], errs[j])) if errs else None
+            rec = {'out_rel': e_out, 'grad_rel_max': errs[w] if errs else 0.0, 'worst_grad': self.names[live[w]] if errs else None,
+                   'nonfinite_grads': nonfinite}
+            res['replays'].append(rec)
+            bad = nonfinite or not (e_out <= bound) or not (rec['grad_rel_max'] <= bound)
+            ok = ok and not bad
+        self._restore_buffers(saved)
+        res.update(ok=ok, bound=bound, out_rel_max=max(r['out_rel'] for r in res['replays']),
+                   grad_rel_max=max(r['grad_rel_max'] for r in res['replays']))
+        return res
 
     def __call__(self, *args):
         if self._probe is not None and self._probe[0].grad is not None and self._probe[0].grad.data_ptr() == self._probe[1].data_ptr():

@@ -44,16 +44,24 @@ class ManbaWorldDecoder(nn.Module):
         self.dec_score_head = nn.ModuleList(ContrastiveHeadMLP() for _ in range(ndl))
         self.dec_bbox_head = nn.ModuleList(MLP(hd, hd, 4, num_layers=3) for _ in range(ndl))
         self._anchor_cache = {}
+        # teacher forcing of the one discrete choice of the head (parity measurements): a LongTensor [B, nq] of anchor positions used
+        # INSTEAD of torch.topk's picks in _get_decoder_input; None (always, outside tests) = the reference's top-k (head.py:1237)
+        self.fixed_topk = None
         self._reset_parameters()
 
     def forward(self, x, text, batch=None):
         return self.decode(*self.encode(x), text, batch)
 
-    def encode(self, x):
+    def draw_drop_scales(self, n, device):
+        """[num_Blocks, 2, n]: this step's DropPath factors of the VSS blocks (vss.VSSBlock.draw_drop_scales), drawn outside encode()
+        so that a recorded graph of encode() is a deterministic function of its inputs."""
+        return torch.stack([blk.draw_drop_scales(n, device) for blk in self.VSSBlocks])
+
+    def encode(self, x, drop_scales=None):
         """The three trunk maps -> the token memory `feats` [B, L, hd] and the level shapes.  Shapes depend on the image size only."""
         # VSS blocks run channels-last ([B,H,W,C], head.py:1136-1140); their outputs stay token-major: the 1x1 input projection
         # is a GEMM over tokens and its result is already in the [B, L, hd] layout of the token memory
-        toks = [blk(f.permute(0, 2, 3, 1)) for blk, f in zip(self.VSSBlocks, x)]
+        toks = [blk(f.permute(0, 2, 3, 1), None if drop_scales is None else drop_scales[i]) for i, (blk, f) in enumerate(zip(self.VSSBlocks, x))]
         return self._get_encoder_input(toks)
 
     def decode(self, feats, shapes, text, batch=None):
@@ -128,7 +136,7 @@ class ManbaWorldDecoder(nn.Module):
             y = lin(valid.to(feats.dtype) * feats)
         memory = VSSBlock._ln(norm, y)  # LayerNorm kernel in the activation dtype
         scores = self.enc_score_head(memory)
-        top = torch.topk(scores.max(-1).values, self.num_queries, dim=1).indices
+        top = torch.topk(scores.max(-1).values, self.num_queries, dim=1).indices if self.fixed_topk is None else self.fixed_topk.to(feats.device)
         bi = torch.arange(bs, device=feats.device).unsqueeze(-1)
         top_feat = memory[bi, top]
         refer = self.enc_bbox_head(top_feat).float() + anchors[0][top]

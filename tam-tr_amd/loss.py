@@ -211,6 +211,9 @@ class DETRLoss(nn.Module):
         self.loss_gain = loss_gain or {'class': 1, 'bbox': 5, 'giou': 2, 'no_object': 0.1, 'mask': 1, 'dice': 1}
         self.matcher = HungarianMatcher(cost_gain={'class': 2, 'bbox': 5, 'giou': 2})
         self.aux_loss, self.use_fl, self.use_vfl = aux_loss, use_fl, use_vfl
+        # teacher forcing of the Hungarian assignment (parity measurements): per stacked layer [enc, dec 0..n-1] a list of per-image
+        # (query_idx, gt_idx) pairs used INSTEAD of the matcher's; None (always, outside tests) = the matcher (loss.py:282-326)
+        self.fixed_matches = None
 
     def _layers(self, pb, ps, gt_bboxes, gt_cls, gt_groups, match):
         """(class, bbox, giou) of ALL decoder layers at once: pb [layers, bs, nq, 4], ps [layers, bs, nq, nc] -> three [layers]
@@ -218,7 +221,10 @@ class DETRLoss(nn.Module):
         ~40 tiny kernels (and as many in the backward) into one."""
         dev = pb.device
         Lr, bs, nq = pb.shape[:3]
-        if match is None:
+        if match is None and self.fixed_matches is not None:
+            assert len(self.fixed_matches) == Lr, (len(self.fixed_matches), Lr)
+            flats = [flat_matches(Matches(m), dev) for m in self.fixed_matches]
+        elif match is None:
             flats = [flat_matches(m, dev) for m in self.matcher(pb, ps, gt_bboxes, gt_cls, gt_groups)]
         else:
             flats = [flat_matches(match, dev)] * Lr

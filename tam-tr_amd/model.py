@@ -115,8 +115,8 @@ class _StaticPart(nn.Module):
         self.trunk, self.vss, self.proj = nn.ModuleList(model.model[:-1]), head.VSSBlocks, head.input_proj
         object.__setattr__(self, '_owner', model)
 
-    def forward(self, img, txt):
-        return self._owner.token_memory(img, txt, autocast_cache=False)[0]
+    def forward(self, img, txt, drop_scales):
+        return self._owner.token_memory(img, txt, autocast_cache=False, drop_scales=drop_scales)[0]
 
 
 class RTDETRDetectionWorldModel(nn.Module):
@@ -169,9 +169,10 @@ class RTDETRDetectionWorldModel(nn.Module):
     def is_fused(self, thresh=10):
         return sum(isinstance(v, nn.BatchNorm2d) for v in self.modules()) < thresh
 
-    def token_memory(self, x, txt, autocast_cache=True):
+    def token_memory(self, x, txt, autocast_cache=True, drop_scales=None):
         """Trunk -> VSS blocks -> input projection: the part of the step whose shapes follow from the image size alone (what
-        capture_static_part() records as HIP graphs).  Returns the token memory [B, L, hd] and the level shapes."""
+        capture_static_part() records as HIP graphs).  Returns the token memory [B, L, hd] and the level shapes.
+        drop_scales [3, 2, B]: this step's DropPath factors (head.draw_drop_scales); None = the blocks draw their own."""
         head = self.model[-1]
         with torch.autocast('cuda', dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None,
                             cache_enabled=autocast_cache):
@@ -192,25 +193,52 @@ class RTDETRDetectionWorldModel(nn.Module):
                 else:
                     x = m(*args)
                 y.append(x if m.i in self.save else None)
-            feats, shapes = head.encode([y[j] for j in head.f])
+            feats, shapes = head.encode([y[j] for j in head.f], drop_scales)
             if counters is not None:
                 ops.end_bn_counter_batch()  # num_batches_tracked += 1 of every BatchNorm that ran, in one multi-tensor kernel
         return feats, shapes
 
-    def capture_static_part(self, img, txt_feats, warmup=3):
+    def capture_static_part(self, img, txt_feats, warmup=3, verify=True, log=None):
         """Record token_memory() - forward and backward - as two HIP graphs for this image shape, dtype mode and training state
         (graphs.GraphedPart): ~3/4 of the step's kernel launches become two graph launches.  Everything after
         the token memory (query selection, denoising groups, decoder, loss) has shapes that follow the labels and stays eager.
-        `img` / `txt_feats`: tensors of the shapes the training loop will pass.  Undo with release_static_part()."""
-        from .graphs import GraphedPart
+        `img` / `txt_feats`: tensors of the shapes the training loop will pass.  Undo with release_static_part().
+
+        The model is left exactly as it was found: BatchNorm running statistics / counters moved by the warm-up passes are put back and
+        no random numbers are drawn (the DropPath factors are an INPUT of the recorded function; the step draws them eagerly).
+        verify=True: the recorded graphs are replayed once and held to an eager forward + backward on the same inputs
+        (GraphedPart.verify: token memory and every parameter gradient); on a mismatch the graphs are dropped, the reason is logged and
+        RuntimeError is raised - callers (engine.fit, bench.py, tools/train.py) then run eagerly.  The result is kept in
+        `self.static_part_check`."""
+        import torch.version
+        from .graphs import GraphedPart, VALIDATED_HIP
         self.release_static_part()
         part = _StaticPart(self)
         part.train(self.training)
         txt = txt_feats.to(device=img.device, dtype=torch.float32)
+        if len(txt) != len(img):
+            txt = txt.repeat(len(img), 1, 1)
+        saved = [b.detach().clone() for b in part.buffers()]
+        head = self.model[-1]
         with torch.no_grad():
             _, shapes = self.token_memory(img, txt)  # the level shapes
-        graphed = GraphedPart(part, (img.detach(), txt.detach()), warmup=warmup)
-        self._static = (graphed, tuple(img.shape), img.dtype, self.autocast_dtype, self.training, shapes)
+        dp = torch.ones(head.num_Blocks, 2, len(img), device=img.device)
+        graphed = GraphedPart(part, (img.detach(), txt.detach(), dp), warmup=warmup)
+        try:
+            self.static_part_check = graphed.verify() if verify else None
+        finally:
+            with torch.no_grad():
+                for b, v in zip(part.buffers(), saved):
+                    b.copy_(v)
+        if verify and not self.static_part_check['ok']:
+            chk = self.static_part_check
+            msg = (f"HIP-graph replay of the static part does not reproduce eager execution (token memory rel {chk['out_rel_max']:.2e}, worst gradient "
+                   f"rel {chk['grad_rel_max']:.2e} at {chk['replays'][-1]['worst_grad']}, bound {chk['bound']:.1e}; HIP {torch.version.hip}): running eagerly")
+            (log or print)(msg)
+            raise RuntimeError(msg)
+        if log is not None and not any(str(torch.version.hip).startswith(v) for v in VALIDATED_HIP):
+            log(f'HIP-graph replay: runtime {torch.version.hip} is not one this package was validated on {VALIDATED_HIP}; the replay check passed')
+        self._static = (graphed, tuple(img.shape), img.dtype, self.autocast_dtype, self.training, shapes, tuple(txt.shape))
         return self
 
     def release_static_part(self):
@@ -222,10 +250,13 @@ class RTDETRDetectionWorldModel(nn.Module):
             txt = txt.repeat(len(x), 1, 1)
         head = self.model[-1]
         st = getattr(self, '_static', None)
-        if st is not None and st[1:5] == (tuple(x.shape), x.dtype, self.autocast_dtype, self.training) and torch.is_grad_enabled():
-            feats, shapes = st[0](x, txt), st[5]
-        else:
-            feats, shapes = self.token_memory(x, txt)
+        # this step's DropPath factors of the VSS blocks: one draw on the ordinary generator, the same for the replayed and the eager path
+        dp = head.draw_drop_scales(len(x), x.device) if self.training and x.is_cuda else None
+        if st is not None and st[1:5] == (tuple(x.shape), x.dtype, self.autocast_dtype, self.training) and st[6] == tuple(txt.shape) \
+                and torch.is_grad_enabled():
+            feats, shapes = st[0](x, txt, dp), st[5]
+        else:  # other shapes (a tail batch, another prompt count), evaluation, no_grad: kernel by kernel
+            feats, shapes = self.token_memory(x, txt, drop_scales=dp)
         with torch.autocast('cuda', dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None):
             return head.decode(feats, shapes, txt.clone(), batch)
 

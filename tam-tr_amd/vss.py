@@ -163,17 +163,30 @@ class VSSBlock(nn.Module):
             return ops.layer_norm(x, norm.weight, norm.bias, norm.eps)  # activation dtype in and out (no autocast casts around it)
         return norm(x)
 
-    def _residual(self, x, branch):
+    def _residual(self, x, branch, scale=None):
         """x + DropPath(branch) in one kernel: the per-sample keep mask / (1 - p) is a [B,1,1,1] factor of an addcmul (timm's
-        DropPath as separate ops is a mul, a div and an add over the whole map)."""
+        DropPath as separate ops is a mul, a div and an add over the whole map).  `scale` [B]: the factor drawn by the caller
+        (draw_drop_scales) - a recorded HIP graph takes it as an INPUT, so a replay and an eager pass given the same draw are the same
+        function (the draw itself stays outside the graph, on the ordinary generator)."""
         p = self.drop_path.drop_prob
+        if scale is not None:
+            return torch.addcmul(x, branch, scale.to(x.dtype).view((x.shape[0],) + (1,) * (x.dim() - 1)))
         if p == 0.0 or not self.training:
             return x + branch
         keep = 1.0 - p
         scale = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep) / keep
         return torch.addcmul(x, branch, scale)
 
-    def forward(self, x):
+    def draw_drop_scales(self, n, device):
+        """[2, n] fp32: keep mask / (1 - p) of the block's two residual branches (ones when DropPath is inactive)."""
+        p = self.drop_path.drop_prob
+        if p == 0.0 or not self.training:
+            return torch.ones(2, n, device=device)
+        keep = 1.0 - p
+        return torch.empty(2, n, device=device).bernoulli_(keep) / keep
+
+    def forward(self, x, drop_scales=None):
         x = x.contiguous()  # the head hands in a permuted NCHW view: one copy here keeps both residual adds contiguous
-        x = self._residual(x, self.op(self._ln(self.norm, x)))
-        return self._residual(x, self.mlp(self._ln(self.norm2, x)))
+        s1, s2 = (None, None) if drop_scales is None else (drop_scales[0], drop_scales[1])
+        x = self._residual(x, self.op(self._ln(self.norm, x)), s1)
+        return self._residual(x, self.mlp(self._ln(self.norm2, x)), s2)

@@ -235,3 +235,52 @@ def test_reducer_buckets_keep_channels_last_strides_single_process():
             flat = [b['flat'] for b in red.buckets if any(q is p for _, q in b['params'])][0]
             assert flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + flat.numel() * flat.element_size()
     red.remove()
+
+
+# ------------------------------------------------------------------------------------------------ `--gpus N` starts its own ranks
+def test_launch_plan_decision_and_argv():
+    """bench.py / tools/train.py started as plain `python script --gpus N` become the launcher of N ranks (reference:
+    engine/trainer.py:161-189 -> utils/dist.py:50-62); under a launcher (RANK / WORLD_SIZE set) or for one GPU they do not."""
+    from tamtr_amd.dist import launch_plan
+    script = os.path.join(ROOT, 'bench.py')
+    assert launch_plan(1, {}, ['--gpus', '1'], script) is None
+    assert launch_plan(4, {'WORLD_SIZE': '4', 'RANK': '0'}, ['--gpus', '4'], script) is None          # the driver's torch.distributed.run form
+    assert launch_plan(4, {'RANK': '2'}, ['--gpus', '4'], script) is None
+    cmd = launch_plan(4, {'PATH': '/usr/bin'}, ['--gpus', '4', '--steps', '20', '--warmup', '5'], 'bench.py')
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert '--nnodes=1' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '4' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    port = int(cmd[cmd.index('--master-port') + 1])
+    assert 1024 < port < 65536
+    k = cmd.index(os.path.abspath('bench.py'))                 # the script by absolute path, then the caller's own arguments unchanged
+    assert cmd[k + 1:] == ['--gpus', '4', '--steps', '20', '--warmup', '5']
+
+
+def test_self_launch_runs_two_gloo_ranks_and_returns_their_code(tmp_path):
+    """The launch itself, on the CPU: a script that calls launch_plan / self_launch the way bench.py does comes back as two gloo ranks
+    that see each other; a failing rank's exit code is propagated."""
+    script = tmp_path / 'mini.py'
+    script.write_text(f'''
+import os, sys
+sys.path.insert(0, {ROOT!r})
+from tamtr_amd import dist as tdist
+plan = tdist.launch_plan(int(sys.argv[sys.argv.index('--gpus') + 1]), os.environ, sys.argv[1:], __file__)
+if plan is not None:
+    raise SystemExit(tdist.self_launch(plan))
+import torch, torch.distributed as dist
+rank, local, world = tdist.init_from_env('gloo')
+t = torch.tensor([float(rank + 1)])
+dist.all_reduce(t)
+if rank == 0:
+    open(sys.argv[sys.argv.index('--out') + 1], 'w').write(f'{{world}} {{float(t)}}')
+dist.barrier()
+dist.destroy_process_group()
+raise SystemExit(3 if '--fail' in sys.argv else 0)
+''')
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = tmp_path / 'o.txt'
+    r = subprocess.run([sys.executable, str(script), '--gpus', '2', '--out', str(out)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out.read_text() == '2 3.0'
+    r = subprocess.run([sys.executable, str(script), '--gpus', '2', '--out', str(out), '--fail'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0

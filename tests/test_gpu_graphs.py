@@ -77,6 +77,68 @@ def test_vss_and_projection_replay_equals_eager(pkg):
         assert worst[0] <= 2e-3, (rep, worst, noise)   # library GEMMs may pick another algorithm on the capture stream (measured 2.4e-4); garbage is > 1e-1
 
 
+def test_whole_static_part_replay_equals_eager_at_the_bench_configuration(pkg):
+    """The execution mode bench.py measures: trunk + VSS blocks + input projection (everything model.capture_static_part records) at
+    640 x 640, 16 images, bf16, replayed SIX times (eager allocations between the forward and the backward replay, as decoder and loss
+    make them) against eager execution of the same function on the same inputs and cotangent: the token memory and ALL 552 parameter
+    gradients, per tensor as max |difference| / max |reference|, next to the eager run-to-run level of the same quantities (MIOpen's
+    split-K / atomic solvers).  A replay gone wrong is off by > 1e-1 or NaN (profiles/r02_graph_capture_findings.txt); DropPath is ON:
+    its factors are an input of the recorded function (drawn once here)."""
+    import json, os
+    from conftest import ROOT
+    torch.manual_seed(0)
+    model = pkg.model.RTDETRDetectionWorldModel(nc=10).cuda().train()
+    model.autocast_dtype = torch.bfloat16
+    B, S = 16, 640
+    batch = {k: (dev(v) if k in ('img', 'txt_feats') else v) for k, v in _bench_batch(B, S, 1).items()}
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    rng = torch.cuda.get_rng_state()
+    model.capture_static_part(batch['img'], batch['txt_feats'], verify=False)
+    # capture leaves the model as it found it: BatchNorm statistics / counters and the generator (ADVICE r2: +4 momentum updates before step 1)
+    after = model.state_dict()
+    assert all(torch.equal(after[k], before[k]) for k in before)
+    assert torch.equal(torch.cuda.get_rng_state(), rng)
+    gp = model._static[0]
+    assert gp.n_live == 552 and len(gp.params) == 582
+    gp.static_in[2].copy_(model.model[-1].draw_drop_scales(B, 'cuda'))      # a real DropPath draw (some factors 0, the others 1 / 0.9)
+    assert float(gp.static_in[2].min()) == 0.0 or B < 8
+    chk = gp.verify(replays=6, tol=3e-3, noise_factor=4.0)
+    rec = {k: v for k, v in chk.items() if k != 'replays'}
+    rec['per_replay'] = chk['replays']
+    out = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(out):
+        json.dump(rec, open(os.path.join(out, 'graph_replay_check_640_bs16.json'), 'w'), indent=1)
+    print('static part replay check:', json.dumps(rec))
+    assert chk['grads'] == 552
+    assert all(r['nonfinite_grads'] == 0 for r in chk['replays'])
+    assert chk['ok'], rec                                    # every replay within max(3e-3, 4 x eager run-to-run) on every tensor
+    assert chk['bound'] <= 2e-2, rec                         # and that run-to-run level is itself small
+    after = model.state_dict()
+    assert all(torch.equal(after[k], before[k]) for k in before)   # verify() put the statistics back as well
+    model.release_static_part()
+
+
+def test_replay_key_includes_the_prompt_shape(pkg):
+    """A batch with another prompt count (or image shape) must run eagerly instead of reaching static_in.copy_."""
+    torch.manual_seed(0)
+    model = pkg.model.RTDETRDetectionWorldModel(nc=10).cuda().train()
+    model.autocast_dtype = torch.bfloat16
+    B, S = 2, 256
+    batch = {k: (dev(v) if k in ('img', 'txt_feats') else v) for k, v in _bench_batch(B, S, 3).items()}
+    model.capture_static_part(batch['img'], batch['txt_feats'])
+    assert model.static_part_check['ok']
+    gp = model._static[0]
+    loss, _ = model(batch)
+    assert gp.n_replays == 1
+    out = model.predict(batch['img'], txt_feats=batch['txt_feats'][:, :7].contiguous())    # 7 prompts: not the recorded function
+    assert gp.n_replays == 1 and out[1].shape[-1] == 7 and torch.isfinite(out[1]).all()
+    out = model.predict(batch['img'][:, :, :192].contiguous(), txt_feats=batch['txt_feats'])  # another image shape: eager as well
+    assert gp.n_replays == 1 and torch.isfinite(out[0]).all()
+    out = model.predict(batch['img'], txt_feats=batch['txt_feats'])
+    assert gp.n_replays == 2
+    model.release_static_part()
+
+
 def test_capture_after_eager_steps_then_train(pkg):
     torch.manual_seed(0)
     model = pkg.model.RTDETRDetectionWorldModel(nc=10).cuda().train()
@@ -107,8 +169,10 @@ def test_capture_after_eager_steps_then_train(pkg):
     assert all(torch.isfinite(torch.tensor(graphed))), graphed
     none = [k for k, p in model.named_parameters() if p.grad is None]
     assert len(none) == 30 and all('.attn.' in k for k in none)
-    # DropPath draws differ between a replayed and an eager step (the graph has its own Philox offsets): trajectories, not bits
-    assert abs(graphed[-1] - eager[-1]) / eager[-1] < 0.15, (graphed, eager)
+    # same seeds => same denoising groups AND same DropPath factors (they are drawn outside the recorded function): the two
+    # trajectories differ by bf16 / split-K run-to-run noise amplified over 8 optimizer steps on a 2-image batch (measured: see below)
+    print('graphed', graphed, 'eager', eager)
+    assert max(abs(g - e) / e for g, e in zip(graphed, eager)) < 0.05, (graphed, eager)
     assert graphed[-1] < graphed[0]
     # accumulating onto the adopted static buffers would double the gradient: refused
     model.zero_grad(set_to_none=False)

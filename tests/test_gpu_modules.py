@@ -216,9 +216,11 @@ def test_tall_linear_weight_gradient(pkg, M, N, K):
     assert pkg.ops._split_count(16 * 33600) == 64 and pkg.ops._split_count(3000) == 1
 
 
-def test_linear_bf16_full_size(pkg):
-    """BASELINE shape M = 16 * 33600, N = K = 512: checksum-of-rows property against an fp32 GEMV (size independent)."""
-    M, N, K = 16 * 33600, 512, 512
+@pytest.mark.parametrize('M', [16 * 33600, 8 * 134400])
+def test_linear_bf16_full_size(pkg, M):
+    """BASELINE shapes M = 16 * 33 600 (640^2, 16 images) and M = 8 * 134 400 = 1 075 200 (configs[4]: 1280^2, 8 images), N = K = 512:
+    checksum-of-rows property against an fp32 GEMV (size independent) + sampled rows against the fp32 product."""
+    N, K = 512, 512
     g = torch.Generator(device='cuda').manual_seed(0)
     x = torch.randn(M, K, device='cuda', generator=g).bfloat16()
     w = (torch.randn(N, K, device='cuda', generator=g) * K ** -0.5).bfloat16()
@@ -227,8 +229,8 @@ def test_linear_bf16_full_size(pkg):
     want = (x.float().sum(0, keepdim=True) @ w.float().t()).squeeze(0)
     got = y.float().sum(0)
     assert_close(got, want, 0, 1e-2 * float(np.sqrt(M)), 'column checksum')  # bf16 output rounding: sigma ~ 1.1e-3 * sqrt(M) per column
-    idx = torch.randint(0, M, (64,), device='cuda', generator=g)
-    assert_close(y[idx].float(), x[idx].float() @ w.float().t(), 2 ** -8, 1e-3, 'sampled rows')
+    idx = torch.cat([torch.randint(0, M, (64,), device='cuda', generator=g), torch.tensor([0, 1, M // 2, M - 2, M - 1], device='cuda')])
+    assert_close(y[idx].float(), x[idx].float() @ w.float().t(), 2 ** -8, 1e-3, 'sampled rows (incl. the first and the last block)')
 
 
 # ------------------------------------------------------------------------------------------------ modules vs fixtures

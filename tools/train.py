@@ -2,7 +2,8 @@
 """Train TAM-TR on a YOLO-format dataset (the reference's trainTAMTR.py flow on tam-tr_amd/engine.py + data.py).
 
     python tools/train.py --data dataset.yaml --text-feats clip_vitb32.npz --epochs 300 --batch 6 --save-dir runs/train/TAMTR
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/train.py ...   # one rank per GPU
+    python tools/train.py --gpus 8 ...                         # one rank per GPU: the script starts its own torch.distributed.run child
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/train.py --gpus 8 ...   # or under a launcher
 
 dataset.yaml: `path`, `train`, `val` (image directories or list files) and `names` (index -> class name, `a/b` = synonyms), as
 dataset/visdrone.yaml in the reference.  --text-feats: .npz {texts [n], feats [n, 512]} or a torch-saved {text: vector} with one
@@ -40,6 +41,8 @@ def synthetic_dataset(root, n, size=(540, 960), seed=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--data')
+    ap.add_argument('--gpus', type=int, default=None, help="GPUs of this node (the reference's device='0,1,..'): N > 1 without a launcher "
+                                                           'in the environment starts N ranks (trainer.py:161-189); default: WORLD_SIZE or 1')
     ap.add_argument('--text-feats')
     ap.add_argument('--synthetic', type=int, default=0)
     ap.add_argument('--epochs', type=int, default=300)
@@ -63,7 +66,12 @@ def main():
     import tamtr_amd  # noqa: F401  (raises if the HIP library is missing)
     from tamtr_amd import data as D, dist as tdist, engine as E
     from tamtr_amd.model import RTDETRDetectionWorldModel
+    plan = tdist.launch_plan(args.gpus or 1, os.environ, sys.argv[1:], __file__)
+    if plan is not None:   # become the launcher of the ranks (a child process; nothing here has touched the GPU)
+        raise SystemExit(tdist.self_launch(plan))
     rank, local, world = tdist.init_from_env()
+    if args.gpus is not None and args.gpus != world:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     from tamtr_amd.tuning import use_tuned_convolutions
     conv_tuning = use_tuned_convolutions(args.conv_tuning)   # before the first convolution (tables cover 640 px / 16 images; other shapes are searched once)
     if rank == 0:
@@ -114,6 +122,8 @@ def main():
         return D.preprocess_batch(batch, tf if training else None, dev)
 
     def log(rec):
+        if not isinstance(rec, dict):
+            return print(rec, flush=True)
         print(json.dumps({k: (round(v, 5) if isinstance(v, float) else v) for k, v in rec.items()}), flush=True)
     E.fit(model, tl, prepare, args.epochs, val_loader=vl, lr0=args.lr0, close_mosaic=args.close_mosaic, imgsz=args.imgsz, reducer=reducer,
           rank=rank, world=world, save_dir=args.save_dir if rank == 0 else None, max_steps=args.max_steps, log=log, resume=resume,
