@@ -91,6 +91,17 @@ int tamtr_msdeform_attn_bwd(const void* gout, const void* value, const int32_t* 
                             const float* aw, float* gvalue, float* gloc, float* gaw, int B, int L, int M, int D, int Q,
                             int nl, int P, int dtype, void* stream);
 
+/*      Backward without atomics: the same gloc / gaw, and gvalue (T, the VALUE's dtype) written exactly once per element as an
+ *      ordered sum - the caller neither zeroes it nor casts it, and two calls on the same inputs give the same bits (the
+ *      reference trains with deterministic=True: ultralytics/cfg/default.yaml:26, utils/torch_utils.py:371-389; torch's own
+ *      grid_sample backward is the atomic scatter this replaces).  Per (image, head, level) the Q*P*4 bilinear corners are sorted
+ *      by destination row in LDS and every row sums its run.  gvalue rows have pitch ldg elements (M*D for a plain [B,L,M,D]
+ *      tensor).  Limits: Q*P*4 <= 8192, D % 8 == 0, D <= 256, H*W < 2^19 - 1 per level; TAMTR_EUNSUP otherwise.
+ */
+int tamtr_msdeform_attn_bwd_sorted(const void* gout, const void* value, const int32_t* shapes_host, const float* loc,
+                                   const float* aw, void* gvalue, float* gloc, float* gaw, int B, int L, int M, int D, int Q,
+                                   int nl, int P, long long ldg, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * a-8  Text-contrastive logits.  Replaces ContrastiveHeadMLP.forward, ultralytics/nn/modules/block.py:534-541:
  *          logits[b,q,k] = < x[b,q,:]/max(|x|,1e-12), w[b,k,:]/max(|w|,1e-12) > * exp(logit_scale) + bias
@@ -100,9 +111,12 @@ int tamtr_msdeform_attn_bwd(const void* gout, const void* value, const int32_t* 
 int tamtr_contrastive_logits_fwd(const void* x, const float* w, const float* logit_scale, const float* bias, float* logits,
                                  float* xinv, float* winv, int B, int Q, int K, int C, int dtype, void* stream);
 
-/*      Backward: g f32 [B,Q,K] -> dx (T) [B,Q,C], dwhat f32 [B,K,C] (ACCUMULATED: caller zeroes it; it is the gradient
- *      w.r.t. the *normalised* text rows, the host projects it through the normalisation - a [B,K,C] elementwise op).
+/*      Backward: g f32 [B,Q,K] -> dx (T) [B,Q,C], dwhat f32 [B, S, K, C] with S = tamtr_contrastive_bwd_slabs(Q): every
+ *      workgroup STORES the partial sum of its query rows into its own slab (no atomics between workgroups; for K <= 16 none
+ *      inside either, so the result is bitwise reproducible); the caller adds the S slabs.  The sum is the gradient w.r.t. the
+ *      *normalised* text rows, which the host projects through the normalisation - a [B,K,C] elementwise op.
  */
+int tamtr_contrastive_bwd_slabs(int Q);
 int tamtr_contrastive_logits_bwd(const float* g, const void* x, const float* w, const float* logit_scale, const float* xinv,
                                  const float* winv, void* dx, float* dwhat, int B, int Q, int K, int C, int dtype,
                                  void* stream);
@@ -150,31 +164,36 @@ int tamtr_selective_scan_fwd(const float* u, const float* delta, const float* A,
                              const float* D, const float* dbias, float* y, float* hstate, int B, int K, int Dk, int N, int L,
                              int xmode, void* stream);
 /*      Backward: gy f32 [B,KD,L] -> gu, gdelta f32 [B,KD,L] (in xmode gu is per direction, stored un-reversed: the host adds
- *      gu[:, k] + gu[:, k+2] to get the gradient of u[:, k]); gB, gC f32 [B,K,N,L] (plain stores); gA f32 [KD,N], gD,
- *      gdbias f32 [KD] (ACCUMULATED over the batch: caller zeroes).  ws: caller workspace of
- *      2 * tamtr_selective_scan_bwd_slabs(Dk) * B*K*N*L floats (per-workgroup partial dB/dC slabs, summed by a second kernel).
+ *      gu[:, k] + gu[:, k+2] to get the gradient of u[:, k]); gB, gC f32 [B,K,N,L] (plain stores);
+ *      grow f32 [B, KD, S], S = tamtr_selective_scan_row_sums() (= 64): per image and row the sums over time
+ *          grow[b, kd, 0:16] = dA[kd, :] | [16:16+R] = d(Wdt)[kd, :] (dtproj variant) | [48] = dD[kd] | [49] = d(dbias)[kd]
+ *      written with plain stores (one writer per (b, kd)); the caller adds the B images - in a fixed order, so the result is bitwise
+ *      reproducible (ABI <= 21 accumulated gA / gD / gdbias / gWdt over the batch with float atomics).  ws: caller workspace of
+ *      2 * tamtr_selective_scan_bwd_slabs(Dk) * B*K*N*L floats (per-workgroup partial dB/dC slabs, summed in slab order by a second
+ *      kernel; the dtproj variant reuses it for the row-split partials of gdtr on short sequences).
  *      xmode = 3 (backward only): as xmode = 1 and gy is ALSO in pair layout [B, 2, Dk, L] - the gradient of the
  *      cross-merged map (CrossMerge, csms6s.py:26-34) in its row-major and column-major flattening; direction k reads
  *      gy[:, k & 1], so the four per-direction gradient planes are never materialised.
  */
 int tamtr_selective_scan_bwd_slabs(int Dk);
+int tamtr_selective_scan_row_sums(void);
 int tamtr_selective_scan_bwd(const float* gy, const float* u, const float* delta, const float* A, const float* Bm,
                              const float* Cm, const float* D, const float* dbias, const float* hstate, float* gu,
-                             float* gdelta, float* gA, float* gB, float* gC, float* gD, float* gdbias, float* ws, int B, int K,
-                             int Dk, int N, int L, int xmode, void* stream);
+                             float* gdelta, float* grow, float* gB, float* gC, float* ws, int B, int K, int Dk, int N, int L,
+                             int xmode, void* stream);
 
 /*      Fused dt projection (replaces the `dts = einsum("bkrl,kdr->bkdl")` of SS2D.forward_corev2, vmamba.py:972, whose
  *      [B, 4*d_inner, L] result is never materialised): delta[b, k*Dk+d, t] = sum_r Wdt[k*Dk+d, r] * dtr[b, k, r, t] is formed
  *      inside the scan.  dtr f32 [B, K, R, L], Wdt f32 [KD, R], R <= 32.  Backward additionally returns gdtr f32 [B,K,R,L]
- *      (plain stores), gWdt f32 [KD, R] (ACCUMULATED over the batch: caller zeroes); gdelta_ws: caller workspace [B,KD,L].
+ *      (plain stores) and d(Wdt) inside grow (see above); gdelta_ws: caller workspace [B,KD,L].
  */
 int tamtr_selective_scan_dtproj_fwd(const float* u, const float* dtr, const float* Wdt, const float* A, const float* Bm,
                                     const float* Cm, const float* D, const float* dbias, float* y, float* hstate, int B, int K,
                                     int Dk, int N, int R, int L, int xmode, void* stream);
 int tamtr_selective_scan_dtproj_bwd(const float* gy, const float* u, const float* dtr, const float* Wdt, const float* A,
                                     const float* Bm, const float* Cm, const float* D, const float* dbias, const float* hstate,
-                                    float* gu, float* gdelta_ws, float* gdtr, float* gWdt, float* gA, float* gB, float* gC, float* gD,
-                                    float* gdbias, float* ws, int B, int K, int Dk, int N, int R, int L, int xmode, void* stream);
+                                    float* gu, float* gdelta_ws, float* gdtr, float* grow, float* gB, float* gC, float* ws, int B,
+                                    int K, int Dk, int N, int R, int L, int xmode, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * a-10 / next-4  Device-side Hungarian assignment.  Replaces `C.cpu()` + scipy.optimize.linear_sum_assignment per

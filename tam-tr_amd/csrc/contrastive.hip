@@ -13,7 +13,7 @@ namespace {
 constexpr int CT_THREADS = 256;
 constexpr int CT_WAVES = CT_THREADS / WAVE;
 constexpr int CT_ROWS = 16;  // query rows per workgroup (forward)
-constexpr int CT_BROWS = 80; // backward: few workgroups per image, so that d(what) meets few global atomics per address
+constexpr int CT_BROWS = 80; // backward: few workgroups per image: each stores its d(what) partial, the caller adds the few partials
 constexpr int CT_KR = 16;    // text rows whose d(what) partial sums a wave keeps in registers (larger vocabularies: LDS atomics)
 
 template <typename ET>
@@ -217,20 +217,28 @@ __global__ __launch_bounds__(CT_THREADS) void contrastive_bwd_kernel(const float
       }
     }
   }
-  if (REGS) {   // the four waves' register sums meet in LDS once
+  if (REGS) {   // the four waves' register sums meet in LDS once, one wave after the other: a fixed order of additions
+    for (int turn = 0; turn < CT_WAVES; ++turn) {
+      __syncthreads();
+      if (wave == turn) {
 #pragma unroll
-    for (int k = 0; k < CT_KR; ++k)
-      if (k < K)
+        for (int k = 0; k < CT_KR; ++k)
+          if (k < K)
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          const int c = (p * WAVE + lane) * V;
-          if (c < C)
+            for (int p = 0; p < NP; ++p) {
+              const int c = (p * WAVE + lane) * V;
+              if (c < C)
 #pragma unroll
-            for (int i = 0; i < V; ++i) atomicAdd(&s_acc[(size_t)k * C + c + i], wacc[k][p][i]);
-        }
+                for (int i = 0; i < V; ++i) s_acc[(size_t)k * C + c + i] += wacc[k][p][i];
+            }
+      }
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < K * C; i += CT_THREADS) atomicAdd(dwhat + (size_t)b * K * C + i, s_acc[i]);
+  // this workgroup's partial of d(what): plain stores into its own slab [b][blockIdx.x][K][C] (no global atomics; the caller sums the
+  // ceil(Q / CT_BROWS) slabs)
+  float* slab = dwhat + ((size_t)b * gridDim.x + blockIdx.x) * K * C;
+  for (int i = threadIdx.x; i < K * C; i += CT_THREADS) slab[i] = s_acc[i];
 }
 
 inline int pick_np(int C, int V) {
@@ -264,6 +272,8 @@ extern "C" int tamtr_contrastive_logits_fwd(const void* x, const float* w, const
 #undef GO1
   return tamtr_launch_status();
 }
+
+extern "C" int tamtr_contrastive_bwd_slabs(int Q) { return Q > 0 ? (Q + CT_BROWS - 1) / CT_BROWS : 0; }
 
 extern "C" int tamtr_contrastive_logits_bwd(const float* g, const void* x, const float* w, const float* logit_scale,
                                             const float* xinv, const float* winv, void* dx, float* dwhat, int B, int Q, int K,

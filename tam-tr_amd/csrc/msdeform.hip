@@ -95,7 +95,7 @@ __global__ __launch_bounds__(MSDA_THREADS) void msda_fwd_kernel(const ET* __rest
 }
 
 // one lane per channel (LPG = min(64, pow2ceil(D)) lanes per item; D > 64 loops)
-template <typename ET, int LPG>
+template <typename ET, int LPG, bool SCATTER>
 __global__ __launch_bounds__(MSDA_THREADS) void msda_bwd_kernel(const ET* __restrict__ gout, const ET* __restrict__ value,
                                                                  const float* __restrict__ loc, const float* __restrict__ aw,
                                                                  float* __restrict__ gvalue, float* __restrict__ gloc,
@@ -138,8 +138,10 @@ __global__ __launch_bounds__(MSDA_THREADS) void msda_bwd_kernel(const ET* __rest
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           if (okc[c]) {  // group-uniform
-            const float w = ((c & 1) ? fx : 1.f - fx) * ((c >> 1) ? fy : 1.f - fy);
-            atomicAdd(gvalue + oc[c], w * a * g);
+            if (SCATTER) {
+              const float w = ((c & 1) ? fx : 1.f - fx) * ((c >> 1) ? fy : 1.f - fy);
+              atomicAdd(gvalue + oc[c], w * a * g);
+            }
           } else {
             vc[c] = 0.f;
           }
@@ -155,6 +157,133 @@ __global__ __launch_bounds__(MSDA_THREADS) void msda_bwd_kernel(const ET* __rest
       if (gl == 0) {
         gaw[(size_t)gid * nl * P + l * P + p] = s_aw;
         *reinterpret_cast<float2*>(gloc + ((size_t)gid * nl * P + l * P + p) * 2) = make_float2(s_x * a * W, s_y * a * H);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// d/d(value) WITHOUT atomics (and without a zero fill, an fp32 accumulator or a cast): every row of the gradient is written exactly
+// once, in the value's own dtype, as an ordered sum.
+//   One workgroup per (image, head, row slice of one level).  The contributions of that (image, head) to the level are the
+//   Q*P*4 bilinear corners (<= 8192): the workgroup computes them into LDS as 32-bit keys (row inside the level << 13 | corner
+//   index; corners off the map get the all-ones key), sorts the keys (bitonic, in LDS), finds every row's run of keys by binary
+//   search, and then walks its rows: a group of D/8 lanes owns a row, adds weight * gout[b, q, m, :] over the row's run IN KEY
+//   ORDER (= a fixed order: bitwise reproducible) and stores the row - zeros for the (majority of) rows nobody sampled.
+//   Row slices (<= MSDA_SLICE_ROWS rows) only spread the store traffic over more workgroups; each re-sorts its level's keys
+//   (~10 us against ~0.8 MB of stores).
+constexpr int MSDA_SORT_THREADS = 1024;
+constexpr int MSDA_MAX_KEYS = 8192;      // corners per (image, head, level): Q * P * 4
+constexpr int MSDA_IDX_BITS = 13;
+constexpr int MSDA_SLICE_ROWS = 6400;
+
+struct SliceTab {
+  int first[MAXL + 1];  // prefix sums of the slices per level; first[nl] = slices in total
+};
+
+template <typename ET, int LPR>  // LPR lanes per row, 8 channels each
+__global__ __launch_bounds__(MSDA_SORT_THREADS) void msda_gvalue_sorted_kernel(const ET* __restrict__ gout, const float* __restrict__ loc,
+                                                                                const float* __restrict__ aw, ET* __restrict__ gvalue,
+                                                                                Levels lv, SliceTab tab, int L, int M, int D, int Q,
+                                                                                int nl, int P, int NS, long long ldg) {
+  __shared__ uint32_t keys[MSDA_MAX_KEYS];
+  __shared__ float wts[MSDA_MAX_KEYS];
+  __shared__ uint16_t first_key[MSDA_SLICE_ROWS + 2];
+  const int tid = threadIdx.x;
+  const int m = blockIdx.y, b = blockIdx.z;
+  int l = 0;
+  while (l + 1 < nl && (int)blockIdx.x >= tab.first[l + 1]) ++l;
+  const int H = lv.H[l], W = lv.W[l];
+  const int rows = H * W;
+  const int nsl = tab.first[l + 1] - tab.first[l];
+  const int per = (rows + nsl - 1) / nsl;
+  const int lo = ((int)blockIdx.x - tab.first[l]) * per;
+  const int hi = min(lo + per, rows);
+  // ---- the level's corners of this (image, head)
+  const int n_pts = Q * P;
+  for (int e = tid; e < n_pts; e += MSDA_SORT_THREADS) {
+    const int q = e / P, p = e - q * P;
+    const size_t at = ((((size_t)b * Q + q) * M + m) * nl + l) * P + p;
+    const float2 xy = *reinterpret_cast<const float2*>(loc + at * 2);
+    const float a = aw[at];
+    const float x = xy.x * W - 0.5f, y = xy.y * H - 0.5f;
+    const float xf = floorf(x), yf = floorf(y);
+    const float fx = x - xf, fy = y - yf;
+    // floorf of a huge / non-finite coordinate: clamp before the int conversion (any value outside the map is "off")
+    const int x0 = (int)fminf(fmaxf(xf, -2.f), (float)W + 1.f), y0 = (int)fminf(fmaxf(yf, -2.f), (float)H + 1.f);
+    const bool fin = (x == x) & (y == y);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int xi = x0 + (c & 1), yi = y0 + (c >> 1);
+      const bool ok = fin & (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H);
+      const int idx = e * 4 + c;
+      keys[idx] = ok ? (((uint32_t)(yi * W + xi) << MSDA_IDX_BITS) | (uint32_t)idx) : 0xffffffffu;
+      wts[idx] = ((c & 1) ? fx : 1.f - fx) * ((c >> 1) ? fy : 1.f - fy) * a;
+    }
+  }
+  for (int i = n_pts * 4 + tid; i < NS; i += MSDA_SORT_THREADS) keys[i] = 0xffffffffu;
+  __syncthreads();
+  // ---- bitonic sort of NS keys, ascending
+  for (int k = 2; k <= NS; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (NS >> 1); t += MSDA_SORT_THREADS) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // the lower index of pair t at distance j
+        const int ix = i | j;
+        const uint32_t ka = keys[i], kb = keys[ix];
+        const bool up = (i & k) == 0;
+        if ((ka > kb) == up) { keys[i] = kb; keys[ix] = ka; }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- first key of every row of the slice (and of the row after it)
+  for (int r = lo + tid; r <= hi; r += MSDA_SORT_THREADS) {
+    const uint32_t want = (uint32_t)r << MSDA_IDX_BITS;
+    int a0 = 0, n = NS;           // lower_bound(keys, want)
+    while (n > 0) {
+      const int h = n >> 1;
+      if (keys[a0 + h] < want) { a0 += h + 1; n -= h + 1; } else n = h;
+    }
+    first_key[r - lo] = (uint16_t)a0;
+  }
+  __syncthreads();
+  // ---- the rows
+  const int g = tid / LPR, ln = tid % LPR;
+  const int d0 = ln * 8;
+  const bool act = d0 < D;
+  const size_t gb = (size_t)b * Q * M * D + (size_t)m * D + (act ? d0 : 0);
+  ET* const ob = gvalue + ((size_t)b * L + lv.start[l]) * ldg + (size_t)m * D + (act ? d0 : 0);
+  for (int r = lo + g; r < hi; r += MSDA_SORT_THREADS / LPR) {
+    const int s = first_key[r - lo], e = first_key[r - lo + 1];
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int i = s; i < e; ++i) {
+      const int idx = (int)(keys[i] & (MSDA_MAX_KEYS - 1));
+      const float w = wts[idx];
+      const int q = idx / (4 * P);
+      float gv[8];
+      if (sizeof(ET) == 2) {
+        VecLd<bf16_t, 8>::ld(reinterpret_cast<const bf16_t*>(gout) + gb + (size_t)q * M * D, gv);
+      } else {
+        const float* gp = reinterpret_cast<const float*>(gout) + gb + (size_t)q * M * D;
+        float lo4[4], hi4[4];
+        Elt<float>::ld4(gp, lo4);
+        Elt<float>::ld4(gp + 4, hi4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { gv[t] = lo4[t]; gv[4 + t] = hi4[t]; }
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = fmaf(w, gv[t], acc[t]);
+    }
+    if (act) {
+      if (sizeof(ET) == 2) {
+        VecLd<bf16_t, 8>::st(reinterpret_cast<bf16_t*>(ob) + (size_t)r * ldg, acc);
+      } else {
+        float* op = reinterpret_cast<float*>(ob) + (size_t)r * ldg;
+        const float lo4[4] = {acc[0], acc[1], acc[2], acc[3]}, hi4[4] = {acc[4], acc[5], acc[6], acc[7]};
+        Elt<float>::st4(op, lo4);
+        Elt<float>::st4(op + 4, hi4);
       }
     }
   }
@@ -223,7 +352,7 @@ extern "C" int tamtr_msdeform_attn_bwd(const void* gout, const void* value, cons
   {                                                                                                                       \
     const int per_blk = MSDA_THREADS / LPG;                                                                               \
     dim3 grid((unsigned)((n_items + per_blk - 1) / per_blk));                                                             \
-    hipLaunchKernelGGL((msda_bwd_kernel<ET, LPG>), grid, dim3(MSDA_THREADS), 0, s, (const ET*)gout, (const ET*)value, loc, aw, \
+    hipLaunchKernelGGL((msda_bwd_kernel<ET, LPG, true>), grid, dim3(MSDA_THREADS), 0, s, (const ET*)gout, (const ET*)value, loc, aw, \
                        gvalue, gloc, gaw, lv, (int)n_items, L, M, D, Q, nl, P);                                           \
   }
 #define PICK(ET)                                                                                           \
@@ -231,6 +360,58 @@ extern "C" int tamtr_msdeform_attn_bwd(const void* gout, const void* value, cons
   if (dtype == TAMTR_F32) { PICK(float) }
   else if (dtype == TAMTR_BF16) { PICK(bf16_t) }
   else return TAMTR_EINVAL;
+#undef PICK
+#undef GO
+  return tamtr_launch_status();
+}
+
+// Deterministic backward: gloc / gaw as above (no scatter), gvalue by the sorted segmented sum - written ONCE per element in the
+// value's dtype (no zero fill by the caller, no float atomics, bitwise reproducible).  ldg: token pitch of gvalue in elements
+// (M*D when it is its own [B,L,M,D] tensor; larger when it is a column block of a wider [B*L, ldg] matrix).
+extern "C" int tamtr_msdeform_attn_bwd_sorted(const void* gout, const void* value, const int32_t* shapes_host, const float* loc,
+                                              const float* aw, void* gvalue, float* gloc, float* gaw, int B, int L, int M, int D, int Q,
+                                              int nl, int P, long long ldg, int dtype, void* stream) {
+  if (!gout || !value || !shapes_host || !loc || !aw || !gvalue || !gloc || !gaw || B <= 0 || L <= 0 || M <= 0 || D <= 0 ||
+      Q <= 0 || P <= 0 || ldg < (long long)M * D)
+    return TAMTR_EINVAL;
+  Levels lv;
+  if (!make_levels(shapes_host, nl, L, lv)) return TAMTR_EINVAL;
+  const long long n_items = (long long)B * Q * M;
+  if (n_items > (1ll << 30) || D > 256 || D % 8 || (long long)Q * P * 4 > MSDA_MAX_KEYS || M > 65535 || B > 65535 ||
+      (dtype != TAMTR_F32 && dtype != TAMTR_BF16) || (ldg % (dtype == TAMTR_BF16 ? 8 : 4)))
+    return TAMTR_EUNSUP;
+  SliceTab tab;
+  tab.first[0] = 0;
+  for (int l = 0; l < nl; ++l) {
+    const long long rows = (long long)lv.H[l] * lv.W[l];
+    if (rows >= (1ll << (32 - MSDA_IDX_BITS)) - 1) return TAMTR_EUNSUP;
+    tab.first[l + 1] = tab.first[l] + (int)((rows + MSDA_SLICE_ROWS - 1) / MSDA_SLICE_ROWS);
+  }
+  int NS = 64;
+  while (NS < Q * P * 4) NS <<= 1;
+  hipStream_t s = (hipStream_t)stream;
+  {  // d/d(loc), d/d(weight): the gather half of the old kernel
+#define GO(ET, LPG)                                                                                                       \
+  {                                                                                                                       \
+    const int per_blk = MSDA_THREADS / LPG;                                                                               \
+    dim3 grid((unsigned)((n_items + per_blk - 1) / per_blk));                                                             \
+    hipLaunchKernelGGL((msda_bwd_kernel<ET, LPG, false>), grid, dim3(MSDA_THREADS), 0, s, (const ET*)gout, (const ET*)value, loc, aw, \
+                       (float*)nullptr, gloc, gaw, lv, (int)n_items, L, M, D, Q, nl, P);                                  \
+  }
+#define PICK(ET)                                                                                           \
+  if (D <= 8) GO(ET, 8) else if (D <= 16) GO(ET, 16) else if (D <= 32) GO(ET, 32) else GO(ET, 64)
+    if (dtype == TAMTR_F32) { PICK(float) } else { PICK(bf16_t) }
+#undef PICK
+#undef GO
+  }
+  dim3 grid((unsigned)tab.first[nl], (unsigned)M, (unsigned)B);
+#define GO(ET, LPR)                                                                                                          \
+  hipLaunchKernelGGL((msda_gvalue_sorted_kernel<ET, LPR>), grid, dim3(MSDA_SORT_THREADS), 0, s, (const ET*)gout, loc, aw, (ET*)gvalue, lv, \
+                     tab, L, M, D, Q, nl, P, NS, ldg)
+#define PICK(ET)                                                                                                             \
+  if (D <= 8) GO(ET, 1); else if (D <= 16) GO(ET, 2); else if (D <= 32) GO(ET, 4); else if (D <= 64) GO(ET, 8);              \
+  else if (D <= 128) GO(ET, 16); else GO(ET, 32)
+  if (dtype == TAMTR_F32) { PICK(float); } else { PICK(bf16_t); }
 #undef PICK
 #undef GO
   return tamtr_launch_status();

@@ -463,10 +463,9 @@ template <bool VEC, int SETS>
 __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
     const float* __restrict__ gy, const float* __restrict__ u, const float* __restrict__ delta, const float* __restrict__ Am,
     const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ Dv, const float* __restrict__ dbias,
-    const float* __restrict__ hstate, float* __restrict__ gu, float* __restrict__ gdelta, float* __restrict__ gA,
-    float* __restrict__ wsB, float* __restrict__ wsC, float* __restrict__ gD, float* __restrict__ gdbias, int K, int Dk, int L,
-    int nchunk, size_t slab_elems, int xmode, const float* __restrict__ dtr, const float* __restrict__ Wdt, float* __restrict__ gWdt,
-    int R) {
+    const float* __restrict__ hstate, float* __restrict__ gu, float* __restrict__ gdelta, float* __restrict__ grow,
+    float* __restrict__ wsB, float* __restrict__ wsC, int K, int Dk, int L,
+    int nchunk, size_t slab_elems, int xmode, const float* __restrict__ dtr, const float* __restrict__ Wdt, int R) {
   constexpr bool DTR = SETS > 0;
   // one dynamic LDS array: B tile | C tile (the dB/dC fold tile aliases them) | rank-R dt factors | Wdt rows | per-row sums | carry
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -749,15 +748,12 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
     gu[18 + 4 * wg] = (float)(xcc & 0xf);
   }
 #endif
+  // the rows' sums over time - dA | d(Wdt) | dD, d(bias) - as they lie in LDS: one 256-byte row per (image, row), plain stores (every
+  // (b, kd) has exactly one writer); the caller adds the images in a fixed order (round 2 added them here with float atomics, whose
+  // order - and last bits - changed from run to run)
   for (int r = 0; r < BWD_RPW; ++r) {
     const int d = d0 + r, wr = wave * BWD_RPW + r;
-    if (d < Dk) {
-      const int kd = k * Dk + d;
-      const float* acc = s_acc + wr * ACC;
-      if (lane < NS) atomicAdd(gA + (size_t)kd * NS + lane, acc[lane]);  // summed over the batch only: no contention
-      if (lane == 0) { atomicAdd(gD + kd, acc[48]); atomicAdd(gdbias + kd, acc[49]); }
-      if (DTR && lane < R) atomicAdd(gWdt + (size_t)kd * R + lane, acc[16 + lane]);
-    }
+    if (d < Dk) grow[(((size_t)b * K + k) * Dk + d) * ACC + lane] = s_acc[wr * ACC + lane];
   }
 }
 
@@ -774,6 +770,18 @@ __global__ void slab_sum_kernel(const float* __restrict__ wsB, const float* __re
     }
     reinterpret_cast<float4*>(gB)[i] = sb;
     reinterpret_cast<float4*>(gC)[i] = sc;
+  }
+}
+
+// out[i] = sum_s ws[s][i], one array
+__global__ void slab_sum1_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t n4, int nslab) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nslab; ++s) {
+      const float4 b = reinterpret_cast<const float4*>(ws)[(size_t)s * n4 + i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = a;
   }
 }
 
@@ -794,7 +802,7 @@ __global__ __launch_bounds__(256) void dtproj_gdtr_scalar_kernel(const float* __
 
 template <int RT>
 __global__ __launch_bounds__(256) void dtproj_gdtr_kernel(const float* __restrict__ gdelta, const float* __restrict__ Wdt,
-                                                          float* __restrict__ gdtr, int K, int Dk, int R, int L) {
+                                                          float* __restrict__ gdtr, int K, int Dk, int R, int L, size_t zstride) {
   __shared__ float sW[64][RT];
   const int bk = blockIdx.y, k = bk % K;
   const int l0 = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -804,7 +812,8 @@ __global__ __launch_bounds__(256) void dtproj_gdtr_kernel(const float* __restric
   for (int r = 0; r < RT; ++r) acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f;
   const float* gp = gdelta + (size_t)bk * Dk * L;
   // gridDim.z > 1: the Dk rows are split over z (short sequences alone do not fill the chip: L = 1600 gives 2 x 64 workgroups);
-  // the slices are then combined with float atomics into a zeroed gdtr (<= 16 adders per element)
+  // slice z then writes its partial into slab z of `gdtr` (a workspace of gridDim.z slabs of zstride floats), summed afterwards in
+  // slab order by slab_sum1_kernel (round 2: float atomics into a zeroed gdtr)
   const int dper = ((Dk + (int)gridDim.z - 1) / (int)gridDim.z + 63) / 64 * 64;
   const int dbeg = blockIdx.z * dper, dend = min(Dk, dbeg + dper);
   for (int d0 = dbeg; d0 < dend; d0 += 64) {
@@ -831,9 +840,8 @@ __global__ __launch_bounds__(256) void dtproj_gdtr_kernel(const float* __restric
 #pragma unroll
     for (int r = 0; r < RT; ++r)
       if (r < R) {
-        float* o = gdtr + ((size_t)bk * R + r) * L + l0;
-        if (gridDim.z == 1) *reinterpret_cast<float4*>(o) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
-        else if (dbeg < dend) { atomicAdd(o, acc[r][0]); atomicAdd(o + 1, acc[r][1]); atomicAdd(o + 2, acc[r][2]); atomicAdd(o + 3, acc[r][3]); }
+        float* o = gdtr + (size_t)blockIdx.z * zstride + ((size_t)bk * R + r) * L + l0;
+        *reinterpret_cast<float4*>(o) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);   // (an empty slice stores zeros)
       }
   }
 }
@@ -880,34 +888,35 @@ extern "C" int tamtr_selective_scan_dtproj_fwd(const float* u, const float* dtr,
 
 static int scan_bwd_launch(const float* gy, const float* u, const float* delta, const float* dtr, const float* Wdt, int R,
                            const float* A, const float* Bm, const float* Cm, const float* D, const float* dbias, const float* hstate,
-                           float* gu, float* gdelta, float* gdtr, float* gWdt, float* gA, float* gB, float* gC, float* gD,
-                           float* gdbias, float* ws, int B, int K, int Dk, int N, int L, int xmode, void* stream);
+                           float* gu, float* gdelta, float* gdtr, float* grow, float* gB, float* gC, float* ws, int B, int K, int Dk,
+                           int N, int L, int xmode, void* stream);
+
+extern "C" int tamtr_selective_scan_row_sums(void) { return ACC; }
 
 extern "C" int tamtr_selective_scan_bwd(const float* gy, const float* u, const float* delta, const float* A, const float* Bm,
                                         const float* Cm, const float* D, const float* dbias, const float* hstate, float* gu,
-                                        float* gdelta, float* gA, float* gB, float* gC, float* gD, float* gdbias, float* ws, int B,
-                                        int K, int Dk, int N, int L, int xmode, void* stream) {
+                                        float* gdelta, float* grow, float* gB, float* gC, float* ws, int B, int K, int Dk, int N, int L,
+                                        int xmode, void* stream) {
   if (!delta) return TAMTR_EINVAL;
-  return scan_bwd_launch(gy, u, delta, nullptr, nullptr, 0, A, Bm, Cm, D, dbias, hstate, gu, gdelta, nullptr, nullptr, gA, gB, gC, gD,
-                         gdbias, ws, B, K, Dk, N, L, xmode, stream);
+  return scan_bwd_launch(gy, u, delta, nullptr, nullptr, 0, A, Bm, Cm, D, dbias, hstate, gu, gdelta, nullptr, grow, gB, gC, ws, B, K, Dk,
+                         N, L, xmode, stream);
 }
 
 extern "C" int tamtr_selective_scan_dtproj_bwd(const float* gy, const float* u, const float* dtr, const float* Wdt, const float* A,
                                                const float* Bm, const float* Cm, const float* D, const float* dbias,
-                                               const float* hstate, float* gu, float* gdelta_ws, float* gdtr, float* gWdt, float* gA,
-                                               float* gB, float* gC, float* gD, float* gdbias, float* ws, int B, int K, int Dk, int N,
-                                               int R, int L, int xmode, void* stream) {
-  if (!dtr || !Wdt || !gdtr || !gWdt) return TAMTR_EINVAL;
-  return scan_bwd_launch(gy, u, nullptr, dtr, Wdt, R, A, Bm, Cm, D, dbias, hstate, gu, gdelta_ws, gdtr, gWdt, gA, gB, gC, gD, gdbias, ws,
-                         B, K, Dk, N, L, xmode, stream);
+                                               const float* hstate, float* gu, float* gdelta_ws, float* gdtr, float* grow, float* gB,
+                                               float* gC, float* ws, int B, int K, int Dk, int N, int R, int L, int xmode, void* stream) {
+  if (!dtr || !Wdt || !gdtr) return TAMTR_EINVAL;
+  return scan_bwd_launch(gy, u, nullptr, dtr, Wdt, R, A, Bm, Cm, D, dbias, hstate, gu, gdelta_ws, gdtr, grow, gB, gC, ws, B, K, Dk, N, L,
+                         xmode, stream);
 }
 
 static int scan_bwd_launch(const float* gy, const float* u, const float* delta, const float* dtr, const float* Wdt, int R,
                            const float* A, const float* Bm, const float* Cm, const float* D, const float* dbias, const float* hstate,
-                           float* gu, float* gdelta, float* gdtr, float* gWdt, float* gA, float* gB, float* gC, float* gD,
-                           float* gdbias, float* ws, int B, int K, int Dk, int N, int L, int xmode, void* stream) {
-  if (!gy || !u || (!delta && !dtr) || !A || !Bm || !Cm || !D || !dbias || !hstate || !gu || !gdelta || !gA || !gB || !gC || !gD ||
-      !gdbias || !ws || B <= 0 || K <= 0 || Dk <= 0 || L <= 0)
+                           float* gu, float* gdelta, float* gdtr, float* grow, float* gB, float* gC, float* ws, int B, int K, int Dk,
+                           int N, int L, int xmode, void* stream) {
+  if (!gy || !u || (!delta && !dtr) || !A || !Bm || !Cm || !D || !dbias || !hstate || !gu || !gdelta || !grow || !gB || !gC || !ws ||
+      B <= 0 || K <= 0 || Dk <= 0 || L <= 0)
     return TAMTR_EINVAL;
   if (xmode != 0 && xmode != 1 && xmode != 3) return TAMTR_EINVAL;
   if (N != NS || (long long)B * K > 65535 || (xmode && K != 4) || (dtr && (R < 1 || R > RMAX))) return TAMTR_EUNSUP;
@@ -923,28 +932,37 @@ static int scan_bwd_launch(const float* gy, const float* u, const float* delta, 
   const size_t dyn = ((size_t)2 * NS * CHUNK + (size_t)R * CHUNK + (size_t)BWD_ROWS * (RMAX + ACC + NS)) * sizeof(float);
 #define LAUNCH_BWD(VEC, SETS)                                                                                                          \
   hipLaunchKernelGGL((selscan_bwd_kernel<VEC, SETS>), grid, dim3(BWD_WAVES * WAVE), dyn, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu, \
-                     gdelta, gA, wsB, wsC, gD, gdbias, K, Dk, L, nchunk, slab, xmode, dtr, Wdt, gWdt, R)
+                     gdelta, grow, wsB, wsC, K, Dk, L, nchunk, slab, xmode, dtr, Wdt, R)
   if (L % 4 == 0) {
     if (R == 0) LAUNCH_BWD(true, 0); else if (R <= 16) LAUNCH_BWD(true, 1); else LAUNCH_BWD(true, 2);
   } else {
     if (R == 0) LAUNCH_BWD(false, 0); else if (R <= 16) LAUNCH_BWD(false, 1); else LAUNCH_BWD(false, 2);
   }
 #undef LAUNCH_BWD
+  // dB / dC: the workgroups' slabs added in slab order (this also frees the workspace for the split gdtr product below)
+  const size_t n4 = slab / 4;  // N = 16 makes slab a multiple of 4
+  const unsigned blocks = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, s, wsB, wsC, gB, gC, n4, nslab);
   if (dtr && L % 4) {
     hipLaunchKernelGGL(dtproj_gdtr_scalar_kernel, dim3((L + 255) / 256, B * K), dim3(256), 0, s, gdelta, Wdt, gdtr, K, Dk, R, L);
   } else if (dtr) {  // gdtr = Wdt^T gdelta (position space, un-reversed)
     dim3 g2((L / 4 + 255) / 256, B * K);
     const int wgs = (int)g2.x * B * K;
-    if (wgs < 768 && Dk >= 128) {  // not enough workgroups for 256 CUs: split the rows, combine with atomics
+    const size_t gsz = (size_t)B * K * R * L;
+    float* out = gdtr;
+    if (wgs < 768 && Dk >= 128) {  // not enough workgroups for 256 CUs: split the rows over z, one partial slab per slice in the
+      // (now free) dB/dC workspace - z * R <= (Dk / 64) * 32 <= 2 * nslab * 16 floats per position, so it fits
       g2.z = (unsigned)min(Dk / 64, (1024 + wgs - 1) / wgs);
-      (void)hipMemsetAsync(gdtr, 0, (size_t)B * K * R * L * sizeof(float), s);
+      if (g2.z > 1) out = ws;
     }
-    if (R <= 8) hipLaunchKernelGGL(dtproj_gdtr_kernel<8>, g2, dim3(256), 0, s, gdelta, Wdt, gdtr, K, Dk, R, L);
-    else if (R <= 16) hipLaunchKernelGGL(dtproj_gdtr_kernel<16>, g2, dim3(256), 0, s, gdelta, Wdt, gdtr, K, Dk, R, L);
-    else hipLaunchKernelGGL(dtproj_gdtr_kernel<32>, g2, dim3(256), 0, s, gdelta, Wdt, gdtr, K, Dk, R, L);
+    if (R <= 8) hipLaunchKernelGGL(dtproj_gdtr_kernel<8>, g2, dim3(256), 0, s, gdelta, Wdt, out, K, Dk, R, L, gsz);
+    else if (R <= 16) hipLaunchKernelGGL(dtproj_gdtr_kernel<16>, g2, dim3(256), 0, s, gdelta, Wdt, out, K, Dk, R, L, gsz);
+    else hipLaunchKernelGGL(dtproj_gdtr_kernel<32>, g2, dim3(256), 0, s, gdelta, Wdt, out, K, Dk, R, L, gsz);
+    if (out != gdtr) {
+      const size_t m4 = gsz / 4;  // L % 4 == 0 here
+      const unsigned bl = (unsigned)((m4 + 255) / 256 < 4096 ? (m4 + 255) / 256 : 4096);
+      hipLaunchKernelGGL(slab_sum1_kernel, dim3(bl), dim3(256), 0, s, ws, gdtr, m4, (int)g2.z);
+    }
   }
-  const size_t n4 = slab / 4;  // N = 16 makes slab a multiple of 4
-  const unsigned blocks = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-  hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, s, wsB, wsC, gB, gC, n4, nslab);
   return tamtr_launch_status();
 }

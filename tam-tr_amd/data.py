@@ -557,9 +557,10 @@ def seed_worker(worker_id):
     random.seed(seed)
 
 
-def build_dataloader(dataset, batch, workers=4, shuffle=True, rank=-1):
+def build_dataloader(dataset, batch, workers=4, shuffle=True, rank=-1, drop_last=False):
     """torch DataLoader with the reference's conventions: DistributedSampler when ranked, fixed generator seed + rank, workers
-    re-seeded from torch's per-worker seed, pinned batches."""
+    re-seeded from torch's per-worker seed, pinned batches.  drop_last (not in the reference, default off): leave out an epoch's
+    incomplete tail batch - a shape of its own, i.e. a MIOpen search of its own and an eager (un-replayed) step."""
     batch = min(batch, len(dataset))
     nw = min(os.cpu_count() // max(torch.cuda.device_count(), 1), batch if batch > 1 else 0, workers)
     sampler = None if rank == -1 else torch.utils.data.distributed.DistributedSampler(dataset, shuffle=shuffle)
@@ -567,7 +568,7 @@ def build_dataloader(dataset, batch, workers=4, shuffle=True, rank=-1):
     gen.manual_seed(6148914691236517205 + max(rank, -1))
     return torch.utils.data.DataLoader(dataset, batch_size=batch, shuffle=shuffle and sampler is None, num_workers=nw, sampler=sampler,
                                        pin_memory=torch.cuda.is_available(), collate_fn=collate, worker_init_fn=seed_worker,
-                                       generator=gen, persistent_workers=nw > 0)
+                                       generator=gen, persistent_workers=nw > 0, drop_last=drop_last)
 
 
 def reset_workers(loader):

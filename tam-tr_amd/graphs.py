@@ -134,7 +134,7 @@ class GraphedPart:
         worst_noise = max([noise_out] + noise)
         res = {'grads': len(live), 'eager_noise_out': noise_out, 'eager_noise_grad_max': max(noise) if noise else 0.0, 'replays': []}
         ok = True
-        bound = max(tol, noise_factor * worst_noise)
+        bound = min(max(tol, noise_factor * worst_noise), 0.25)   # (a replay that went wrong is off by > 1 or NaN)
         for rep in range(replays):
             self._restore_buffers(saved)
             self.static_gout.copy_(cot)

@@ -220,9 +220,9 @@ class RTDETRDetectionWorldModel(nn.Module):
             txt = txt.repeat(len(img), 1, 1)
         saved = [b.detach().clone() for b in part.buffers()]
         head = self.model[-1]
-        with torch.no_grad():
-            _, shapes = self.token_memory(img, txt)  # the level shapes
         dp = torch.ones(head.num_Blocks, 2, len(img), device=img.device)
+        with torch.no_grad():
+            _, shapes = self.token_memory(img, txt, drop_scales=dp)  # the level shapes (DropPath factors given: nothing is drawn)
         graphed = GraphedPart(part, (img.detach(), txt.detach(), dp), warmup=warmup)
         try:
             self.static_part_check = graphed.verify() if verify else None

@@ -319,6 +319,22 @@ def maxsigmoid_gate(x, gk, bias, v, nh, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------------------ a-6 deformable core
+import os as _os
+
+_MSDA_ATOMICS = _os.environ.get('TAMTR_MSDA_ATOMICS') == '1'   # A/B switch: the round-1/2 float-atomic scatter
+
+
+def deterministic():
+    """TAMTR_DETERMINISTIC=1 or torch.use_deterministic_algorithms(True): the reference's `deterministic: True`
+    (cfg/default.yaml:26, utils/torch_utils.py:371-389).  Kernels of this package are order-fixed by construction; the switch makes
+    the few paths that would fall back to an atomic kernel raise instead, and tuning.py keeps MIOpen off its split-K solvers."""
+    return _os.environ.get('TAMTR_DETERMINISTIC') == '1' or torch.are_deterministic_algorithms_enabled()
+
+
+def msda_sorted_ok(Q, P, D):
+    return Q * P * 4 <= 8192 and D % 8 == 0 and D <= 256
+
+
 class _MSDeformCore(torch.autograd.Function):
     @staticmethod
     def forward(ctx, value, shapes, loc, aw):
@@ -342,9 +358,19 @@ class _MSDeformCore(torch.autograd.Function):
         B, L, M, D = value.shape
         Q = loc32.shape[1]
         gout = _c(gout.to(value.dtype))
-        gvalue = torch.zeros(B, L, M, D, device=value.device, dtype=torch.float32)  # float-atomic accumulator
         gloc = torch.empty_like(loc32)
         gaw = torch.empty_like(aw32)
+        if msda_sorted_ok(Q, P, D) and not _MSDA_ATOMICS:
+            # ordered segmented sum (csrc/msdeform.hip): every element of the value gradient written once, in the value's dtype -
+            # no 1.1 GB fp32 zero fill, no float atomics, no cast pass, and the same bits on every run
+            gvalue = torch.empty(B, L, M, D, device=value.device, dtype=value.dtype)
+            call('tamtr_msdeform_attn_bwd_sorted', ptr(gout), ptr(value), ctypes.cast(sh, ctypes.c_void_p), ptr(loc32), ptr(aw32),
+                 ptr(gvalue), ptr(gloc), ptr(gaw), B, L, M, D, Q, nl, P, M * D, dtype_code(value), stream_ptr())
+            return gvalue, None, gloc.to(loc_dt), gaw.to(aw_dt)
+        if deterministic():
+            raise _lib.TamtrHipError(f'deterministic mode: the deformable-attention backward has no atomics-free kernel for Q*P*4 = {Q * P * 4} > 8192 '
+                                     f'corners per level or D = {D} (csrc/msdeform.hip)')
+        gvalue = torch.zeros(B, L, M, D, device=value.device, dtype=torch.float32)  # float-atomic accumulator
         call('tamtr_msdeform_attn_bwd', ptr(gout), ptr(value), ctypes.cast(sh, ctypes.c_void_p), ptr(loc32), ptr(aw32),
              ptr(gvalue), ptr(gloc), ptr(gaw), B, L, M, D, Q, nl, P, dtype_code(value), stream_ptr())
         return gvalue.to(value.dtype), None, gloc.to(loc_dt), gaw.to(aw_dt)
@@ -382,9 +408,13 @@ class _ContrastiveLogits(torch.autograd.Function):
         K = w32.shape[1]
         g = _c(g.float())
         dx = torch.empty_like(x)
-        dwhat = torch.zeros(B, K, C, device=x.device, dtype=torch.float32)
+        if K > 16 and deterministic():
+            raise _lib.TamtrHipError(f'deterministic mode: the contrastive head backward sums d(what) with LDS atomics for K = {K} > 16 prompts')
+        slabs = _lib.lib().tamtr_contrastive_bwd_slabs(Q)   # per-workgroup partials of d(what), added below in a fixed order
+        dwhat = torch.empty(B, slabs, K, C, device=x.device, dtype=torch.float32)
         call('tamtr_contrastive_logits_bwd', ptr(g), ptr(x), ptr(w32), ptr(ls), ptr(xinv), ptr(winv), ptr(dx), ptr(dwhat), B, Q, K,
              C, dtype_code(x), stream_ptr())
+        dwhat = dwhat.sum(1) if slabs > 1 else dwhat[:, 0]
         what = w32 * winv.unsqueeze(-1)
         dw = winv.unsqueeze(-1) * (dwhat - (dwhat * what).sum(-1, keepdim=True) * what)
         dls = (g * (logits - bi)).sum().reshape(ls_shape).to(ls_dt)
@@ -658,6 +688,18 @@ def self_attention(q, k, v, nh, attn_mask=None):
 
 
 # ------------------------------------------------------------------------------------------------ a-9 selective scan
+def _scan_row_sums(Bn, KD, device):
+    """Workspace of the scan backward's per-(image, row) sums over time (include/tamtr_hip.h: grow)."""
+    return torch.empty(Bn, KD, _lib.lib().tamtr_selective_scan_row_sums(), device=device, dtype=torch.float32)
+
+
+def _split_row_sums(grow, R):
+    """Add the images (a fixed-order reduction: no float atomics, bitwise reproducible) and cut the row into d(Wdt) [KD, R], dA [KD, 16],
+    dD [KD], d(bias) [KD]."""
+    rs = grow.sum(0)
+    return rs[:, 16:16 + R], rs[:, :16], rs[:, 48], rs[:, 49]
+
+
 class _SelectiveScan(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, delta, A, Bm, Cm, D, dbias, xmode):
@@ -682,12 +724,13 @@ class _SelectiveScan(torch.autograd.Function):
         K, N = Bm.shape[1], Bm.shape[2]
         gy = _c(gy.float())
         gu, gdelta = torch.empty_like(delta), torch.empty_like(delta)
-        gA, gB, gC = torch.zeros_like(A), torch.empty_like(Bm), torch.empty_like(Cm)
-        gD, gbias = torch.zeros_like(D), torch.zeros_like(dbias)
+        gB, gC = torch.empty_like(Bm), torch.empty_like(Cm)
+        grow = _scan_row_sums(Bn, KD, u.device)
         nslab = _lib.lib().tamtr_selective_scan_bwd_slabs(KD // K)
         ws = torch.empty(2 * nslab * Bm.numel(), device=u.device, dtype=torch.float32)  # per-workgroup dB/dC slabs
         call('tamtr_selective_scan_bwd', ptr(gy), ptr(u), ptr(delta), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(dbias), ptr(hstate), ptr(gu),
-             ptr(gdelta), ptr(gA), ptr(gB), ptr(gC), ptr(gD), ptr(gbias), ptr(ws), Bn, K, KD // K, N, L, ctx.xmode, stream_ptr())
+             ptr(gdelta), ptr(grow), ptr(gB), ptr(gC), ptr(ws), Bn, K, KD // K, N, L, ctx.xmode, stream_ptr())
+        _, gA, gD, gbias = _split_row_sums(grow, 0)
         if ctx.xmode:  # [B, 4*Dk, L] per direction (un-reversed) -> gradient of the two stored copies [B, 2, Dk, L]
             g4 = gu.view(Bn, 4, KD // 4, L)
             gu = g4[:, :2] + g4[:, 2:]
@@ -732,14 +775,14 @@ class _SelectiveScanDtProj(torch.autograd.Function):
         gu = torch.empty(Bn, KD, L, device=u.device, dtype=torch.float32)
         gdelta = torch.empty(Bn, KD, L, device=u.device, dtype=torch.float32)  # workspace between the two backward kernels
         gdtr = torch.empty_like(dtr)
-        gW, gA = torch.zeros_like(Wdt), torch.zeros_like(A)
         gB, gC = torch.empty_like(Bm), torch.empty_like(Cm)
-        gD, gbias = torch.zeros_like(D), torch.zeros_like(dbias)
+        grow = _scan_row_sums(Bn, KD, dtr.device)
         nslab = _lib.lib().tamtr_selective_scan_bwd_slabs(KD // K)
         ws = torch.empty(2 * nslab * Bm.numel(), device=u.device, dtype=torch.float32)
         call('tamtr_selective_scan_dtproj_bwd', ptr(gy), ptr(u), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(dbias),
-             ptr(hstate), ptr(gu), ptr(gdelta), ptr(gdtr), ptr(gW), ptr(gA), ptr(gB), ptr(gC), ptr(gD), ptr(gbias), ptr(ws), Bn, K,
+             ptr(hstate), ptr(gu), ptr(gdelta), ptr(gdtr), ptr(grow), ptr(gB), ptr(gC), ptr(ws), Bn, K,
              KD // K, N, R, L, ctx.xmode, stream_ptr())
+        gW, gA, gD, gbias = _split_row_sums(grow, R)
         if ctx.xmode:
             g4 = gu.view(Bn, 4, KD // 4, L)
             gu = g4[:, :2] + g4[:, 2:]
@@ -906,14 +949,14 @@ class _SelectiveScanCrossMerged(torch.autograd.Function):
         gu = torch.empty(Bn, KD, L, device=u2.device, dtype=torch.float32)
         gdelta = torch.empty(Bn, KD, L, device=u2.device, dtype=torch.float32)
         gdtr = torch.empty_like(dtr)
-        gW, gA = torch.zeros_like(Wdt), torch.zeros_like(A)
         gB, gC = torch.empty_like(Bm), torch.empty_like(Cm)
-        gD, gbias = torch.zeros_like(D), torch.zeros_like(dbias)
+        grow = _scan_row_sums(Bn, KD, dtr.device)
         nslab = _lib.lib().tamtr_selective_scan_bwd_slabs(Dk)
         ws = torch.empty(2 * nslab * Bm.numel(), device=u2.device, dtype=torch.float32)
         call('tamtr_selective_scan_dtproj_bwd', ptr(g2), ptr(u2), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(dbias),
-             ptr(hstate), ptr(gu), ptr(gdelta), ptr(gdtr), ptr(gW), ptr(gA), ptr(gB), ptr(gC), ptr(gD), ptr(gbias), ptr(ws), Bn, K,
+             ptr(hstate), ptr(gu), ptr(gdelta), ptr(gdtr), ptr(grow), ptr(gB), ptr(gC), ptr(ws), Bn, K,
              Dk, N, R, L, 3, stream_ptr())
+        gW, gA, gD, gbias = _split_row_sums(grow, R)
         g4 = gu.view(Bn, 4, Dk, L)
         return g4[:, :2] + g4[:, 2:], gdtr, gW, gA, gB, gC, gD, gbias, None, None, None
 
@@ -1038,14 +1081,14 @@ class _SS2DCore(torch.autograd.Function):
         gu = torch.empty(B, K * D, L, device=dev, dtype=torch.float32)
         gdelta = torch.empty(B, K * D, L, device=dev, dtype=torch.float32)
         gdtr = torch.empty_like(dtr)
-        gW, gA = torch.zeros_like(Wdt32), torch.zeros_like(A32)
         gB, gC = torch.empty_like(Bs), torch.empty_like(Cs)
-        gD, gdb = torch.zeros_like(D32), torch.zeros_like(db32)
+        grow = _scan_row_sums(B, K * D, dev)
         nslab = _lib.lib().tamtr_selective_scan_bwd_slabs(D)
         ws = torch.empty(2 * nslab * Bs.numel(), device=dev, dtype=torch.float32)
         call('tamtr_selective_scan_dtproj_bwd', ptr(g2), ptr(u2), ptr(dtr), ptr(Wdt32), ptr(A32), ptr(Bs), ptr(Cs), ptr(D32), ptr(db32),
-             ptr(hstate), ptr(gu), ptr(gdelta), ptr(gdtr), ptr(gW), ptr(gA), ptr(gB), ptr(gC), ptr(gD), ptr(gdb), ptr(ws), B, K, D, N, R, L,
+             ptr(hstate), ptr(gu), ptr(gdelta), ptr(gdtr), ptr(grow), ptr(gB), ptr(gC), ptr(ws), B, K, D, N, R, L,
              3, stream_ptr())
+        gW, gA, gD, gdb = _split_row_sums(grow, R)
         del gdelta, ws, g2
         # x_proj backward: per copy one [D, 2C] x [2C, L] product and the weight gradient as a batched GEMM over L slices
         cdt = ub.dtype

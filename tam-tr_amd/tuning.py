@@ -4,8 +4,9 @@ Out of the box PyTorch asks MIOpen for its *heuristic* solver per convolution.  
 640 px / 16 images that choice leans on split-K implicit-GEMM kernels wrapped in zero-fill and cast kernels (589 launches, 5 ms per
 step) and costs 10 ms per step against what MIOpen's own timed search picks (105.8 -> 95.6 ms per step).  The search takes ~4
 minutes on a fresh machine, so its result - MIOpen's text find-db / perf-db, 130 KB - is shipped under tuned/miopen/ and handed to
-MIOpen through MIOPEN_USER_DB_PATH (a writable copy: MIOpen locks and appends to it).  Shapes that are not in the table are searched
-once and added to the copy.
+MIOpen through MIOPEN_USER_DB_PATH (a writable copy in a persistent per-user, per-MIOpen-build directory: MIOpen locks and appends
+to it).  Shapes that are not in the table are searched once per machine and kept there.  The training loader drops the tail batch
+(data.build_dataloader(drop_last=...)) so that the one uncovered training shape does not occur.
 """
 import glob
 import json
@@ -28,14 +29,62 @@ def shipped_db_matches():
             and meta.get('hip') == torch.version.hip)
 
 
-def use_tuned_convolutions(mode='shipped', db_dir=None):
+def _user_db_dir():
+    """A PERSISTENT per-user directory for MIOpen's writable tables, one per MIOpen / HIP build: what a run has to search (a tail
+    batch, the validation batch size, another image size) is searched once per machine, not once per run, and nothing is left behind in
+    /tmp.  TAMTR_MIOPEN_DB_DIR overrides the place; an unwritable home falls back to a temporary directory removed at exit."""
+    tag = f'miopen-{torch.backends.cudnn.version()}-hip-{torch.version.hip}'
+    base = os.environ.get('TAMTR_MIOPEN_DB_DIR') or os.path.join(os.environ.get('XDG_CACHE_HOME') or os.path.join(os.path.expanduser('~'), '.cache'),
+                                                                 'tamtr_amd')
+    path = os.path.join(base, tag)
+    try:
+        os.makedirs(path, exist_ok=True)
+        probe = os.path.join(path, f'.w{os.getpid()}')
+        open(probe, 'w').close()
+        os.remove(probe)
+        return path, True
+    except OSError:
+        import atexit
+        tmp = tempfile.mkdtemp(prefix='tamtr_miopen_')
+        atexit.register(shutil.rmtree, tmp, ignore_errors=True)
+        return tmp, False
+
+
+def _seed(dst):
+    """Copy the shipped tables into dst unless it already holds them (MIOpen appends its own finds to these files: never overwrite a
+    file that has grown).  Ranks of one job race here harmlessly: the copy goes through a temporary name + rename."""
+    for f in glob.glob(os.path.join(_DIR, '*.txt')):
+        to = os.path.join(dst, os.path.basename(f))
+        if os.path.exists(to) and os.path.getsize(to) >= os.path.getsize(f):
+            continue
+        tmp = f'{to}.{os.getpid()}.tmp'
+        shutil.copy(f, tmp)
+        os.replace(tmp, to)
+
+
+def use_deterministic_convolutions():
+    """The reference's `deterministic: True` (cfg/default.yaml:26 -> utils/torch_utils.py:371-389: cudnn.deterministic +
+    use_deterministic_algorithms(warn_only)) for the MIOpen part of the step: ATen sets MIOpen's DETERMINISTIC convolution attribute,
+    under which the split-K / atomic-add solvers are not applicable; no timed search and no tables (the shipped tables were chosen
+    with those solvers allowed), i.e. MIOpen's heuristic among the deterministic solvers.  Call before the first convolution."""
+    os.environ['MIOPEN_DEBUG_CONVOLUTION_DETERMINISTIC'] = '1'
+    torch.backends.cudnn.deterministic = True
+    torch.backends.cudnn.benchmark = False
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    return 'deterministic (MIOpen heuristic restricted to deterministic solvers)'
+
+
+def use_tuned_convolutions(mode='shipped', db_dir=None, log=None):
     """Call before the first convolution.  mode: 'shipped' - timed-search mode backed by the shipped tables if they match this
     MIOpen build, else MIOpen's default heuristic; 'search' - timed search into db_dir (slow first run; how the tables are made);
-    'off' - default heuristic.  Returns what was set up, for logs."""
+    'off' - default heuristic.  TAMTR_DETERMINISTIC=1 overrides all of them with use_deterministic_convolutions().
+    Returns what was set up, for logs."""
+    if os.environ.get('TAMTR_DETERMINISTIC') == '1':
+        return use_deterministic_convolutions()
     if mode == 'off':
         return 'off (MIOpen heuristic)'
     if mode == 'search':
-        db_dir = db_dir or tempfile.mkdtemp(prefix='tamtr_miopen_')
+        db_dir = db_dir or _user_db_dir()[0]
         os.makedirs(db_dir, exist_ok=True)
         os.environ['MIOPEN_USER_DB_PATH'] = db_dir
         torch.backends.cudnn.benchmark = True
@@ -44,9 +93,12 @@ def use_tuned_convolutions(mode='shipped', db_dir=None):
         raise ValueError(mode)
     if not shipped_db_matches():
         return 'off (shipped tables are for another MIOpen build)'
-    work = tempfile.mkdtemp(prefix='tamtr_miopen_')
-    for f in glob.glob(os.path.join(_DIR, '*.txt')):
-        shutil.copy(f, work)
+    work, persistent = _user_db_dir()
+    _seed(work)
     os.environ['MIOPEN_USER_DB_PATH'] = work
     torch.backends.cudnn.benchmark = True
+    if log:
+        log(f'convolutions: MIOpen timed search backed by the shipped tables (640 px / 16 images, 1280 px / 8 images) in {work}'
+            f'{"" if persistent else " (temporary)"}; a shape outside them - a tail batch, the validation batch - is searched once (minutes) '
+            'and kept there')
     return 'shipped tables'

@@ -164,10 +164,11 @@ def test_full_model_640_fp32_vs_oracle(pkg, case640, mode):
 # rounding measure: a 2 % logit change moves a few of the 100 top-k picks and Hungarian pairs, i.e. discrete flips (measured
 # 1e-2 .. 8e-1 per term: the NCHW trunk gave 7.7e-2 / loss 4.9e-3, the NHWC trunk - same arithmetic, another summation order in
 # BatchNorm - 8.2e-1 on the last layer's class term / loss 1.6e-2).
-# The matched-query terms are recorded but NOT bounded: across runs of identical code (float atomics in the gather backward and MIOpen's
+# The rounding of the matched-query terms IS bounded - with the discrete choices held fixed, in
+# test_full_model_640_bf16_rounding_with_the_oracles_choices above.  In this free-running comparison they are recorded but NOT bounded: across runs of identical code (float atomics in the gather backward and MIOpen's
 # split-K sums make the last bits run-to-run dependent, which moves top-k picks and Hungarian pairs) the last layer's class term landed
 # anywhere between 9e-3 and 1.13 relative, while the denoising terms - fixed query-to-box assignment, i.e. pure rounding - stay within 1.5e-2.
-BF16_BOUNDS = {'loss_rel': 1e-1, 'dn_term_rel_max': 4e-2, 'dn_box_abs_max': 4e-2, 'dn_box_abs_mean': 4e-3,
+BF16_BOUNDS = {'loss_rel': 7.5e-2, 'dn_term_rel_max': 4e-2, 'dn_box_abs_max': 4e-2, 'dn_box_abs_mean': 4e-3,
                'dn_cls_logit_abs_max': 4.0, 'dn_cls_logit_abs_mean': 0.5}
 
 
@@ -187,8 +188,10 @@ def test_full_model_640_fp32_elementwise_with_the_oracles_choices(pkg, case640):
 
 # bf16 ROUNDING of every term, the discrete choices held fixed (the oracle's): ~3x the values measured on MI355X
 # (profiles/r03_bf16_error_640.json).
-BF16_FORCED_BOUNDS = {'loss_rel': 5e-2, 'term_rel_max': 1.5e-1, 'box_abs_max': 8e-2, 'box_abs_mean': 8e-3, 'cls_logit_abs_max': 6.0,
-                      'cls_logit_abs_mean': 0.8}
+# Measured (eager / graph): loss 5.2e-2 / 5.2e-2; worst term 7.3e-2 (loss_class_aux: the VFL weights carry the IoU of the matched boxes);
+# boxes 3.0e-2 / 2.4e-2 max, 1.3e-3 mean (sigmoid space); class logits 1.8 / 2.4 max, 0.18 mean on a scale of 10; encoder scores 3.1 max.
+BF16_FORCED_BOUNDS = {'loss_rel': 1.2e-1, 'term_rel_max': 2e-1, 'box_abs_max': 8e-2, 'box_abs_mean': 4e-3, 'cls_logit_abs_max': 6.0,
+                      'cls_logit_abs_mean': 0.5}
 
 
 @pytest.mark.parametrize('mode', ['eager', 'graph'])
@@ -234,6 +237,90 @@ def test_full_model_640_bf16_error_is_measured_and_bounded(pkg, case640):
     _record('bf16_error_640.json', rec)
     for k, bound in BF16_BOUNDS.items():
         assert rec[k] <= bound, (k, rec[k], bound)
+
+
+# ------------------------------------------------------------------------------------------------ deterministic mode
+@pytest.mark.parametrize('dtype', [None, torch.bfloat16])
+def test_deterministic_mode_two_steps_are_bit_identical(pkg, case640, dtype):
+    """The reference trains with deterministic=True (cfg/default.yaml:26, utils/torch_utils.py:371-389).  Here: no kernel of the package
+    adds floats in a run-dependent order (the deformable backward sums sorted runs, the scan and the contrastive head store per-image /
+    per-workgroup partials), and tuning.use_deterministic_convolutions() keeps MIOpen on its deterministic solvers.  Two consecutive
+    training steps at 640 x 640 from the same state must then give the same bits: loss, the 12 terms and all 552 gradients."""
+    import warnings
+    from tamtr_amd import tuning
+    c = case640
+    model = c['model']
+    keep = (torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark, torch.are_deterministic_algorithms_enabled(),
+            torch.is_deterministic_algorithms_warn_only_enabled())
+    b = {k: dev(v) for k, v in c['batch'].items()}
+    try:
+        tuning.use_deterministic_convolutions()
+        model.autocast_dtype = dtype
+        runs = []
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter('always')
+            for rep in range(2):
+                model.load_state_dict(c['state'])
+                model.train()
+                model.zero_grad(set_to_none=True)
+                torch.manual_seed(5)
+                loss, items = model(b)
+                loss.backward()
+                runs.append((loss.detach().clone(), {k: v.clone() for k, v in model.last_loss_terms.items()},
+                             {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+        nondet = sorted({str(w.message).split('.')[0][:160] for w in caught if 'deterministic' in str(w.message)})
+        print('ops torch flags as nondeterministic:', nondet)
+        (l0, t0, g0), (l1, t1, g1) = runs
+        assert len(g0) == 552 and set(g0) == set(g1)
+        assert torch.equal(l0, l1), (float(l0), float(l1))
+        assert all(torch.equal(t0[k], t1[k]) for k in t0), {k: (float(t0[k]), float(t1[k])) for k in t0 if not torch.equal(t0[k], t1[k])}
+        diff = {k: float((g0[k].float() - g1[k].float()).abs().max()) for k in g0 if not torch.equal(g0[k], g1[k])}
+        assert not diff, (len(diff), sorted(diff.items(), key=lambda kv: -kv[1])[:8])
+        assert not nondet, nondet
+    finally:
+        model.autocast_dtype = None
+        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = keep[0], keep[1]
+        torch.use_deterministic_algorithms(keep[2], warn_only=keep[3])
+        os.environ.pop('MIOPEN_DEBUG_CONVOLUTION_DETERMINISTIC', None)
+
+
+def test_msdeform_backward_is_bit_reproducible_and_matches_the_atomic_kernel(pkg):
+    """tamtr_msdeform_attn_bwd_sorted at the bench shape (16 images, L = 33 600, Q = 292): the same bits on every call, and the same
+    gradient as the float-atomic scatter it replaces (tamtr_msdeform_attn_bwd, still exported) to accumulation-order noise; clustered
+    sampling points (many corners on ONE row) and points off the map included."""
+    import ctypes
+    from tamtr_amd import _lib
+    B, Q, M, Dh = 16, 292, 8, 64
+    shapes = [(160, 160), (80, 80), (40, 40)]
+    L = sum(h * w for h, w in shapes)
+    g = torch.Generator(device='cuda').manual_seed(3)
+    value = torch.randn(B, L, M, Dh, device='cuda', generator=g).bfloat16()
+    loc = torch.rand(B, Q, M, 3, 4, 2, device='cuda', generator=g) * 1.1 - 0.05
+    loc[:, :40] = 0.5 + 0.002 * torch.randn(B, 40, M, 3, 4, 2, device='cuda', generator=g)    # 40 queries piled on the map centre
+    aw = torch.softmax(torch.randn(B, Q, M, 12, device='cuda', generator=g), -1).view(B, Q, M, 3, 4)
+    gout = torch.randn(B, Q, M * Dh, device='cuda', generator=g).bfloat16()
+    sh = (ctypes.c_int32 * 6)(*[v for hw in shapes for v in hw])
+    P = _lib.ptr
+
+    def sorted_bwd():
+        gv, gl, ga = torch.empty_like(value), torch.empty_like(loc), torch.empty_like(aw)
+        _lib.call('tamtr_msdeform_attn_bwd_sorted', P(gout), P(value), ctypes.cast(sh, ctypes.c_void_p), P(loc), P(aw), P(gv), P(gl), P(ga),
+                  B, L, M, Dh, Q, 3, 4, M * Dh, _lib.BF16, _lib.stream_ptr())
+        return gv, gl, ga
+    a, b = sorted_bwd(), sorted_bwd()
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    gv32 = torch.zeros(B, L, M, Dh, device='cuda')
+    gl2, ga2 = torch.empty_like(loc), torch.empty_like(aw)
+    _lib.call('tamtr_msdeform_attn_bwd', P(gout), P(value), ctypes.cast(sh, ctypes.c_void_p), P(loc), P(aw), P(gv32), P(gl2), P(ga2),
+              B, L, M, Dh, Q, 3, 4, _lib.BF16, _lib.stream_ptr())
+    assert torch.equal(a[1], gl2) and torch.equal(a[2], ga2)            # the gather half is the same code
+    scale = float(gv32.abs().max())
+    assert_close(a[0].float(), gv32, 2 ** -7, 2e-3 * scale, 'sorted vs atomic g_value (bf16 store)')
+    assert float((a[0].float() != 0).float().mean()) < 0.6              # most rows are never sampled: written as zeros, not left unwritten
+    stale = torch.full_like(value, float('nan'))
+    _lib.call('tamtr_msdeform_attn_bwd_sorted', P(gout), P(value), ctypes.cast(sh, ctypes.c_void_p), P(loc), P(aw), P(stale), P(gl2), P(ga2),
+              B, L, M, Dh, Q, 3, 4, M * Dh, _lib.BF16, _lib.stream_ptr())
+    assert torch.isfinite(stale.float()).all() and torch.equal(stale, a[0])   # every element written, whatever was there before
 
 
 # ------------------------------------------------------------------------------------------------ scan at the MEH shapes

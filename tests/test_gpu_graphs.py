@@ -86,6 +86,22 @@ def test_whole_static_part_replay_equals_eager_at_the_bench_configuration(pkg):
     its factors are an input of the recorded function (drawn once here)."""
     import json, os
     from conftest import ROOT
+    from tamtr_amd import tuning
+    keep = (torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark, torch.are_deterministic_algorithms_enabled(),
+            torch.is_deterministic_algorithms_warn_only_enabled())
+    # MIOpen on its deterministic solvers: with its split-K / atomic kernels the trunk's FORWARD differs from run to run in the last
+    # bits, and 60 BatchNorm layers on random weights amplify that to O(1) differences of the gradients (measured: eager against eager
+    # 2.0 - 2.9 per tensor), which would make the comparison meaningless
+    tuning.use_deterministic_convolutions()
+    try:
+        _whole_static_part_check(pkg, json, os, ROOT)
+    finally:
+        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = keep[0], keep[1]
+        torch.use_deterministic_algorithms(keep[2], warn_only=keep[3])
+        os.environ.pop('MIOPEN_DEBUG_CONVOLUTION_DETERMINISTIC', None)
+
+
+def _whole_static_part_check(pkg, json, os, ROOT):
     torch.manual_seed(0)
     model = pkg.model.RTDETRDetectionWorldModel(nc=10).cuda().train()
     model.autocast_dtype = torch.bfloat16

@@ -256,6 +256,55 @@ def test_shipped_convolution_tables_match_this_miopen_build():
     assert tuning.use_tuned_convolutions('off').startswith('off')
 
 
+def test_tuned_tables_go_to_a_persistent_directory_and_are_never_clobbered(tmp_path, monkeypatch):
+    """the writable copy of the shipped tables lives in a per-user, per-MIOpen-build directory that survives the run (what a
+    run had to search is searched once per machine); a file MIOpen has appended to is not overwritten by the shipped one."""
+    import glob
+    import os
+    from tamtr_amd import tuning
+    monkeypatch.setenv('TAMTR_MIOPEN_DB_DIR', str(tmp_path))
+    monkeypatch.delenv('TAMTR_DETERMINISTIC', raising=False)
+    monkeypatch.delenv('MIOPEN_USER_DB_PATH', raising=False)
+    keep = torch.backends.cudnn.benchmark
+    try:
+        logs = []
+        assert tuning.use_tuned_convolutions('shipped', log=logs.append) == 'shipped tables'
+        work = os.environ['MIOPEN_USER_DB_PATH']
+        assert work.startswith(str(tmp_path)) and str(torch.backends.cudnn.version()) in work and logs and 'searched once' in logs[0]
+        shipped = sorted(os.path.basename(f) for f in glob.glob(os.path.join(tuning._DIR, '*.txt')))
+        assert sorted(os.listdir(work)) == shipped and torch.backends.cudnn.benchmark
+        grown = os.path.join(work, shipped[0])
+        with open(grown, 'a') as f:
+            f.write('entry found by a later run\n')
+        size = os.path.getsize(grown)
+        tuning.use_tuned_convolutions('shipped')
+        assert os.path.getsize(grown) == size and os.environ['MIOPEN_USER_DB_PATH'] == work   # same place, the find kept
+    finally:
+        torch.backends.cudnn.benchmark = keep
+
+
+def test_deterministic_switch_and_no_tunableop(monkeypatch):
+    """TAMTR_DETERMINISTIC=1 (the reference's `deterministic: True`, cfg/default.yaml:26): MIOpen is held to deterministic solvers and no
+    timed search / shipped tables are used.  And the package never turns PyTorch's TunableOp on (a GEMM candidate it tried
+    faulted the GPU in round 2; the feature stays off)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ('import os, sys; sys.path.insert(0, %r); import torch; import tamtr_amd; from tamtr_amd import tuning, ops; '
+            'r = tuning.use_tuned_convolutions("shipped"); '
+            'print(r.split()[0], torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark, os.environ.get("MIOPEN_DEBUG_CONVOLUTION_DETERMINISTIC"), '
+            'ops.deterministic(), os.environ.get("PYTORCH_TUNABLEOP_ENABLED"))' % ROOT)
+    env = dict(os.environ, TAMTR_DETERMINISTIC='1')
+    env.pop('PYTORCH_TUNABLEOP_ENABLED', None)
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert out.stdout.split() == ['deterministic', 'True', 'False', '1', 'True', 'None'], out.stdout
+    for path in ('bench.py', 'tools/train.py', 'tools/val.py', 'tam-tr_amd/__init__.py', 'tam-tr_amd/tuning.py', 'tam-tr_amd/engine.py'):
+        text = open(os.path.join(ROOT, path)).read()
+        assert 'TUNABLEOP_ENABLED' not in text and 'tunable.enable' not in text, path
+
+
 def test_trunk_glue_falls_back_to_torch_on_cpu():
     """The NHWC glue ops (ops.cat_channels / pack_channels / max_pool2d / to_nchw / to_channels_last, backbone.Upsample) only take their
     HIP kernels for CUDA maps; CPU tensors (the CPU suite, the oracle-side tests) go through torch with identical results."""
