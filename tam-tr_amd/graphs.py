@@ -101,14 +101,19 @@ class GraphedPart:
         for b, v in zip(self.module.buffers(), saved):
             b.copy_(v)
 
-    def verify(self, replays=1, tol=2e-2, noise_factor=8.0, junk_between=True):
+    def verify(self, replays=1, tol=2e-2, noise_factor=6.0, junk_between=True):
         """Replay the two recorded graphs on the capture inputs and hold them to an EAGER forward + backward of the same module on the
-        same inputs and the same cotangent: output and every live parameter gradient, as max |difference| / max |reference| per tensor.
-        The eager pass runs twice, so the result carries the eager run-to-run level (`eager_noise`: MIOpen's split-K / atomic solvers
-        are not bitwise reproducible) next to the replay error.  Buffers the module updates in place (BatchNorm statistics) are
-        restored afterwards; no global RNG is consumed (the module must be a function of its inputs: DropPath factors are inputs).
-        Returns a dict; `ok` is False when anything is non-finite or off by more than max(tol, noise_factor * eager_noise) - a replay
-        that went wrong is off by > 1e-1 or NaN (profiles/r02_graph_capture_findings.txt)."""
+        same inputs and the same cotangent: the output and every live parameter gradient.  The eager pass runs twice, so every figure
+        comes with the eager run-to-run level of the same quantity next to it: with MIOpen's split-K / atomic solvers the trunk is not
+        bitwise reproducible and its BatchNorm stack amplifies that - gradients that are sums with heavy cancellation (biases) then
+        differ by O(1) of their own size between two EAGER runs and carry no information; on deterministic solvers
+        (tuning.use_deterministic_convolutions) eager is reproducible and a replay equals it bit for bit
+        (tests/test_gpu_graphs.py).  Metrics are relative L2 norms: per tensor (`*_rel`) and over all gradients together (`grad_l2_rel`).
+        `ok` is False when anything is non-finite, when the output or the whole gradient is off by more than
+        max(tol, noise_factor * eager level), or when an INFORMATIVE tensor (eager level < 0.1) is off by more than that bound on its
+        own level.  A replay that went wrong is NaN or off by many orders of magnitude (profiles/r03_graph_probe.txt).
+        Buffers the module updates in place (BatchNorm statistics) are restored afterwards; no global RNG is consumed (the module
+        must be a function of its inputs: DropPath factors are inputs)."""
         saved = self._snapshot_buffers()
         live = [i for i, g in enumerate(self.static_grads) if g is not None]
         gen = torch.Generator(device=self.static_out.device).manual_seed(20261004)
@@ -121,20 +126,27 @@ class GraphedPart:
                 gr = torch.autograd.grad(out, [self.params[i] for i in live], cot, allow_unused=True)
             return out.detach().float().clone(), [None if g is None else g.detach().float().clone() for g in gr]
 
-        def rel(a, b):
+        def dist(a, b):   # (|a - b|^2, |b|^2) as python floats; nan-safe
             if a is None or b is None:
-                return 0.0 if a is b else float('inf')
-            d = float((a.float() - b).abs().max())
-            return d / max(float(b.abs().max()), 1e-12) if d == d else float('nan')
+                return (0.0, 0.0) if a is b else (float('inf'), 1.0)
+            d = (a.float() - b).double()
+            return float((d * d).sum()), float((b.double() * b.double()).sum())
+
+        def rel(num, den):
+            return (num / den) ** 0.5 if den > 0 else (0.0 if num == 0 else float('inf'))
 
         o1, g1 = eager()
         o2, g2 = eager()
-        noise_out = rel(o2, o1)
-        noise = [rel(a, b) for a, b in zip(g2, g1)]
-        worst_noise = max([noise_out] + noise)
-        res = {'grads': len(live), 'eager_noise_out': noise_out, 'eager_noise_grad_max': max(noise) if noise else 0.0, 'replays': []}
+        noise_out = rel(*dist(o2, o1))
+        nz = [dist(a, b) for a, b in zip(g2, g1)]
+        noise_t = [rel(*x) for x in nz]
+        noise_all = rel(sum(x[0] for x in nz), sum(x[1] for x in nz))
+        informative = [n == n and n < 0.1 for n in noise_t]
+        res = {'grads': len(live), 'informative_grads': sum(informative), 'eager_noise_out': noise_out, 'eager_noise_grad_l2': noise_all,
+               'eager_noise_grad_max': max(noise_t) if noise_t else 0.0, 'replays': []}
         ok = True
-        bound = min(max(tol, noise_factor * worst_noise), 0.25)   # (a replay that went wrong is off by > 1 or NaN)
+        cap = 0.5
+        b_out, b_all = min(max(tol, noise_factor * noise_out), cap), min(max(tol, noise_factor * noise_all), cap)
         for rep in range(replays):
             self._restore_buffers(saved)
             self.static_gout.copy_(cot)
@@ -143,18 +155,23 @@ class GraphedPart:
                 junk = torch.full((1 << 22,), float('nan'), device=cot.device)
                 del junk
             self.bwd.replay()
-            e_out = rel(self.static_out, o1)
-            errs = [rel(self.static_grads[i], g) for i, g in zip(live, g1)]
+            e_out = rel(*dist(self.static_out, o1))
+            ds = [dist(self.static_grads[i], g) for i, g in zip(live, g1)]
+            errs = [rel(*x) for x in ds]
+            e_all = rel(sum(x[0] for x in ds), sum(x[1] for x in ds))
             nonfinite = sum(1 for i in live if not bool(torch.isfinite(self.static_grads[i]).all()))
-            w = max(range(len(errs)), key=lambda j: (errs[j] != errs[j], errs[j])) if errs else None
-            rec = {'out_rel': e_out, 'grad_rel_max': errs[w] if errs else 0.0, 'worst_grad': self.names[live[w]] if errs else None,
-                   'nonfinite_grads': nonfinite}
+            over = [(errs[j] / max(tol, noise_factor * noise_t[j]), j) for j in range(len(errs)) if informative[j]]
+            over = [(v if v == v else float('inf'), j) for v, j in over]
+            worst = max(over) if over else (0.0, None)
+            rec = {'out_rel': e_out, 'grad_l2_rel': e_all, 'grad_rel_max': max(errs) if errs else 0.0,
+                   'worst_informative_grad': None if worst[1] is None else self.names[live[worst[1]]],
+                   'worst_informative_over_bound': worst[0], 'nonfinite_grads': nonfinite}
             res['replays'].append(rec)
-            bad = nonfinite or not (e_out <= bound) or not (rec['grad_rel_max'] <= bound)
+            bad = nonfinite or not (e_out <= b_out) or not (e_all <= b_all) or not (worst[0] <= 1.0)
             ok = ok and not bad
         self._restore_buffers(saved)
-        res.update(ok=ok, bound=bound, out_rel_max=max(r['out_rel'] for r in res['replays']),
-                   grad_rel_max=max(r['grad_rel_max'] for r in res['replays']))
+        res.update(ok=ok, bound_out=b_out, bound_grad_l2=b_all, out_rel_max=max(r['out_rel'] for r in res['replays']),
+                   grad_l2_rel_max=max(r['grad_l2_rel'] for r in res['replays']), grad_rel_max=max(r['grad_rel_max'] for r in res['replays']))
         return res
 
     def __call__(self, *args):

@@ -55,13 +55,16 @@ class ManbaWorldDecoder(nn.Module):
     def draw_drop_scales(self, n, device):
         """[num_Blocks, 2, n]: this step's DropPath factors of the VSS blocks (vss.VSSBlock.draw_drop_scales), drawn outside encode()
         so that a recorded graph of encode() is a deterministic function of its inputs."""
+        if not all(hasattr(blk, 'draw_drop_scales') for blk in self.VSSBlocks):   # blocks swapped out (tests put nn.Identity here)
+            return None
         return torch.stack([blk.draw_drop_scales(n, device) for blk in self.VSSBlocks])
 
     def encode(self, x, drop_scales=None):
         """The three trunk maps -> the token memory `feats` [B, L, hd] and the level shapes.  Shapes depend on the image size only."""
         # VSS blocks run channels-last ([B,H,W,C], head.py:1136-1140); their outputs stay token-major: the 1x1 input projection
         # is a GEMM over tokens and its result is already in the [B, L, hd] layout of the token memory
-        toks = [blk(f.permute(0, 2, 3, 1), None if drop_scales is None else drop_scales[i]) for i, (blk, f) in enumerate(zip(self.VSSBlocks, x))]
+        toks = [blk(f.permute(0, 2, 3, 1)) if drop_scales is None else blk(f.permute(0, 2, 3, 1), drop_scales[i])
+                for i, (blk, f) in enumerate(zip(self.VSSBlocks, x))]
         return self._get_encoder_input(toks)
 
     def decode(self, feats, shapes, text, batch=None):

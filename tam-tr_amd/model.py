@@ -232,8 +232,10 @@ class RTDETRDetectionWorldModel(nn.Module):
                     b.copy_(v)
         if verify and not self.static_part_check['ok']:
             chk = self.static_part_check
-            msg = (f"HIP-graph replay of the static part does not reproduce eager execution (token memory rel {chk['out_rel_max']:.2e}, worst gradient "
-                   f"rel {chk['grad_rel_max']:.2e} at {chk['replays'][-1]['worst_grad']}, bound {chk['bound']:.1e}; HIP {torch.version.hip}): running eagerly")
+            msg = (f"HIP-graph replay of the static part does not reproduce eager execution (token memory rel {chk['out_rel_max']:.2e} / bound "
+                   f"{chk['bound_out']:.1e}, all gradients rel {chk['grad_l2_rel_max']:.2e} / bound {chk['bound_grad_l2']:.1e}, worst informative tensor "
+                   f"{chk['replays'][-1]['worst_informative_grad']} at {chk['replays'][-1]['worst_informative_over_bound']:.1f} x its bound; "
+                   f"HIP {torch.version.hip}): running eagerly")
             (log or print)(msg)
             raise RuntimeError(msg)
         if log is not None and not any(str(torch.version.hip).startswith(v) for v in VALIDATED_HIP):

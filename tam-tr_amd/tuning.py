@@ -29,11 +29,11 @@ def shipped_db_matches():
             and meta.get('hip') == torch.version.hip)
 
 
-def _user_db_dir():
+def _user_db_dir(suffix=''):
     """A PERSISTENT per-user directory for MIOpen's writable tables, one per MIOpen / HIP build: what a run has to search (a tail
     batch, the validation batch size, another image size) is searched once per machine, not once per run, and nothing is left behind in
     /tmp.  TAMTR_MIOPEN_DB_DIR overrides the place; an unwritable home falls back to a temporary directory removed at exit."""
-    tag = f'miopen-{torch.backends.cudnn.version()}-hip-{torch.version.hip}'
+    tag = f'miopen-{torch.backends.cudnn.version()}-hip-{torch.version.hip}{suffix}'
     base = os.environ.get('TAMTR_MIOPEN_DB_DIR') or os.path.join(os.environ.get('XDG_CACHE_HOME') or os.path.join(os.path.expanduser('~'), '.cache'),
                                                                  'tamtr_amd')
     path = os.path.join(base, tag)
@@ -62,15 +62,22 @@ def _seed(dst):
         os.replace(tmp, to)
 
 
-def use_deterministic_convolutions():
+def use_deterministic_convolutions(search=False):
     """The reference's `deterministic: True` (cfg/default.yaml:26 -> utils/torch_utils.py:371-389: cudnn.deterministic +
     use_deterministic_algorithms(warn_only)) for the MIOpen part of the step: ATen sets MIOpen's DETERMINISTIC convolution attribute,
-    under which the split-K / atomic-add solvers are not applicable; no timed search and no tables (the shipped tables were chosen
-    with those solvers allowed), i.e. MIOpen's heuristic among the deterministic solvers.  Call before the first convolution."""
+    under which the split-K / atomic-add solvers are not applicable.  search=True (TAMTR_DETERMINISTIC=1 runs): MIOpen's timed search
+    among the solvers that remain, kept in a persistent directory of its own (the shipped tables were chosen with the atomic solvers
+    allowed and are not used) - without it MIOpen's heuristic falls back to its naive kernels for the weight gradients once its
+    first choice is not applicable (measured: 17 s per 16-image step).  search=False: that heuristic (fine for a few small steps, as
+    in the tests).  Call before the first convolution."""
     os.environ['MIOPEN_DEBUG_CONVOLUTION_DETERMINISTIC'] = '1'
     torch.backends.cudnn.deterministic = True
-    torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.benchmark = bool(search)
     torch.use_deterministic_algorithms(True, warn_only=True)
+    if search:
+        work, _ = _user_db_dir('-deterministic')
+        os.environ['MIOPEN_USER_DB_PATH'] = work
+        return f'deterministic (MIOpen timed search among its deterministic solvers, {work})'
     return 'deterministic (MIOpen heuristic restricted to deterministic solvers)'
 
 
@@ -80,7 +87,7 @@ def use_tuned_convolutions(mode='shipped', db_dir=None, log=None):
     'off' - default heuristic.  TAMTR_DETERMINISTIC=1 overrides all of them with use_deterministic_convolutions().
     Returns what was set up, for logs."""
     if os.environ.get('TAMTR_DETERMINISTIC') == '1':
-        return use_deterministic_convolutions()
+        return use_deterministic_convolutions(search=True)
     if mode == 'off':
         return 'off (MIOpen heuristic)'
     if mode == 'search':

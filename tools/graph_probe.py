@@ -24,7 +24,7 @@ batch = synth_batch(B, S, 1, 'cuda')
 model.capture_static_part(batch['img'], batch['txt_feats'], verify=False)
 gp = model._static[0]
 gp.static_in[2].copy_(model.model[-1].draw_drop_scales(B, 'cuda'))
-chk = gp.verify(replays=6, tol=3e-3, noise_factor=4.0)
+chk = gp.verify(replays=6)
 opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
 rec = []
 for i in range(6):
@@ -38,6 +38,7 @@ for i in range(6):
     torch.cuda.synchronize()
     rec.append((round((t1 - t0) * 1e3, 1), round((time.perf_counter() - t0) * 1e3, 1), round((time.process_time() - c0) * 1e3, 1)))
 flags = {k: v for k, v in os.environ.items() if k.startswith(('DEBUG_', 'HIP_FORCE', 'AMD_SERIALIZE', 'GPU_', 'ROC_'))}
-print(json.dumps({'tag': tag, 'flags': flags, 'ok': chk['ok'], 'out_rel_max': chk['out_rel_max'], 'grad_rel_max': chk['grad_rel_max'],
-                  'eager_noise': chk['eager_noise_grad_max'], 'nonfinite': [r['nonfinite_grads'] for r in chk['replays']],
-                  'worst': [r['worst_grad'] for r in chk['replays']], 'step_ms(issue, wall, cpu)': rec[2:], 'loss': float(loss)}), flush=True)
+print(json.dumps({'tag': tag, 'flags': flags, 'ok': chk['ok'], 'out_rel_max': chk['out_rel_max'], 'grad_l2_rel_max': chk['grad_l2_rel_max'],
+                  'grad_rel_max': chk['grad_rel_max'], 'eager_noise_out': chk['eager_noise_out'], 'eager_noise_grad_l2': chk['eager_noise_grad_l2'],
+                  'informative': chk['informative_grads'], 'nonfinite': [r['nonfinite_grads'] for r in chk['replays']],
+                  'worst': [r['worst_informative_grad'] for r in chk['replays']], 'step_ms(issue, wall, cpu)': rec[2:], 'loss': float(loss)}), flush=True)
