@@ -717,22 +717,165 @@ __global__ __launch_bounds__(WS_T, 2) void linear_bf16_wstat_kernel(const bf16_t
 #undef WSTAMP
 }
 
+// =====================================================================================================================
+// W-STATIONARY, 64 COLUMNS PER WAVE (K = 512, N % 256 == 0).
+//
+// What holds the kernel above at ~45 % of the MFMA roof is LDS bandwidth: every one of its 8 waves reads the whole 32 KB X block as
+// B-fragments (one ds_read_b128 = 1 KB per MFMA of 32 cycles per SIMD = 128 B/clk per CU = the LDS pipe's peak), so the matrix
+// pipe can never be busy more than the LDS pipe lets it, and the LDS-DMA writes and bank conflicts come on top (measured: MFMA
+// busy 55.8 %, profiles/r02_gemm_pmc.json).  Here every X fragment feeds TWO MFMAs: a wave owns 64 output columns, i.e. 2 x 32
+// fragments of W = 256 registers (the AGPR half of the 512-register budget of a wave that has its SIMD to itself), a workgroup is
+// 4 waves = 256 columns, one workgroup per CU.  LDS reads per block and CU drop from 256 KB to 128 KB.
+//   * Two accumulator tiles per wave = two independent MFMA chains, interleaved: no dependent-issue bubbles.
+//   * With one wave per SIMD nothing else covers a stall, so X does not come through LDS-DMA (whose issue parks a wave for
+//     ~260 cycles per KiB piece): plain 16-byte global loads into registers two blocks ahead, ds_write_b128 into a 3-slot ring one
+//     block ahead - both are fire-and-forget for the wave, and their waits are a full block (~2 000 cycles) behind their issue.
+//   * One barrier per block (the ring slot written in iteration b was last read in iteration b - 2).
+//   * Stores through a buffer resource (rows past M are dropped by the range check: no branch around a memory operation).
+// Same bias-by-MFMA trick, fragment layouts, XOR swizzle and register epilogue as above.
+constexpr int W2_T = 256, W2_SLOTS = 3, W2_PF = 8;
+
+template <int KK>
+__global__ __launch_bounds__(W2_T, 1) void linear_bf16_wstat2_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                                      const float* __restrict__ bias, bf16_t* __restrict__ Y, int M,
+                                                                      int N, int ncol, int n_workers, int n_blocks) {
+  constexpr int RB = KK * 2;          // bytes per X row (1 KB)
+  constexpr int BLK = WS_ROWS * RB;   // bytes per block (32 KB)
+  constexpr int NKS = KK / 16;        // k16 steps (32)
+  constexpr int LPW = WS_ROWS / 4;    // rows (= 1-KB loads) per wave and block (8)
+  static_assert(RB == 1024, "one 16-byte chunk per lane and row");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [W2_SLOTS blocks]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int colgrp = slot % ncol, worker = (slot / ncol) * 8 + xcd;
+  const int n0w = colgrp * WS_COLS + wave * 64;  // this wave's 64 output columns: tiles [n0w, +32) and [n0w + 32, +32)
+  const int my_blocks = worker < n_workers ? (n_blocks - worker + n_workers - 1) / n_workers : 0;
+
+  s16x8 wf[2][NKS + 1];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) wf[c][ks] = *reinterpret_cast<const s16x8*>(W + (size_t)(n0w + 32 * c + lr) * KK + ks * 16 + lh * 8);
+    const float bv = (bias && lh == 0) ? bias[n0w + 32 * c + lr] : 0.f;
+    const bf16_t hi = f2bf(bv), lo = f2bf(bv - bf2f(hi));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wf[c][NKS][j] = 0;
+    wf[c][NKS][0] = (short)hi;
+    wf[c][NKS][1] = (short)lo;
+  }
+  s16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = 0;
+  if (lh == 0) { ones[0] = (short)0x3f80; ones[1] = (short)0x3f80; }
+
+  // staging: wave w carries rows w * 8 .. + 8 of a block, lane l the 16-byte chunk l of the row; it lands at chunk position l ^ (row & 15)
+  // (macros, not lambdas: arrays handed to a lambda by reference are given a scratch home by hipcc)
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // (native vectors: an array of HIP_vector_type structs stayed in scratch)
+  u32x4 st0[LPW], st1[LPW];
+#define W2_FETCH(bi_, r_)                                                                                         \
+  {                                                                                                               \
+    const int m0_ = (worker + (bi_) * n_workers) * WS_ROWS + wave * LPW;                                          \
+    _Pragma("clang loop unroll(full)") for (int j = 0; j < LPW; ++j)                                                               \
+        r_[j] = *reinterpret_cast<const u32x4*>(X + (size_t)min(m0_ + j, M - 1) * KK + lane * 8);                 \
+  }
+#define W2_STASH(bi_, r_)                                                                                         \
+  {                                                                                                               \
+    unsigned char* dst_ = smem + ((bi_) % W2_SLOTS) * BLK;                                                        \
+    _Pragma("clang loop unroll(full)") for (int j = 0; j < LPW; ++j) {                                                             \
+      const int row_ = wave * LPW + j;                                                                            \
+      *reinterpret_cast<u32x4*>(dst_ + row_ * RB + ((lane ^ (row_ & 15)) << 4)) = r_[j];                          \
+    }                                                                                                             \
+  }
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)min((size_t)M * N * 2, (size_t)0x7ffffff0u), 0x00020000);
+
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  auto pack2 = [](float a, float b) -> uint32_t { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2)); };
+
+  // prologue: block 0 into the ring, block 1 in flight
+  if (my_blocks > 0) { W2_FETCH(0, st0) W2_STASH(0, st0) }
+  if (my_blocks > 1) W2_FETCH(1, st1)
+  // the loop is unrolled by two so that the two staging register sets have FIXED roles in each half (selected by a run-time
+  // parity they were given a scratch home)
+#define W2_BODY(bi, S_STASH, S_FETCH)                                                                                       \
+  {                                                                                                                         \
+    /* block bi + 1 (requested one iteration ago) goes into the ring; block bi + 2 is requested into the registers just   */ \
+    /* freed (clamped addresses: the requests are unconditional, only the bookkeeping branches)                           */ \
+    if ((bi) + 1 < my_blocks) W2_STASH((bi) + 1, S_STASH)                                                                   \
+    if ((bi) + 2 < my_blocks) W2_FETCH((bi) + 2, S_FETCH)                                                                   \
+    __syncthreads(); /* block bi is complete in LDS (written one iteration ago); block bi - 1 is no longer read */         \
+    const unsigned char* xb = smem + ((bi) % W2_SLOTS) * BLK + lr * RB;                                                     \
+    int sw = lr & 15;                                                                                                       \
+    asm volatile("" : "+v"(sw));                                                                                            \
+    f32x16 acc0, acc1;                                                                                                      \
+    _Pragma("clang loop unroll(full)") for (int q = 0; q < 16; ++q) { acc0[q] = 0.f; acc1[q] = 0.f; }                                        \
+    s16x8 xf[W2_PF];                                                                                                        \
+    _Pragma("clang loop unroll(full)") for (int ks = 0; ks < W2_PF; ++ks) xf[ks] = *reinterpret_cast<const s16x8*>(xb + (((ks * 2 + lh) ^ sw) << 4)); \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][NKS], ones, acc0, 0, 0, 0); /* bias */                             \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][NKS], ones, acc1, 0, 0, 0);                                        \
+    _Pragma("clang loop unroll(full)") for (int ks = 0; ks < NKS; ++ks) {                                                                    \
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], xf[ks % W2_PF], acc0, 0, 0, 0);                             \
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][ks], xf[ks % W2_PF], acc1, 0, 0, 0);                             \
+      if (ks + W2_PF < NKS) xf[ks % W2_PF] = *reinterpret_cast<const s16x8*>(xb + ((((ks + W2_PF) * 2 + lh) ^ sw) << 4));   \
+    }                                                                                                                       \
+    __builtin_amdgcn_sched_group_barrier(0x100, W2_PF, 0); /* DS_READ x PF */                                               \
+    __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);       /* MFMA x 2 (bias) */                                            \
+    _Pragma("clang loop unroll(full)") for (int ks = 0; ks < NKS; ++ks) {                                                                    \
+      __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);                                                                      \
+      if (ks + W2_PF < NKS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                              \
+    }                                                                                                                       \
+    /* ---- epilogue (layout as in the 32-column kernel), two tiles */                                                      \
+    const int gm = (worker + (bi) * n_workers) * WS_ROWS + lr;                                                              \
+    _Pragma("clang loop unroll(full)") for (int c = 0; c < 2; ++c) {                                                                         \
+      const f32x16& acc = c ? acc1 : acc0;                                                                                  \
+      uint32_t pk[8];                                                                                                       \
+      _Pragma("clang loop unroll(full)") for (int g = 0; g < 4; ++g) { pk[2 * g] = pack2(acc[4 * g], acc[4 * g + 1]); pk[2 * g + 1] = pack2(acc[4 * g + 2], acc[4 * g + 3]); } \
+      _Pragma("clang loop unroll(full)") for (int p = 0; p < 2; ++p) {                                                                       \
+        const auto r0 = __builtin_amdgcn_permlane32_swap(pk[4 * p], pk[4 * p + 2], false, false);                           \
+        const auto r1 = __builtin_amdgcn_permlane32_swap(pk[4 * p + 1], pk[4 * p + 3], false, false);                       \
+        const uint4 v = make_uint4(r0[0], r1[0], r0[1], r1[1]);                                                             \
+        decltype(__builtin_amdgcn_raw_buffer_load_b128(yrs, 0, 0, 0)) w128;                                                 \
+        __builtin_memcpy(&w128, &v, sizeof(v));                                                                             \
+        const unsigned off = gm < M ? (unsigned)(((size_t)gm * N + n0w + 32 * c + 16 * p + 8 * lh) * 2) : 0x7ffffff0u;      \
+        __builtin_amdgcn_raw_buffer_store_b128(w128, yrs, off, 0, 0);                                                       \
+      }                                                                                                                     \
+    }                                                                                                                       \
+  }
+  for (int bi = 0; bi < my_blocks; bi += 2) {
+    W2_BODY(bi, st1, st0)
+    if (bi + 1 < my_blocks) W2_BODY(bi + 1, st0, st1)
+  }
+#undef W2_BODY
+#undef W2_FETCH
+#undef W2_STASH
+}
+
 }  // namespace
 
 extern "C" int tamtr_linear_bf16(const void* X, const void* W, const float* bias, void* Y, int M, int N, int K, void* stream) {
   if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return TAMTR_EINVAL;
   if (K % BK || N % BN) return TAMTR_EUNSUP;
-  if ((K == 512 || K == 256 || K == 128) && N % WS_COLS == 0 && 32 % (N / WS_COLS) == 0 && getenv("TAMTR_GEMM_OLD") == nullptr) {
+  // kernel choice (A/B switch TAMTR_GEMM = ws2 | ws1 | tile), read once when the library is loaded - not per call
+  static const int choice = [] { const char* e = getenv("TAMTR_GEMM"); return !e ? 2 : e[0] == 't' ? 0 : (e[0] == 'w' && e[1] == 's' && e[2] == '1') ? 1 : 2; }();
+  if (choice == 2 && K == 512 && N % WS_COLS == 0 && 32 % (N / WS_COLS) == 0 && (size_t)M * N * 2 < 0x7ffffff0u) {
+    // 64 columns per wave: 256 workgroups of 4 waves, one per CU
+    const int ncol = N / WS_COLS, n_workers = (32 / ncol) * 8, n_blocks = (M + WS_ROWS - 1) / WS_ROWS;
+    const size_t lds = (size_t)W2_SLOTS * WS_ROWS * K * 2;
+    if (hipFuncSetAttribute((const void*)linear_bf16_wstat2_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return TAMTR_ELAUNCH;   // (per call: the attribute is per device, and this is a few hundred nanoseconds)
+    hipLaunchKernelGGL(linear_bf16_wstat2_kernel<512>, dim3(256), dim3(W2_T), lds, (hipStream_t)stream, (const bf16_t*)X, (const bf16_t*)W,
+                       bias, (bf16_t*)Y, M, N, ncol, n_workers, n_blocks);
+    return tamtr_launch_status();
+  }
+  if (choice >= 1 && (K == 512 || K == 256 || K == 128) && N % WS_COLS == 0 && 32 % (N / WS_COLS) == 0) {
     // W-stationary: 256 persistent workgroups, N / 256 of them (same XCD) per row block
     const int ncol = N / WS_COLS, n_workers = (32 / ncol) * 8, n_blocks = (M + WS_ROWS - 1) / WS_ROWS;
     const size_t lds = (size_t)WS_SLOTS * WS_ROWS * K * 2;
 #define LAUNCH_WS(KK)                                                                                                        \
   {                                                                                                                          \
-    static bool attr_set = false;                                                                                            \
-    if (!attr_set) {                                                                                                         \
-      (void)hipFuncSetAttribute((const void*)linear_bf16_wstat_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      attr_set = true;                                                                                                       \
-    }                                                                                                                        \
+    if (hipFuncSetAttribute((const void*)linear_bf16_wstat_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+      return TAMTR_ELAUNCH;   /* per call: the attribute is per DEVICE (a process-wide "done" flag would skip the second GPU) */ \
     hipLaunchKernelGGL(linear_bf16_wstat_kernel<KK>, dim3(256), dim3(WS_T), lds, (hipStream_t)stream, (const bf16_t*)X,      \
                        (const bf16_t*)W, bias, (bf16_t*)Y, M, N, ncol, n_workers, n_blocks);                                 \
   }

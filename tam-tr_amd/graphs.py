@@ -129,7 +129,8 @@ class GraphedPart:
         def dist(a, b):   # (|a - b|^2, |b|^2) as python floats; nan-safe
             if a is None or b is None:
                 return (0.0, 0.0) if a is b else (float('inf'), 1.0)
-            d = (a.float() - b).double()
+            a, b = a.detach(), b.detach()
+            d = (a.float() - b.float()).double()
             return float((d * d).sum()), float((b.double() * b.double()).sum())
 
         def rel(num, den):
