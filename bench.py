@@ -272,6 +272,7 @@ def main():
 
     # bf16 mode against fp32 mode on the same weights and batch (forward only, same denoising seed), before anything is trained
     mode_err = None
+    t_probe = time.perf_counter()
     if args.dtype == 'bf16':
         saved = {k: v.clone() for k, v in model.state_dict().items()}   # BatchNorm statistics move with a training forward
         with torch.no_grad():
@@ -285,6 +286,8 @@ def main():
         mode_err = {'loss_fp32': losses['fp32'], 'loss_bf16': losses['bf16'], 'rel': abs(losses['bf16'] - losses['fp32']) / abs(losses['fp32'])}
         del saved
         torch.manual_seed(0)
+        torch.cuda.synchronize()
+        note(f'bf16 against fp32 forward on the same batch: {time.perf_counter() - t_probe:.1f} s (first convolutions: MIOpen handle, tables, code objects)')
     static_part = 'eager'
     if args.static_part == 'graph':
         try:

@@ -30,7 +30,7 @@ class GraphedPart:
     sample_args: CUDA tensors of those shapes (not differentiated).  Buffers the module updates in place (BatchNorm statistics)
     are updated by every replay, as in eager mode.  Gradients reach the module's parameters through ordinary AccumulateGrad."""
 
-    def __init__(self, module, sample_args, warmup=3):
+    def __init__(self, module, sample_args, warmup=3, log=None):
         if not all(isinstance(a, torch.Tensor) and a.is_cuda for a in sample_args):
             raise ValueError('sample_args must be CUDA tensors')
         from . import GRAPH_REPLAY_SAFE
@@ -48,6 +48,8 @@ class GraphedPart:
         def run():
             return torch.func.functional_call(module, alias, tuple(self.static_in))
 
+        import time
+        t0 = time.perf_counter()
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             for _ in range(warmup):   # MIOpen / hipBLASLt solver selection, lazy workspaces, the leaves' accumulators: all before capture
@@ -57,12 +59,15 @@ class GraphedPart:
                 del out, g
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
+        t1 = time.perf_counter()
         with torch.cuda.graph(self.fwd, pool=pool, stream=self.stream):
             self.static_out = run()
         self.static_gout = torch.zeros_like(self.static_out)
         leaves = [alias[n] for n in self.names if alias[n].requires_grad]
         with torch.cuda.graph(self.bwd, pool=pool, stream=self.stream):
             grads = torch.autograd.grad(self.static_out, leaves, self.static_gout, allow_unused=True)
+        if log is not None:
+            log(f'graph capture: {warmup} warm-up passes (kernel selection / compilation) {t1 - t0:.1f} s, recording forward + backward {time.perf_counter() - t1:.1f} s')
         it = iter(grads)
         self.static_grads = [next(it) if alias[n].requires_grad else None for n in self.names]
         self.n_live = sum(g is not None for g in self.static_grads)

@@ -69,8 +69,10 @@ def build_graph(spec, ch=3, nc=10):
 import os
 # NHWC trunk on the GPU: MIOpen's bf16 convolutions are NHWC kernels and wrap every NCHW operand in a transpose (483 launches,
 # 7.75 ms of the 640 px / bs 16 step).  Channels-last activations + channels-last k x k weights take them as they are (needs
-# PYTORCH_MIOPEN_SUGGEST_NHWC=1, set by the package __init__).  TAMTR_CHANNELS_LAST=0 restores NCHW.
-_CHANNELS_LAST = os.environ.get('TAMTR_CHANNELS_LAST', '1') != '0'
+# PYTORCH_MIOPEN_SUGGEST_NHWC=1, set by the package __init__).  TAMTR_CHANNELS_LAST=0 restores NCHW, and so does the deterministic mode
+# (TAMTR_DETERMINISTIC=1) unless told otherwise: MIOpen 3.5 has no deterministic solver for NHWC bf16 convolutions other than its naive
+# kernels (17 s per 16-image step), for NCHW it has (0.25 s).  Per model: set_channels_last().
+_CHANNELS_LAST = os.environ.get('TAMTR_CHANNELS_LAST', '0' if os.environ.get('TAMTR_DETERMINISTIC') == '1' else '1') != '0'
 
 
 class _CastGroup(torch.autograd.Function):
@@ -130,12 +132,22 @@ class RTDETRDetectionWorldModel(nn.Module):
         self.names = {i: f'{i}' for i in range(nc)}
         self.txt_feats = torch.randn(1, nc, 512)
         self.model, self.save = build_graph(cfg or TAMTR_SPEC, ch, nc)
-        if _CHANNELS_LAST:  # k x k conv weights in the layout the NHWC kernels read (values, keys and shapes are unchanged)
-            for m in self.model[:-1].modules():
-                if isinstance(m, nn.Conv2d) and m.kernel_size != (1, 1):
-                    m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+        self.channels_last = False
+        self.set_channels_last(_CHANNELS_LAST)
         self.stride = torch.Tensor([32])
         self.autocast_dtype = None  # torch.bfloat16 => bf16 activations through the trunk and the head GEMMs
+
+    def set_channels_last(self, flag=True):
+        """Trunk layout of THIS model: NHWC activations + channels-last k x k convolution weights (the default on the GPU), or NCHW
+        (values, state_dict keys and shapes are the same either way; the deterministic mode runs NCHW, see _CHANNELS_LAST).  Recorded
+        graphs belong to the layout they were recorded in: they are dropped."""
+        self.release_static_part()
+        fmt = torch.channels_last if flag else torch.contiguous_format
+        for m in self.model[:-1].modules():
+            if isinstance(m, nn.Conv2d) and m.kernel_size != (1, 1):
+                m.weight.data = m.weight.data.contiguous(memory_format=fmt)
+        self.channels_last = bool(flag)
+        return self
 
     def forward(self, x, *args, **kwargs):
         if isinstance(x, dict):
@@ -176,7 +188,7 @@ class RTDETRDetectionWorldModel(nn.Module):
         head = self.model[-1]
         with torch.autocast('cuda', dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None,
                             cache_enabled=autocast_cache):
-            if _CHANNELS_LAST and x.is_cuda:
+            if self.channels_last and x.is_cuda:
                 x = x.contiguous(memory_format=torch.channels_last)
             from . import ops
             counters = ops.begin_bn_counter_batch() if self.training else None
@@ -223,9 +235,13 @@ class RTDETRDetectionWorldModel(nn.Module):
         dp = torch.ones(head.num_Blocks, 2, len(img), device=img.device)
         with torch.no_grad():
             _, shapes = self.token_memory(img, txt, drop_scales=dp)  # the level shapes (DropPath factors given: nothing is drawn)
-        graphed = GraphedPart(part, (img.detach(), txt.detach(), dp), warmup=warmup)
+        graphed = GraphedPart(part, (img.detach(), txt.detach(), dp), warmup=warmup, log=log)
         try:
+            import time
+            t0 = time.perf_counter()
             self.static_part_check = graphed.verify() if verify else None
+            if log is not None and verify:
+                log(f'graph capture: replay check against eager execution {time.perf_counter() - t0:.1f} s')
         finally:
             with torch.no_grad():
                 for b, v in zip(part.buffers(), saved):

@@ -65,7 +65,9 @@ def _seed(dst):
 def use_deterministic_convolutions(search=False):
     """The reference's `deterministic: True` (cfg/default.yaml:26 -> utils/torch_utils.py:371-389: cudnn.deterministic +
     use_deterministic_algorithms(warn_only)) for the MIOpen part of the step: ATen sets MIOpen's DETERMINISTIC convolution attribute,
-    under which the split-K / atomic-add solvers are not applicable.  search=True (TAMTR_DETERMINISTIC=1 runs): MIOpen's timed search
+    under which the split-K / atomic-add solvers are not applicable.  For NHWC bf16 convolutions that leaves MIOpen 3.5 with its naive
+    kernels only (17 s per 16-image step), so the deterministic mode runs the trunk NCHW (model._CHANNELS_LAST / set_channels_last(False):
+    0.25 s per step eager).  search=True (TAMTR_DETERMINISTIC=1 runs): MIOpen's timed search
     among the solvers that remain, kept in a persistent directory of its own (the shipped tables were chosen with the atomic solvers
     allowed and are not used) - without it MIOpen's heuristic falls back to its naive kernels for the weight gradients once its
     first choice is not applicable (measured: 17 s per 16-image step).  search=False: that heuristic (fine for a few small steps, as

@@ -255,6 +255,7 @@ def test_deterministic_mode_two_steps_are_bit_identical(pkg, case640, dtype):
     b = {k: dev(v) for k, v in c['batch'].items()}
     try:
         tuning.use_deterministic_convolutions()
+        model.set_channels_last(False)      # the deterministic mode's trunk layout (MIOpen: deterministic NHWC bf16 = naive kernels only)
         model.autocast_dtype = dtype
         runs = []
         with warnings.catch_warnings(record=True) as caught:
@@ -280,6 +281,7 @@ def test_deterministic_mode_two_steps_are_bit_identical(pkg, case640, dtype):
         assert not nondet, nondet
     finally:
         model.autocast_dtype = None
+        model.set_channels_last(True)
         torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = keep[0], keep[1]
         torch.use_deterministic_algorithms(keep[2], warn_only=keep[3])
         os.environ.pop('MIOPEN_DEBUG_CONVOLUTION_DETERMINISTIC', None)

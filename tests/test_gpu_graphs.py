@@ -77,13 +77,19 @@ def test_vss_and_projection_replay_equals_eager(pkg):
         assert worst[0] <= 2e-3, (rep, worst, noise)   # library GEMMs may pick another algorithm on the capture stream (measured 2.4e-4); garbage is > 1e-1
 
 
-def test_whole_static_part_replay_equals_eager_at_the_bench_configuration(pkg):
+@pytest.mark.parametrize('layout,B', [('nchw', 16), ('nhwc', 4)])
+def test_whole_static_part_replay_equals_eager_at_the_bench_configuration(pkg, layout, B):
     """The execution mode bench.py measures: trunk + VSS blocks + input projection (everything model.capture_static_part records) at
     640 x 640, 16 images, bf16, replayed SIX times (eager allocations between the forward and the backward replay, as decoder and loss
     make them) against eager execution of the same function on the same inputs and cotangent: the token memory and ALL 552 parameter
     gradients, per tensor as max |difference| / max |reference|, next to the eager run-to-run level of the same quantities (MIOpen's
     split-K / atomic solvers).  A replay gone wrong is off by > 1e-1 or NaN (profiles/r02_graph_capture_findings.txt); DropPath is ON:
-    its factors are an input of the recorded function (drawn once here)."""
+    its factors are an input of the recorded function (drawn once here).
+    Reproducible eager execution needs MIOpen's deterministic solvers, and for NHWC bf16 those are only its naive kernels (17 s per
+    16-image step): the 16-image case therefore runs the NCHW trunk (what TAMTR_DETERMINISTIC=1 selects), and the NHWC trunk - the
+    layout bench.py measures, with its own glue kernels inside the recorded graphs - runs with 4 images.  (bench.py holds its own
+    16-image NHWC capture to eager execution at the run-to-run level of the shipped solver tables: config.static_part_check,
+    config.graph_vs_eager.)"""
     import json, os
     from conftest import ROOT
     from tamtr_amd import tuning
@@ -94,18 +100,18 @@ def test_whole_static_part_replay_equals_eager_at_the_bench_configuration(pkg):
     # 2.0 - 2.9 per tensor), which would make the comparison meaningless
     tuning.use_deterministic_convolutions()
     try:
-        _whole_static_part_check(pkg, json, os, ROOT)
+        _whole_static_part_check(pkg, json, os, ROOT, layout, B)
     finally:
         torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = keep[0], keep[1]
         torch.use_deterministic_algorithms(keep[2], warn_only=keep[3])
         os.environ.pop('MIOPEN_DEBUG_CONVOLUTION_DETERMINISTIC', None)
 
 
-def _whole_static_part_check(pkg, json, os, ROOT):
+def _whole_static_part_check(pkg, json, os, ROOT, layout, B):
     torch.manual_seed(0)
-    model = pkg.model.RTDETRDetectionWorldModel(nc=10).cuda().train()
+    model = pkg.model.RTDETRDetectionWorldModel(nc=10).cuda().train().set_channels_last(layout == 'nhwc')
     model.autocast_dtype = torch.bfloat16
-    B, S = 16, 640
+    S = 640
     batch = {k: (dev(v) if k in ('img', 'txt_feats') else v) for k, v in _bench_batch(B, S, 1).items()}
     before = {k: v.clone() for k, v in model.state_dict().items()}
     rng = torch.cuda.get_rng_state()
@@ -117,13 +123,13 @@ def _whole_static_part_check(pkg, json, os, ROOT):
     gp = model._static[0]
     assert gp.n_live == 552 and len(gp.params) == 582
     gp.static_in[2].copy_(model.model[-1].draw_drop_scales(B, 'cuda'))      # a real DropPath draw (some factors 0, the others 1 / 0.9)
-    assert float(gp.static_in[2].min()) == 0.0 or B < 8
+    assert float(gp.static_in[2].min()) == 0.0 or B < 16
     chk = gp.verify(replays=6, tol=1e-3, noise_factor=4.0)
     rec = {k: v for k, v in chk.items() if k != 'replays'}
     rec['per_replay'] = chk['replays']
     out = os.path.join(ROOT, 'gpurun_out')
     if os.path.isdir(out):
-        json.dump(rec, open(os.path.join(out, 'graph_replay_check_640_bs16.json'), 'w'), indent=1)
+        json.dump(rec, open(os.path.join(out, f'graph_replay_check_640_{layout}_bs{B}.json'), 'w'), indent=1)
     print('static part replay check:', json.dumps(rec))
     assert chk['grads'] == 552 and chk['informative_grads'] == 552, rec   # on deterministic solvers EVERY gradient is reproducible in eager mode
     assert all(r['nonfinite_grads'] == 0 for r in chk['replays'])
