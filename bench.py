@@ -213,6 +213,7 @@ def main():
                          'tam-tr_amd/tuned/miopen (default), a fresh search (minutes), or its heuristic')
     ap.add_argument('--conv-db', default=None, help='directory the search writes its tables to (--conv-tuning search)')
     ap.add_argument('--grad-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire (N > 1)')
+    ap.add_argument('--no-graph-check', action='store_true', help='skip the graph-vs-eager step after the timed loop (profiling runs: keeps the trace to the timed steps)')
     ap.add_argument('--cpu-baseline-images', type=int, default=8, help='images of the CPU-oracle sample (BASELINE configs[0]: 8)')
     args = ap.parse_args()
 
@@ -326,7 +327,7 @@ def main():
         host_all = h.tolist()
     note(f'timed {args.steps} steps: {dt / args.steps * 1e3:.1f} ms/step (host CPU {max(host_all):.1f} ms/step)')
     gve = None
-    if static_part == 'hip-graph':   # the replayed path against kernel-by-kernel execution, at the end of the run (every rank: same work)
+    if static_part == 'hip-graph' and not args.no_graph_check:   # the replayed path against kernel-by-kernel execution, at the end of the run (every rank: same work)
         if reducer is None:
             opt.zero_grad(set_to_none=True)
         try:

@@ -717,204 +717,13 @@ __global__ __launch_bounds__(WS_T, 2) void linear_bf16_wstat_kernel(const bf16_t
 #undef WSTAMP
 }
 
-// =====================================================================================================================
-// W-STATIONARY, 64 COLUMNS PER WAVE (K = 512, N % 256 == 0).
-//
-// What holds the kernel above at ~45 % of the MFMA roof is LDS bandwidth: every one of its 8 waves reads the whole 32 KB X block as
-// B-fragments (one ds_read_b128 = 1 KB per MFMA of 32 cycles per SIMD = 128 B/clk per CU = the LDS pipe's peak), so the matrix
-// pipe can never be busy more than the LDS pipe lets it, and the LDS-DMA writes and bank conflicts come on top (measured: MFMA
-// busy 55.8 %, profiles/r02_gemm_pmc.json).  Here every X fragment feeds TWO MFMAs: a wave owns 64 output columns, i.e. 2 x 32
-// fragments of W = 256 registers (half of the 512-register budget of a wave that has its SIMD to itself), a workgroup is
-// 4 waves = 256 columns, one workgroup per CU.  LDS reads per block and CU drop from 256 KB to 128 KB.
-// With ONE wave per SIMD nothing else covers a stall, so the wave's instruction stream is laid out by hand as one continuous
-// chain of MFMAs (2 per k16 step, two independent accumulator tiles) with everything else slotted between them, one item per step:
-//   steps  0 ..  7   the previous block's epilogue (its accumulators are a second register set): 4 x (4 cvt_pk, 2 permlane32_swap,
-//                    1 buffer store - rows past M are dropped by the buffer's range check, no branch)
-//   steps  2 ..  9   block b+1, fetched during block b-1, goes from registers into the 3-slot LDS ring (8 ds_write_b128)
-//   steps 10 .. 17   block b+2 is requested: 8 plain 16-byte global loads (fire and forget; LDS-DMA parks the issuing wave ~260 cycles
-//                    per KiB piece, which two waves per SIMD could hide and one cannot)
-//   step  23         s_waitcnt lgkmcnt(0) + s_barrier: every wave's ds_writes of block b+1 are visible (no __syncthreads: its fence
-//                    would also drain the global loads and stores just issued)
-//   steps 24 .. 31   the ring re-fills continue into block b+1 (its first 8 fragments), so that the next chain starts without an LDS round trip
-// and every step re-fills the 8-entry fragment ring 8 steps ahead.  The order is pinned with sched_barrier(0) after every step.
-// Same bias-by-MFMA trick, fragment layouts, XOR swizzle and register epilogue as above.
-constexpr int W2_T = 256, W2_SLOTS = 3, W2_PF = 8;
-
-template <int KK>
-__global__ __launch_bounds__(W2_T, 1) void linear_bf16_wstat2_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
-                                                                      const float* __restrict__ bias, bf16_t* __restrict__ Y, int M,
-                                                                      int N, int ncol, int n_workers, int n_blocks) {
-  constexpr int RB = KK * 2;          // bytes per X row (1 KB)
-  constexpr int BLK = WS_ROWS * RB;   // bytes per block (32 KB)
-  constexpr int NKS = KK / 16;        // k16 steps (32)
-  constexpr int LPW = WS_ROWS / 4;    // rows (= 1-KB loads) per wave and block (8)
-  static_assert(RB == 1024 && NKS == 32 && LPW == 8 && W2_PF == 8, "the step table below is written for K = 512");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [W2_SLOTS blocks]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 31, lh = lane >> 5;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int colgrp = slot % ncol, worker = (slot / ncol) * 8 + xcd;
-  const int n0w = colgrp * WS_COLS + wave * 64;  // this wave's 64 output columns: tiles [n0w, +32) and [n0w + 32, +32)
-  const int my_blocks = worker < n_workers ? (n_blocks - worker + n_workers - 1) / n_workers : 0;
-  if (my_blocks == 0) return;  // (whole workgroups: no barrier is left waiting)
-
-  s16x8 wf[2][NKS + 1];
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) wf[c][ks] = *reinterpret_cast<const s16x8*>(W + (size_t)(n0w + 32 * c + lr) * KK + ks * 16 + lh * 8);
-    const float bv = (bias && lh == 0) ? bias[n0w + 32 * c + lr] : 0.f;
-    const bf16_t hi = f2bf(bv), lo = f2bf(bv - bf2f(hi));
-#pragma unroll
-    for (int j = 0; j < 8; ++j) wf[c][NKS][j] = 0;
-    wf[c][NKS][0] = (short)hi;
-    wf[c][NKS][1] = (short)lo;
-  }
-  s16x8 ones;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) ones[j] = 0;
-  if (lh == 0) { ones[0] = (short)0x3f80; ones[1] = (short)0x3f80; }
-
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // (native vectors: an array of HIP_vector_type structs stayed in scratch)
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)min((size_t)M * N * 2, (size_t)0x7ffffff0u), 0x00020000);
-  // staging: wave w carries rows w * 8 .. + 8 of a block, lane l the 16-byte chunk l of the row; it lands at chunk position l ^ (row & 15).
-  // Blocks past the worker's last one are fetched from clamped rows and written into ring slots nobody reads: no branches around memory ops.
-  u32x4 st[LPW];
-#define W2_ROW0(bi_) ((worker + (bi_) * n_workers) * WS_ROWS)
-  // (lane-derived offsets go through opaque per-block copies ln_ / lr_ / lh_: as loop invariants they are hoisted out of the block loop
-  // into ~50 registers that this kernel does not have)
-#define W2_FETCH1(bi_, j_) st[j_] = *reinterpret_cast<const u32x4*>(X + (size_t)min(W2_ROW0(bi_) + wave * LPW + (j_), M - 1) * KK + ln_ * 8);
-#define W2_STASH1(bi_, j_)                                                                                                  \
-  *reinterpret_cast<u32x4*>(smem + ((bi_) % W2_SLOTS) * BLK + (wave * LPW + (j_)) * RB + ((ln_ ^ ((wave * LPW + (j_)) & 15)) << 4)) = st[j_];
-#define W2_FRAG(bi_, f_) (*reinterpret_cast<const s16x8*>(smem + ((bi_) % W2_SLOTS) * BLK + lr_ * RB + ((((f_) * 2 + lh_) ^ (lr_ & 15)) << 4)))
-  // one quarter of a block's epilogue: tile c, column half p (accumulator layout as in the 32-column kernel)
-#define W2_EPI(bi_, ACC, c_, p_)                                                                                            \
-  {                                                                                                                         \
-    const uint32_t k0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{ACC[8 * (p_)], ACC[8 * (p_) + 1]}, bf16x2));           \
-    const uint32_t k1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{ACC[8 * (p_) + 2], ACC[8 * (p_) + 3]}, bf16x2));       \
-    const uint32_t k2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{ACC[8 * (p_) + 4], ACC[8 * (p_) + 5]}, bf16x2));       \
-    const uint32_t k3 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{ACC[8 * (p_) + 6], ACC[8 * (p_) + 7]}, bf16x2));       \
-    const auto r0 = __builtin_amdgcn_permlane32_swap(k0, k2, false, false);                                                 \
-    const auto r1 = __builtin_amdgcn_permlane32_swap(k1, k3, false, false);                                                 \
-    const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};                                                                           \
-    decltype(__builtin_amdgcn_raw_buffer_load_b128(yrs, 0, 0, 0)) w128;                                                     \
-    __builtin_memcpy(&w128, &v, sizeof(v));                                                                                 \
-    const int gm_ = W2_ROW0(bi_) + lr_;                                                                                     \
-    const unsigned off_ = ((bi_) >= 0 && gm_ < M) ? (unsigned)(((size_t)gm_ * N + n0w + 32 * (c_) + 16 * (p_) + 8 * lh_) * 2) : 0x7ffffff0u; \
-    __builtin_amdgcn_raw_buffer_store_b128(w128, yrs, off_, 0, 0);                                                          \
-  }
-#define W2_FENCE __builtin_amdgcn_sched_barrier(0);
-  // k16 step ks of block bi: two MFMAs on fragment xf[ks % 8], then that ring entry is re-filled with fragment ks + 8 - of this block, or
-  // (steps 24 .. 31, behind the barrier) with fragment ks - 24 of the next one, which is exactly where the next block's step ks - 24 looks
-#define W2_STEP(bi, ks, C0, C1)                                                                                             \
-  C0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], xf[(ks) % W2_PF], C0, 0, 0, 0);                                   \
-  C1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][ks], xf[(ks) % W2_PF], C1, 0, 0, 0);                                   \
-  xf[(ks) % W2_PF] = (ks) + W2_PF < NKS ? W2_FRAG(bi, (ks) + W2_PF) : W2_FRAG((bi) + 1, (ks) + W2_PF - NKS);
-  // the whole block: see the step table in the header
-#define W2_BODY(bi, C0, C1, P0, P1)                                                                                         \
-  {                                                                                                                         \
-    int ln_ = lane, lr_ = lr, lh_ = lh;                                                                                     \
-    asm volatile("" : "+v"(ln_), "+v"(lr_), "+v"(lh_));                                                                     \
-    _Pragma("unroll") for (int q = 0; q < 16; ++q) { C0[q] = 0.f; C1[q] = 0.f; }                                            \
-    C0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][NKS], ones, C0, 0, 0, 0); /* bias */                                 \
-    C1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][NKS], ones, C1, 0, 0, 0);                                            \
-    W2_FENCE                                                                                                                \
-    W2_STEP(bi, 0, C0, C1) W2_EPI((bi) - 1, P0, 0, 0) W2_FENCE                                                          \
-    W2_STEP(bi, 1, C0, C1) W2_FENCE                                                                                     \
-    W2_STEP(bi, 2, C0, C1) W2_EPI((bi) - 1, P0, 0, 1) W2_STASH1((bi) + 1, 0) W2_FENCE                                   \
-    W2_STEP(bi, 3, C0, C1) W2_STASH1((bi) + 1, 1) W2_FENCE                                                              \
-    W2_STEP(bi, 4, C0, C1) W2_EPI((bi) - 1, P1, 1, 0) W2_STASH1((bi) + 1, 2) W2_FENCE                                   \
-    W2_STEP(bi, 5, C0, C1) W2_STASH1((bi) + 1, 3) W2_FENCE                                                              \
-    W2_STEP(bi, 6, C0, C1) W2_EPI((bi) - 1, P1, 1, 1) W2_STASH1((bi) + 1, 4) W2_FENCE                                   \
-    W2_STEP(bi, 7, C0, C1) W2_STASH1((bi) + 1, 5) W2_FENCE                                                              \
-    W2_STEP(bi, 8, C0, C1) W2_STASH1((bi) + 1, 6) W2_FENCE                                                              \
-    W2_STEP(bi, 9, C0, C1) W2_STASH1((bi) + 1, 7) W2_FENCE                                                              \
-    W2_STEP(bi, 10, C0, C1) W2_FETCH1((bi) + 2, 0) W2_FENCE                                                             \
-    W2_STEP(bi, 11, C0, C1) W2_FETCH1((bi) + 2, 1) W2_FENCE                                                             \
-    W2_STEP(bi, 12, C0, C1) W2_FETCH1((bi) + 2, 2) W2_FENCE                                                             \
-    W2_STEP(bi, 13, C0, C1) W2_FETCH1((bi) + 2, 3) W2_FENCE                                                             \
-    W2_STEP(bi, 14, C0, C1) W2_FETCH1((bi) + 2, 4) W2_FENCE                                                             \
-    W2_STEP(bi, 15, C0, C1) W2_FETCH1((bi) + 2, 5) W2_FENCE                                                             \
-    W2_STEP(bi, 16, C0, C1) W2_FETCH1((bi) + 2, 6) W2_FENCE                                                             \
-    W2_STEP(bi, 17, C0, C1) W2_FETCH1((bi) + 2, 7) W2_FENCE                                                             \
-    W2_STEP(bi, 18, C0, C1) W2_FENCE                                                                                    \
-    W2_STEP(bi, 19, C0, C1) W2_FENCE                                                                                    \
-    W2_STEP(bi, 20, C0, C1) W2_FENCE                                                                                    \
-    W2_STEP(bi, 21, C0, C1) W2_FENCE                                                                                    \
-    W2_STEP(bi, 22, C0, C1) W2_FENCE                                                                                    \
-    W2_STEP(bi, 23, C0, C1)                                                                                             \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave's ring writes (steps 2 .. 9) have landed */             \
-    __builtin_amdgcn_s_barrier();                       /* ... and everybody's: block bi + 1 is readable   */               \
-    W2_FENCE                                                                                                                \
-    W2_STEP(bi, 24, C0, C1) W2_FENCE                                                      \
-    W2_STEP(bi, 25, C0, C1) W2_FENCE                                                      \
-    W2_STEP(bi, 26, C0, C1) W2_FENCE                                                      \
-    W2_STEP(bi, 27, C0, C1) W2_FENCE                                                      \
-    W2_STEP(bi, 28, C0, C1) W2_FENCE                                                      \
-    W2_STEP(bi, 29, C0, C1) W2_FENCE                                                      \
-    W2_STEP(bi, 30, C0, C1) W2_FENCE                                                      \
-    W2_STEP(bi, 31, C0, C1) W2_FENCE                                                      \
-  }
-
-  // ---- prologue: block 0 into the ring, block 1 requested, the first fragments of block 0 read
-  const int ln_ = lane, lr_ = lr, lh_ = lh;
-#pragma unroll
-  for (int j = 0; j < LPW; ++j) { W2_FETCH1(0, j) }
-#pragma unroll
-  for (int j = 0; j < LPW; ++j) { W2_STASH1(0, j) }
-#pragma unroll
-  for (int j = 0; j < LPW; ++j) { W2_FETCH1(1, j) }
-  __syncthreads();
-  s16x8 xf[W2_PF];
-#pragma unroll
-  for (int f = 0; f < W2_PF; ++f) xf[f] = W2_FRAG(0, f);
-  f32x16 a0, a1, b0, b1;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) { b0[q] = 0.f; b1[q] = 0.f; }
-  W2_FENCE
-  // two blocks per trip so that the two accumulator / fragment register sets keep fixed roles; an odd count runs one block of
-  // clamped loads and dropped stores at the end
-  const int trips = (my_blocks + 1) / 2;
-  for (int t = 0; t < trips; ++t) {
-    const int bi = 2 * t;
-    W2_BODY(bi, a0, a1, b0, b1)
-    W2_BODY(bi + 1, b0, b1, a0, a1)
-  }
-  // the last block's epilogue (block 2 * trips - 1; dropped if it does not exist: its rows are past M only when ... see below)
-  {
-    const int bl = 2 * trips - 1;
-    const int live = bl < my_blocks ? bl : -1;   // an odd block count: the padding block's results are not stored
-    W2_EPI(live, b0, 0, 0) W2_EPI(live, b0, 0, 1) W2_EPI(live, b1, 1, 0) W2_EPI(live, b1, 1, 1)
-  }
-#undef W2_BODY
-#undef W2_STEP
-#undef W2_FENCE
-#undef W2_EPI
-#undef W2_FRAG
-#undef W2_STASH1
-#undef W2_FETCH1
-#undef W2_ROW0
-}
-
 }  // namespace
 
 extern "C" int tamtr_linear_bf16(const void* X, const void* W, const float* bias, void* Y, int M, int N, int K, void* stream) {
   if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return TAMTR_EINVAL;
   if (K % BK || N % BN) return TAMTR_EUNSUP;
-  // kernel choice (A/B switch TAMTR_GEMM = ws2 | ws1 | tile), read once when the library is loaded - not per call
-  static const int choice = [] { const char* e = getenv("TAMTR_GEMM"); return !e ? 2 : e[0] == 't' ? 0 : (e[0] == 'w' && e[1] == 's' && e[2] == '1') ? 1 : 2; }();
-  if (choice == 2 && K == 512 && N % WS_COLS == 0 && 32 % (N / WS_COLS) == 0 && (size_t)M * N * 2 < 0x7ffffff0u) {
-    // 64 columns per wave: 256 workgroups of 4 waves, one per CU
-    const int ncol = N / WS_COLS, n_workers = (32 / ncol) * 8, n_blocks = (M + WS_ROWS - 1) / WS_ROWS;
-    const size_t lds = (size_t)W2_SLOTS * WS_ROWS * K * 2;
-    if (hipFuncSetAttribute((const void*)linear_bf16_wstat2_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return TAMTR_ELAUNCH;   // (per call: the attribute is per device, and this is a few hundred nanoseconds)
-    hipLaunchKernelGGL(linear_bf16_wstat2_kernel<512>, dim3(256), dim3(W2_T), lds, (hipStream_t)stream, (const bf16_t*)X, (const bf16_t*)W,
-                       bias, (bf16_t*)Y, M, N, ncol, n_workers, n_blocks);
-    return tamtr_launch_status();
-  }
+  // kernel choice (A/B switch TAMTR_GEMM = ws1 | tile), read once when the library is loaded - not per call
+  static const int choice = [] { const char* e = getenv("TAMTR_GEMM"); return (e && e[0] == 't') ? 0 : 1; }();
   if (choice >= 1 && (K == 512 || K == 256 || K == 128) && N % WS_COLS == 0 && 32 % (N / WS_COLS) == 0) {
     // W-stationary: 256 persistent workgroups, N / 256 of them (same XCD) per row block
     const int ncol = N / WS_COLS, n_workers = (32 / ncol) * 8, n_blocks = (M + WS_ROWS - 1) / WS_ROWS;

@@ -3,7 +3,7 @@
 tag=${1:-x}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_step
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_step -o st --output-format csv -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_step_bench.json 2> gpurun_out/prof_step_bench.err
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_step -o st --output-format csv -- python3 bench.py --no-cpu-baseline --no-graph-check > gpurun_out/prof_step_bench.json 2> gpurun_out/prof_step_bench.err
 ms=$(python3 -c "import json; print(json.load(open('gpurun_out/prof_step_bench.json'))['ms_per_step'])")
 python3 tools/prof_summary.py gpurun_out/prof_step/st_kernel_trace.csv 10 $ms 70 > gpurun_out/prof_step_$tag.txt
 python3 tools/gemm_launches.py gpurun_out/prof_step/st_kernel_trace.csv 10 $ms > gpurun_out/prof_step_${tag}_gemm_launches.txt
