@@ -5,6 +5,7 @@ Data layout in HBM: the three input maps go VSSBlock (NHWC) -> 1x1 conv+BN -> fl
 value projections and the gather kernels all read that one buffer.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -14,6 +15,10 @@ from . import ops
 from .loss import get_cdn_group
 from .modules import ContrastiveHeadMLP, DeformableTransformerDecoderLayer, MLP, TextDeformableTransformerDecoder
 from .vss import TallLinear, VSSBlock
+
+
+_VSS_STREAMS = os.environ.get('TAMTR_VSS_STREAMS', '1') != '0'
+_SIDE_STREAMS = {}
 
 
 class ManbaWorldDecoder(nn.Module):
@@ -60,12 +65,42 @@ class ManbaWorldDecoder(nn.Module):
         return torch.stack([blk.draw_drop_scales(n, device) for blk in self.VSSBlocks])
 
     def encode(self, x, drop_scales=None):
-        """The three trunk maps -> the token memory `feats` [B, L, hd] and the level shapes.  Shapes depend on the image size only."""
+        """The three trunk maps -> the token memory `feats` [B, L, hd] and the level shapes.  Shapes depend on the image size only.
+        The levels are independent of each other up to the concatenation.  On the GPU the finest level (the most work) runs on the
+        current stream and the other two, one after the other, on a side stream: their kernels fill the wave slots that the finest
+        level's scans leave idle (the scan forward holds 512 workgroups where 768 fit; the scan backward's workgroups finish in two
+        groups 2.6 ms apart and half of the chip waits for the late one).  Autograd runs every backward node on its forward's stream,
+        so the backward overlaps the same way, and a recorded graph keeps the two branches.  TAMTR_VSS_STREAMS=0: one stream."""
         # VSS blocks run channels-last ([B,H,W,C], head.py:1136-1140); their outputs stay token-major: the 1x1 input projection
         # is a GEMM over tokens and its result is already in the [B, L, hd] layout of the token memory
-        toks = [blk(f.permute(0, 2, 3, 1)) if drop_scales is None else blk(f.permute(0, 2, 3, 1), drop_scales[i])
-                for i, (blk, f) in enumerate(zip(self.VSSBlocks, x))]
-        return self._get_encoder_input(toks)
+        def level(i):
+            f = x[i].permute(0, 2, 3, 1)
+            tok = self.VSSBlocks[i](f) if drop_scales is None else self.VSSBlocks[i](f, drop_scales[i])
+            return self._project_level(i, tok)
+        n = len(x)
+        if not (_VSS_STREAMS and n > 1 and x[0].is_cuda):
+            outs = [level(i) for i in range(n)]
+        else:
+            main = torch.cuda.current_stream()
+            side = self._side_stream(x[0].device)
+            side.wait_stream(main)
+            outs = [None] * n
+            with torch.cuda.stream(side):
+                for i in range(1, n):
+                    x[i].record_stream(side)          # produced on `main`, read here: keep its block out of main's free list until then
+                    outs[i] = level(i)
+            outs[0] = level(0)
+            main.wait_stream(side)
+            for i in range(1, n):
+                outs[i][0].record_stream(main)        # produced on `side`, read by the concatenation on `main`
+        return torch.cat([o[0] for o in outs], 1), [o[1] for o in outs]
+
+    @staticmethod
+    def _side_stream(device):
+        st = _SIDE_STREAMS.get(device)     # (per device, not on the module: modules get deep-copied - EMA - and pickled)
+        if st is None:
+            st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+        return st
 
     def decode(self, feats, shapes, text, batch=None):
         dn_embed, dn_bbox, attn_mask, dn_meta = get_cdn_group(batch, self.nc, self.num_queries,
@@ -102,30 +137,30 @@ class ManbaWorldDecoder(nn.Module):
         return a.to(dtype), valid
 
     def _get_encoder_input(self, toks):
-        """input_proj (Conv1x1 no bias + BatchNorm, head.py:1087) on channels-last tokens + concatenation over the levels
-        (head.py:1202-1219).  toks: list of [B, H, W, C].  A 1x1 convolution IS a per-token linear map, so it runs as a
-        [B*H*W, C] x [C, hd] GEMM (bf16: the MFMA kernel) and BatchNorm takes its batch statistics over the token axis -
-        no NCHW round trip, no transposing concatenation."""
-        feats, shapes = [], []
-        for proj, t in zip(self.input_proj, toks):
-            conv, bn = proj[0], proj[1]
-            B, H, W, C = t.shape
-            t2 = t.reshape(B * H * W, C)
-            w = conv.weight.view(conv.out_channels, C)
-            if t2.is_cuda and t2.dtype == torch.bfloat16 and C % 64 == 0 and conv.out_channels % 128 == 0:
-                y = ops.linear_bf16(t2, w, None)
-            else:
-                y = torch.nn.functional.linear(t2, w.to(t2.dtype))
-            C2 = y.shape[1]
-            if y.is_cuda and bn.training and ops.bn_cl_ok(C2, y.dtype):
-                y = ops.bn_act(y, bn, False)  # channels-last BatchNorm kernels (csrc/bn.hip)
-            else:
-                if bn.training and bn.track_running_stats:
-                    bn.num_batches_tracked += 1
-                y = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
-            feats.append(y.view(B, H * W, -1))
-            shapes.append([H, W])
-        return torch.cat(feats, 1), shapes
+        """input_proj on channels-last tokens + concatenation over the levels (head.py:1202-1219).  toks: list of [B, H, W, C]."""
+        outs = [self._project_level(i, t) for i, t in enumerate(toks)]
+        return torch.cat([o[0] for o in outs], 1), [o[1] for o in outs]
+
+    def _project_level(self, i, t):
+        """input_proj[i] (Conv1x1 no bias + BatchNorm, head.py:1087) on channels-last tokens t [B, H, W, C] -> ([B, H*W, hd], [H, W]).
+        A 1x1 convolution IS a per-token linear map, so it runs as a [B*H*W, C] x [C, hd] GEMM (bf16: the MFMA kernel) and BatchNorm
+        takes its batch statistics over the token axis - no NCHW round trip, no transposing concatenation."""
+        conv, bn = self.input_proj[i][0], self.input_proj[i][1]
+        B, H, W, C = t.shape
+        t2 = t.reshape(B * H * W, C)
+        w = conv.weight.view(conv.out_channels, C)
+        if t2.is_cuda and t2.dtype == torch.bfloat16 and C % 64 == 0 and conv.out_channels % 128 == 0:
+            y = ops.linear_bf16(t2, w, None)
+        else:
+            y = torch.nn.functional.linear(t2, w.to(t2.dtype))
+        C2 = y.shape[1]
+        if y.is_cuda and bn.training and ops.bn_cl_ok(C2, y.dtype):
+            y = ops.bn_act(y, bn, False)  # channels-last BatchNorm kernels (csrc/bn.hip)
+        else:
+            if bn.training and bn.track_running_stats:
+                bn.num_batches_tracked += 1
+            y = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
+        return y.view(B, H * W, -1), [H, W]
 
     def _get_decoder_input(self, feats, shapes, dn_embed=None, dn_bbox=None, text=None):
         bs = feats.shape[0]
