@@ -185,15 +185,17 @@ int tamtr_selective_scan_bwd(const float* gy, const float* u, const float* delta
 /*      Fused dt projection (replaces the `dts = einsum("bkrl,kdr->bkdl")` of SS2D.forward_corev2, vmamba.py:972, whose
  *      [B, 4*d_inner, L] result is never materialised): delta[b, k*Dk+d, t] = sum_r Wdt[k*Dk+d, r] * dtr[b, k, r, t] is formed
  *      inside the scan.  dtr f32 [B, K, R, L], Wdt f32 [KD, R], R <= 32.  Backward additionally returns gdtr f32 [B,K,R,L]
- *      (plain stores) and d(Wdt) inside grow (see above); gdelta_ws: caller workspace [B,KD,L].
+ *      (plain stores) and d(Wdt) inside grow (see above); gdelta_ws: caller workspace [B,KD,L] - f32, or bf16 with ws_bf16 = 1 (L % 4 == 0):
+ *      d(delta) is only the operand of gdtr = Wdt^T d(delta) there, so in bf16 mode - where the caller rounds gdtr to bf16 anyway - the
+ *      workspace, the largest buffer the backward writes and re-reads, can be half the size.
  */
 int tamtr_selective_scan_dtproj_fwd(const float* u, const float* dtr, const float* Wdt, const float* A, const float* Bm,
                                     const float* Cm, const float* D, const float* dbias, float* y, float* hstate, int B, int K,
                                     int Dk, int N, int R, int L, int xmode, void* stream);
 int tamtr_selective_scan_dtproj_bwd(const float* gy, const float* u, const float* dtr, const float* Wdt, const float* A,
                                     const float* Bm, const float* Cm, const float* D, const float* dbias, const float* hstate,
-                                    float* gu, float* gdelta_ws, float* gdtr, float* grow, float* gB, float* gC, float* ws, int B,
-                                    int K, int Dk, int N, int R, int L, int xmode, void* stream);
+                                    float* gu, void* gdelta_ws, float* gdtr, float* grow, float* gB, float* gC, float* ws, int B,
+                                    int K, int Dk, int N, int R, int L, int xmode, int ws_bf16, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * a-10 / next-4  Device-side Hungarian assignment.  Replaces `C.cpu()` + scipy.optimize.linear_sum_assignment per

@@ -41,7 +41,7 @@ _SIGS = {
     'tamtr_selective_scan_row_sums': [],
     'tamtr_selective_scan_bwd': [_P] * 15 + [_I, _I, _I, _I, _I, _I, _P],
     'tamtr_selective_scan_dtproj_fwd': [_P] * 10 + [_I] * 7 + [_P],
-    'tamtr_selective_scan_dtproj_bwd': [_P] * 17 + [_I] * 7 + [_P],
+    'tamtr_selective_scan_dtproj_bwd': [_P] * 17 + [_I] * 8 + [_P],
     'tamtr_lsap_assign': [_P, _P, _I, _I, _I, _P, _P, _P, _P],
     'tamtr_img_augment_u8': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'tamtr_cpam_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -184,20 +184,28 @@ struct SliceTab {
 template <typename ET, int LPR>  // LPR lanes per row, 8 channels each
 __global__ __launch_bounds__(MSDA_SORT_THREADS) void msda_gvalue_sorted_kernel(const ET* __restrict__ gout, const float* __restrict__ loc,
                                                                                 const float* __restrict__ aw, ET* __restrict__ gvalue,
-                                                                                Levels lv, SliceTab tab, int L, int M, int D, int Q,
+                                                                                Levels lv, SliceTab tab, int B, int L, int M, int D, int Q,
                                                                                 int nl, int P, int NS, long long ldg) {
   __shared__ uint32_t keys[MSDA_MAX_KEYS];
   __shared__ float wts[MSDA_MAX_KEYS];
   __shared__ uint16_t first_key[MSDA_SLICE_ROWS + 2];
   const int tid = threadIdx.x;
-  const int m = blockIdx.y, b = blockIdx.z;
+  // workgroup id -> (image, slice, head), XCD-aware: the hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so
+  // id = xcd + 8 * (m + M * t) puts the M heads of one (image, slice) on ONE XCD, back to back in dispatch order.  Their stores are the M
+  // 128-byte pieces of the same 1 KB token rows: meeting in one L2 they leave for HBM as whole rows (with the heads spread over the
+  // XCDs every 128-byte line went out alone: 1.5 TB/s).
+  const int nslices = tab.first[nl];
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int m = q % M, bs = (q / M) * 8 + xcd;   // bs = b * nslices + slice
+  if (bs >= B * nslices) return;                  // (grid padded to a multiple of 8 (image, slice) pairs; whole workgroups leave)
+  const int b = bs / nslices, sl = bs - b * nslices;
   int l = 0;
-  while (l + 1 < nl && (int)blockIdx.x >= tab.first[l + 1]) ++l;
+  while (l + 1 < nl && sl >= tab.first[l + 1]) ++l;
   const int H = lv.H[l], W = lv.W[l];
   const int rows = H * W;
   const int nsl = tab.first[l + 1] - tab.first[l];
   const int per = (rows + nsl - 1) / nsl;
-  const int lo = ((int)blockIdx.x - tab.first[l]) * per;
+  const int lo = (sl - tab.first[l]) * per;
   const int hi = min(lo + per, rows);
   // ---- the level's corners of this (image, head)
   const int n_pts = Q * P;
@@ -404,10 +412,12 @@ extern "C" int tamtr_msdeform_attn_bwd_sorted(const void* gout, const void* valu
 #undef PICK
 #undef GO
   }
-  dim3 grid((unsigned)tab.first[nl], (unsigned)M, (unsigned)B);
+  const long long pairs = ((long long)B * tab.first[nl] + 7) / 8 * 8;   // (image, slice) pairs, padded to the 8 XCDs
+  if (pairs * M > 0x7fffffffLL) return TAMTR_EUNSUP;
+  dim3 grid((unsigned)(pairs * M));
 #define GO(ET, LPR)                                                                                                          \
   hipLaunchKernelGGL((msda_gvalue_sorted_kernel<ET, LPR>), grid, dim3(MSDA_SORT_THREADS), 0, s, (const ET*)gout, loc, aw, (ET*)gvalue, lv, \
-                     tab, L, M, D, Q, nl, P, NS, ldg)
+                     tab, B, L, M, D, Q, nl, P, NS, ldg)
 #define PICK(ET)                                                                                                             \
   if (D <= 8) GO(ET, 1); else if (D <= 16) GO(ET, 2); else if (D <= 32) GO(ET, 4); else if (D <= 64) GO(ET, 8);              \
   else if (D <= 128) GO(ET, 16); else GO(ET, 32)

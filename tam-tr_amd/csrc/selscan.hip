@@ -102,6 +102,17 @@ __device__ __forceinline__ void store4(float* __restrict__ rowp, int t, int L, c
   }
 }
 
+// the same for a row of bf16 (the d(delta) workspace of the bf16 mode): 4 values = 8 bytes per lane; L % 4 == 0 only
+__device__ __forceinline__ void store4_bf16(bf16_t* __restrict__ rowp, int t, int L, const float (&v)[ITEMS], bool rev) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rowp, 0, L * 2, 0x00020000);
+  float o[ITEMS];
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) o[i] = rev ? v[ITEMS - 1 - i] : v[i];
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 w = {(uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16), (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16)};
+  __builtin_amdgcn_raw_buffer_store_b64(w, rs, t < L ? (rev ? L - 4 - t : t) * 2 : OOB, 0, 0);
+}
+
 // DPP move: lanes without a valid source (row edge / masked row) keep `old`
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ float dpp(float old, float src) {
@@ -459,7 +470,9 @@ __device__ __forceinline__ float bwd_fetch_param(const float* __restrict__ Am, c
 
 // Backward: BWD_WAVES waves x BWD_RPW rows each = BWD_ROWS rows of one (b, k) group per workgroup.
 // SETS: 16-value sets of d(Wdt) factors per row (0: materialised delta, no dt projection; 1: rank <= 16; 2: rank <= 32)
-template <bool VEC, int SETS>
+// GD16: d(delta) is written as bf16 (dt-projection variant in bf16 mode: it is only the operand of gdtr = Wdt^T gdelta, whose result
+// the caller rounds to bf16 anyway; halves the 5.9 GB per step that this workspace is written and read)
+template <bool VEC, int SETS, bool GD16 = false>
 __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
     const float* __restrict__ gy, const float* __restrict__ u, const float* __restrict__ delta, const float* __restrict__ Am,
     const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ Dv, const float* __restrict__ dbias,
@@ -645,7 +658,8 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
         dD = fmaf(g[i], uu[i], dD);
       }
       store4<VEC>(gu + row * L, t, L, du, rev);  // gu is always [B, K*Dk, L]; the host folds direction pairs in xmode
-      store4<VEC>(gdelta + row * L, t, L, gd, rev);
+      if (GD16) store4_bf16(reinterpret_cast<bf16_t*>(gdelta) + row * L, t, L, gd, rev);
+      else store4<VEC>(gdelta + row * L, t, L, gd, rev);
       // ---- per-row sums over the chunk's steps by reduce-scatter, two sets of 16 values at a time: the 16 dA_n travel with the
       // first 16 d(Wdt) factors (gWdt[kd, q] += sum_t gdelta_t * dtr[q, t]); at ranks > 16 the other factors with (dD, d(bias))
       float* acc = s_acc + wr * ACC;
@@ -800,7 +814,7 @@ __global__ __launch_bounds__(256) void dtproj_gdtr_scalar_kernel(const float* __
   }
 }
 
-template <int RT>
+template <int RT, bool G16>
 __global__ __launch_bounds__(256) void dtproj_gdtr_kernel(const float* __restrict__ gdelta, const float* __restrict__ Wdt,
                                                           float* __restrict__ gdtr, int K, int Dk, int R, int L, size_t zstride) {
   __shared__ float sW[64][RT];
@@ -811,6 +825,7 @@ __global__ __launch_bounds__(256) void dtproj_gdtr_kernel(const float* __restric
 #pragma unroll
   for (int r = 0; r < RT; ++r) acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f;
   const float* gp = gdelta + (size_t)bk * Dk * L;
+  const bf16_t* gp16 = reinterpret_cast<const bf16_t*>(gdelta) + (size_t)bk * Dk * L;
   // gridDim.z > 1: the Dk rows are split over z (short sequences alone do not fill the chip: L = 1600 gives 2 x 64 workgroups);
   // slice z then writes its partial into slab z of `gdtr` (a workspace of gridDim.z slabs of zstride floats), summed afterwards in
   // slab order by slab_sum1_kernel (round 2: float atomics into a zeroed gdtr)
@@ -826,7 +841,13 @@ __global__ __launch_bounds__(256) void dtproj_gdtr_kernel(const float* __restric
     if (live) {
       const int dn = min(64, dend - d0);
       for (int dd = 0; dd < dn; ++dd) {
-        const float4 g = *reinterpret_cast<const float4*>(gp + (size_t)(d0 + dd) * L + l0);
+        float4 g;
+        if (G16) {
+          const uint2 h = *reinterpret_cast<const uint2*>(gp16 + (size_t)(d0 + dd) * L + l0);
+          g = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xffff0000u));
+        } else {
+          g = *reinterpret_cast<const float4*>(gp + (size_t)(d0 + dd) * L + l0);
+        }
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
           const float w = sW[dd][r];
@@ -889,7 +910,7 @@ extern "C" int tamtr_selective_scan_dtproj_fwd(const float* u, const float* dtr,
 static int scan_bwd_launch(const float* gy, const float* u, const float* delta, const float* dtr, const float* Wdt, int R,
                            const float* A, const float* Bm, const float* Cm, const float* D, const float* dbias, const float* hstate,
                            float* gu, float* gdelta, float* gdtr, float* grow, float* gB, float* gC, float* ws, int B, int K, int Dk,
-                           int N, int L, int xmode, void* stream);
+                           int N, int L, int xmode, int gd16, void* stream);
 
 extern "C" int tamtr_selective_scan_row_sums(void) { return ACC; }
 
@@ -899,22 +920,24 @@ extern "C" int tamtr_selective_scan_bwd(const float* gy, const float* u, const f
                                         int xmode, void* stream) {
   if (!delta) return TAMTR_EINVAL;
   return scan_bwd_launch(gy, u, delta, nullptr, nullptr, 0, A, Bm, Cm, D, dbias, hstate, gu, gdelta, nullptr, grow, gB, gC, ws, B, K, Dk,
-                         N, L, xmode, stream);
+                         N, L, xmode, 0, stream);
 }
 
 extern "C" int tamtr_selective_scan_dtproj_bwd(const float* gy, const float* u, const float* dtr, const float* Wdt, const float* A,
                                                const float* Bm, const float* Cm, const float* D, const float* dbias,
-                                               const float* hstate, float* gu, float* gdelta_ws, float* gdtr, float* grow, float* gB,
-                                               float* gC, float* ws, int B, int K, int Dk, int N, int R, int L, int xmode, void* stream) {
-  if (!dtr || !Wdt || !gdtr) return TAMTR_EINVAL;
-  return scan_bwd_launch(gy, u, nullptr, dtr, Wdt, R, A, Bm, Cm, D, dbias, hstate, gu, gdelta_ws, gdtr, grow, gB, gC, ws, B, K, Dk, N, L,
-                         xmode, stream);
+                                               const float* hstate, float* gu, void* gdelta_ws, float* gdtr, float* grow, float* gB,
+                                               float* gC, float* ws, int B, int K, int Dk, int N, int R, int L, int xmode, int ws_bf16,
+                                               void* stream) {
+  if (!dtr || !Wdt || !gdtr || (ws_bf16 != 0 && ws_bf16 != 1)) return TAMTR_EINVAL;
+  if (ws_bf16 && L % 4) return TAMTR_EUNSUP;
+  return scan_bwd_launch(gy, u, nullptr, dtr, Wdt, R, A, Bm, Cm, D, dbias, hstate, gu, (float*)gdelta_ws, gdtr, grow, gB, gC, ws, B, K, Dk, N,
+                         L, xmode, ws_bf16, stream);
 }
 
 static int scan_bwd_launch(const float* gy, const float* u, const float* delta, const float* dtr, const float* Wdt, int R,
                            const float* A, const float* Bm, const float* Cm, const float* D, const float* dbias, const float* hstate,
                            float* gu, float* gdelta, float* gdtr, float* grow, float* gB, float* gC, float* ws, int B, int K, int Dk,
-                           int N, int L, int xmode, void* stream) {
+                           int N, int L, int xmode, int gd16, void* stream) {
   if (!gy || !u || (!delta && !dtr) || !A || !Bm || !Cm || !D || !dbias || !hstate || !gu || !gdelta || !grow || !gB || !gC || !ws ||
       B <= 0 || K <= 0 || Dk <= 0 || L <= 0)
     return TAMTR_EINVAL;
@@ -931,14 +954,20 @@ static int scan_bwd_launch(const float* gy, const float* u, const float* delta, 
   // B/C tiles | rank-R dt factors | Wdt rows | per-row sums | carry: 78 KB at rank 32, two workgroups per CU
   const size_t dyn = ((size_t)2 * NS * CHUNK + (size_t)R * CHUNK + (size_t)BWD_ROWS * (RMAX + ACC + NS)) * sizeof(float);
 #define LAUNCH_BWD(VEC, SETS)                                                                                                          \
-  hipLaunchKernelGGL((selscan_bwd_kernel<VEC, SETS>), grid, dim3(BWD_WAVES * WAVE), dyn, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu, \
+  hipLaunchKernelGGL((selscan_bwd_kernel<VEC, SETS, false>), grid, dim3(BWD_WAVES * WAVE), dyn, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu, \
                      gdelta, grow, wsB, wsC, K, Dk, L, nchunk, slab, xmode, dtr, Wdt, R)
-  if (L % 4 == 0) {
+#define LAUNCH_BWD16(SETS)                                                                                                             \
+  hipLaunchKernelGGL((selscan_bwd_kernel<true, SETS, true>), grid, dim3(BWD_WAVES * WAVE), dyn, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu, \
+                     gdelta, grow, wsB, wsC, K, Dk, L, nchunk, slab, xmode, dtr, Wdt, R)
+  if (gd16 && dtr) {
+    if (R <= 16) LAUNCH_BWD16(1); else LAUNCH_BWD16(2);
+  } else if (L % 4 == 0) {
     if (R == 0) LAUNCH_BWD(true, 0); else if (R <= 16) LAUNCH_BWD(true, 1); else LAUNCH_BWD(true, 2);
   } else {
     if (R == 0) LAUNCH_BWD(false, 0); else if (R <= 16) LAUNCH_BWD(false, 1); else LAUNCH_BWD(false, 2);
   }
 #undef LAUNCH_BWD
+#undef LAUNCH_BWD16
   // dB / dC: the workgroups' slabs added in slab order (this also frees the workspace for the split gdtr product below)
   const size_t n4 = slab / 4;  // N = 16 makes slab a multiple of 4
   const unsigned blocks = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
@@ -955,9 +984,13 @@ static int scan_bwd_launch(const float* gy, const float* u, const float* delta, 
       g2.z = (unsigned)min(Dk / 64, (1024 + wgs - 1) / wgs);
       if (g2.z > 1) out = ws;
     }
-    if (R <= 8) hipLaunchKernelGGL(dtproj_gdtr_kernel<8>, g2, dim3(256), 0, s, gdelta, Wdt, out, K, Dk, R, L, gsz);
-    else if (R <= 16) hipLaunchKernelGGL(dtproj_gdtr_kernel<16>, g2, dim3(256), 0, s, gdelta, Wdt, out, K, Dk, R, L, gsz);
-    else hipLaunchKernelGGL(dtproj_gdtr_kernel<32>, g2, dim3(256), 0, s, gdelta, Wdt, out, K, Dk, R, L, gsz);
+#define GDTR(RT)                                                                                                       \
+  {                                                                                                                    \
+    if (gd16) hipLaunchKernelGGL((dtproj_gdtr_kernel<RT, true>), g2, dim3(256), 0, s, gdelta, Wdt, out, K, Dk, R, L, gsz); \
+    else hipLaunchKernelGGL((dtproj_gdtr_kernel<RT, false>), g2, dim3(256), 0, s, gdelta, Wdt, out, K, Dk, R, L, gsz);   \
+  }
+    if (R <= 8) GDTR(8) else if (R <= 16) GDTR(16) else GDTR(32)
+#undef GDTR
     if (out != gdtr) {
       const size_t m4 = gsz / 4;  // L % 4 == 0 here
       const unsigned bl = (unsigned)((m4 + 255) / 256 < 4096 ? (m4 + 255) / 256 : 4096);

@@ -5,7 +5,6 @@ Data layout in HBM: the three input maps go VSSBlock (NHWC) -> 1x1 conv+BN -> fl
 value projections and the gather kernels all read that one buffer.
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -15,10 +14,6 @@ from . import ops
 from .loss import get_cdn_group
 from .modules import ContrastiveHeadMLP, DeformableTransformerDecoderLayer, MLP, TextDeformableTransformerDecoder
 from .vss import TallLinear, VSSBlock
-
-
-_VSS_STREAMS = os.environ.get('TAMTR_VSS_STREAMS', '1') != '0'
-_SIDE_STREAMS = {}
 
 
 class ManbaWorldDecoder(nn.Module):
@@ -66,41 +61,16 @@ class ManbaWorldDecoder(nn.Module):
 
     def encode(self, x, drop_scales=None):
         """The three trunk maps -> the token memory `feats` [B, L, hd] and the level shapes.  Shapes depend on the image size only.
-        The levels are independent of each other up to the concatenation.  On the GPU the finest level (the most work) runs on the
-        current stream and the other two, one after the other, on a side stream: their kernels fill the wave slots that the finest
-        level's scans leave idle (the scan forward holds 512 workgroups where 768 fit; the scan backward's workgroups finish in two
-        groups 2.6 ms apart and half of the chip waits for the late one).  Autograd runs every backward node on its forward's stream,
-        so the backward overlaps the same way, and a recorded graph keeps the two branches.  TAMTR_VSS_STREAMS=0: one stream."""
+        (Round 3 tried the three independent levels on two streams, to fill the wave slots the finest level's scans leave idle: as
+        parallel branches of the recorded graphs, back-to-back replays of consecutive steps never returned from the runtime - the bench
+        hung in its timed loop after three synchronised warm-up steps had passed - so the levels run one after the other.)"""
         # VSS blocks run channels-last ([B,H,W,C], head.py:1136-1140); their outputs stay token-major: the 1x1 input projection
         # is a GEMM over tokens and its result is already in the [B, L, hd] layout of the token memory
-        def level(i):
-            f = x[i].permute(0, 2, 3, 1)
-            tok = self.VSSBlocks[i](f) if drop_scales is None else self.VSSBlocks[i](f, drop_scales[i])
-            return self._project_level(i, tok)
-        n = len(x)
-        if not (_VSS_STREAMS and n > 1 and x[0].is_cuda):
-            outs = [level(i) for i in range(n)]
-        else:
-            main = torch.cuda.current_stream()
-            side = self._side_stream(x[0].device)
-            side.wait_stream(main)
-            outs = [None] * n
-            with torch.cuda.stream(side):
-                for i in range(1, n):
-                    x[i].record_stream(side)          # produced on `main`, read here: keep its block out of main's free list until then
-                    outs[i] = level(i)
-            outs[0] = level(0)
-            main.wait_stream(side)
-            for i in range(1, n):
-                outs[i][0].record_stream(main)        # produced on `side`, read by the concatenation on `main`
+        outs = []
+        for i, (blk, f) in enumerate(zip(self.VSSBlocks, x)):
+            f = f.permute(0, 2, 3, 1)
+            outs.append(self._project_level(i, blk(f) if drop_scales is None else blk(f, drop_scales[i])))
         return torch.cat([o[0] for o in outs], 1), [o[1] for o in outs]
-
-    @staticmethod
-    def _side_stream(device):
-        st = _SIDE_STREAMS.get(device)     # (per device, not on the module: modules get deep-copied - EMA - and pickled)
-        if st is None:
-            st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
-        return st
 
     def decode(self, feats, shapes, text, batch=None):
         dn_embed, dn_bbox, attn_mask, dn_meta = get_cdn_group(batch, self.nc, self.num_queries,

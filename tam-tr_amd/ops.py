@@ -781,7 +781,7 @@ class _SelectiveScanDtProj(torch.autograd.Function):
         ws = torch.empty(2 * nslab * Bm.numel(), device=u.device, dtype=torch.float32)
         call('tamtr_selective_scan_dtproj_bwd', ptr(gy), ptr(u), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(dbias),
              ptr(hstate), ptr(gu), ptr(gdelta), ptr(gdtr), ptr(grow), ptr(gB), ptr(gC), ptr(ws), Bn, K,
-             KD // K, N, R, L, ctx.xmode, stream_ptr())
+             KD // K, N, R, L, ctx.xmode, 0, stream_ptr())
         gW, gA, gD, gbias = _split_row_sums(grow, R)
         if ctx.xmode:
             g4 = gu.view(Bn, 4, KD // 4, L)
@@ -955,7 +955,7 @@ class _SelectiveScanCrossMerged(torch.autograd.Function):
         ws = torch.empty(2 * nslab * Bm.numel(), device=u2.device, dtype=torch.float32)
         call('tamtr_selective_scan_dtproj_bwd', ptr(g2), ptr(u2), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(dbias),
              ptr(hstate), ptr(gu), ptr(gdelta), ptr(gdtr), ptr(grow), ptr(gB), ptr(gC), ptr(ws), Bn, K,
-             Dk, N, R, L, 3, stream_ptr())
+             Dk, N, R, L, 3, 0, stream_ptr())
         gW, gA, gD, gbias = _split_row_sums(grow, R)
         g4 = gu.view(Bn, 4, Dk, L)
         return g4[:, :2] + g4[:, 2:], gdtr, gW, gA, gB, gC, gD, gbias, None, None, None
@@ -1079,7 +1079,9 @@ class _SS2DCore(torch.autograd.Function):
         call('tamtr_cross_merge_bwd', ptr(gy), ptr(g2), B, D, H, W, stream_ptr())
         del gy
         gu = torch.empty(B, K * D, L, device=dev, dtype=torch.float32)
-        gdelta = torch.empty(B, K * D, L, device=dev, dtype=torch.float32)
+        # d(delta) workspace: only the operand of gdtr = Wdt^T d(delta); in bf16 mode (gdtr is rounded to bf16 below anyway) kept in bf16
+        ws16 = ub.dtype == torch.bfloat16 and L % 4 == 0
+        gdelta = torch.empty(B, K * D, L, device=dev, dtype=torch.bfloat16 if ws16 else torch.float32)
         gdtr = torch.empty_like(dtr)
         gB, gC = torch.empty_like(Bs), torch.empty_like(Cs)
         grow = _scan_row_sums(B, K * D, dev)
@@ -1087,7 +1089,7 @@ class _SS2DCore(torch.autograd.Function):
         ws = torch.empty(2 * nslab * Bs.numel(), device=dev, dtype=torch.float32)
         call('tamtr_selective_scan_dtproj_bwd', ptr(g2), ptr(u2), ptr(dtr), ptr(Wdt32), ptr(A32), ptr(Bs), ptr(Cs), ptr(D32), ptr(db32),
              ptr(hstate), ptr(gu), ptr(gdelta), ptr(gdtr), ptr(grow), ptr(gB), ptr(gC), ptr(ws), B, K, D, N, R, L,
-             3, stream_ptr())
+             3, int(ws16), stream_ptr())
         gW, gA, gD, gdb = _split_row_sums(grow, R)
         del gdelta, ws, g2
         # x_proj backward: per copy one [D, 2C] x [2C, L] product and the weight gradient as a batched GEMM over L slices
