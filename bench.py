@@ -193,7 +193,7 @@ def graph_vs_eager(model, batch, seed=4321):
 def _brief(chk):
     if not chk:
         return None
-    return {k: chk[k] for k in ('ok', 'grads', 'informative_grads', 'out_rel_max', 'grad_l2_rel_max', 'eager_noise_out', 'eager_noise_grad_l2',
+    return {k: chk[k] for k in ('ok', 'conclusive', 'grads', 'informative_grads', 'out_rel_max', 'grad_l2_rel_max', 'eager_noise_out', 'eager_noise_grad_l2',
                                 'bound_out', 'bound_grad_l2')}
 
 

@@ -285,6 +285,12 @@ int tamtr_ln_gate_bwd(const void* gout, const float* x, const void* xz, long lon
  *      tensor with several consumers - the MEH token memory feeds enc_output and every decoder layer's value_proj (head.py:1152-1160,
  *      transformer.py:273) - in one pass instead of autograd's n - 1 pairwise adds. */
 int tamtr_sum_n(const void* const* src, int n, void* out, long long n_elems, int dtype, void* stream);
+
+/*      Column sums of a tall bf16 matrix: the bias gradient of a token-wise nn.Linear (value_proj transformer.py:273, enc_output
+ *      head.py:1118: db = sum over the B*L tokens of dY).  X bf16 [M, N] -> partial f32 [tamtr_colsum_blocks(M), N], one row of sums per
+ *      workgroup, added by the caller (fixed order).  N % 8 == 0, N <= 2048, 256 % (N / 8) == 0. */
+int tamtr_colsum_blocks(long long M);
+int tamtr_colsum_bf16(const void* X, float* partial, long long M, int N, void* stream);
 int tamtr_fold_add(const float* g4, const void* m0, const void* m1, float* out, int B, long long n, int dtype, void* stream);
 
 /*      tamtr_layernorm_* : LayerNorm over the channel axis of a token-major map, VSSBlock.norm / norm2

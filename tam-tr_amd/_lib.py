@@ -56,6 +56,8 @@ _SIGS = {
     'tamtr_maxpool_fwd': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'tamtr_maxpool_bwd': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'tamtr_sum_n': [_P, _I, _P, _LL, _I, _P],
+    'tamtr_colsum_blocks': [_LL],
+    'tamtr_colsum_bf16': [_P, _P, _LL, _I, _P],
     'tamtr_fold_add': [_P, _P, _P, _P, _I, _LL, _I, _P],
     'tamtr_resample2': [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     'tamtr_cat_rows': [_P, _P, _P, _I, _P, _LL, _LL, _I, _P],

@@ -116,7 +116,7 @@ class GraphedPart:
         (tests/test_gpu_graphs.py).  Metrics are relative L2 norms: per tensor (`*_rel`) and over all gradients together (`grad_l2_rel`).
         `ok` is False when anything is non-finite, when the output or the whole gradient is off by more than
         max(tol, noise_factor * eager level), or when an INFORMATIVE tensor (eager level < 0.1) is off by more than that bound on its
-        own level.  A replay that went wrong is NaN or off by many orders of magnitude (profiles/r03_graph_probe.txt).
+        own level.  When eager itself is not reproducible to 5 % (`conclusive: False`) only "finite and within 10 x" is decided.  A replay that went wrong is NaN or off by many orders of magnitude (profiles/r03_graph_probe.txt).
         Buffers the module updates in place (BatchNorm statistics) are restored afterwards; no global RNG is consumed (the module
         must be a function of its inputs: DropPath factors are inputs)."""
         saved = self._snapshot_buffers()
@@ -151,8 +151,15 @@ class GraphedPart:
         res = {'grads': len(live), 'informative_grads': sum(informative), 'eager_noise_out': noise_out, 'eager_noise_grad_l2': noise_all,
                'eager_noise_grad_max': max(noise_t) if noise_t else 0.0, 'replays': []}
         ok = True
-        cap = 0.5
-        b_out, b_all = min(max(tol, noise_factor * noise_out), cap), min(max(tol, noise_factor * noise_all), cap)
+        # Two regimes.  Eager reproducible to a few per cent (the tuned tables: 2e-3; deterministic solvers: 0): the bound is tight and the
+        # check is conclusive.  Eager itself all over the place (MIOpen's heuristic solvers on this graph: two eager runs differ by 0.1 - 1
+        # in the whole-gradient norm): nothing finer than "finite and not orders of magnitude off" can be decided - the result says so
+        # (`conclusive: False`); a replay gone wrong in the way round 2 saw it (1e20 .. NaN) is still caught.
+        conclusive = noise_all < 0.05 and noise_out < 0.05
+        if conclusive:
+            b_out, b_all = max(tol, noise_factor * noise_out), max(tol, noise_factor * noise_all)
+        else:
+            b_out = b_all = 10.0
         for rep in range(replays):
             self._restore_buffers(saved)
             self.static_gout.copy_(cot)
@@ -176,7 +183,7 @@ class GraphedPart:
             bad = nonfinite or not (e_out <= b_out) or not (e_all <= b_all) or not (worst[0] <= 1.0)
             ok = ok and not bad
         self._restore_buffers(saved)
-        res.update(ok=ok, bound_out=b_out, bound_grad_l2=b_all, out_rel_max=max(r['out_rel'] for r in res['replays']),
+        res.update(ok=ok, conclusive=conclusive, bound_out=b_out, bound_grad_l2=b_all, out_rel_max=max(r['out_rel'] for r in res['replays']),
                    grad_l2_rel_max=max(r['grad_l2_rel'] for r in res['replays']), grad_rel_max=max(r['grad_rel_max'] for r in res['replays']))
         return res
 

@@ -254,6 +254,11 @@ class RTDETRDetectionWorldModel(nn.Module):
                    f"HIP {torch.version.hip}): running eagerly")
             (log or print)(msg)
             raise RuntimeError(msg)
+        if log is not None and verify and not self.static_part_check['conclusive']:
+            chk = self.static_part_check
+            log(f"HIP-graph replay check inconclusive: eager execution itself is not reproducible here (whole-gradient difference between two eager "
+                f"runs {chk['eager_noise_grad_l2']:.2e}, replay against eager {chk['grad_l2_rel_max']:.2e}); only finiteness and order of magnitude were "
+                'checked - TAMTR_DETERMINISTIC=1 gives an exact comparison')
         if log is not None and not any(str(torch.version.hip).startswith(v) for v in VALIDATED_HIP):
             log(f'HIP-graph replay: runtime {torch.version.hip} is not one this package was validated on {VALIDATED_HIP}; the replay check passed')
         self._static = (graphed, tuple(img.shape), img.dtype, self.autocast_dtype, self.training, shapes, tuple(txt.shape))

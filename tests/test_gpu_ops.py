@@ -699,3 +699,17 @@ def test_fanout_sums_consumer_gradients_in_one_pass(ops, dt, n):
     sum((b * w).float().sum() for w in ws).backward()
     tol = 1e-6 if dt == torch.float32 else 2e-2
     assert_close(a.grad.float(), b.grad.float(), tol, tol * float(b.grad.abs().max()), 'fanout grad')
+
+
+@pytest.mark.parametrize('M,N', [(16 * 33600, 512), (4672, 512), (100003, 1024), (5000, 64), (40000, 2048)])
+def test_colsum_bias_gradient_kernel(M, N):
+    """ops.colsum (tamtr_colsum_bf16: the bias gradient of the token-wise linears, db = column sums of dY over B*L tokens) against a
+    float64 sum of the same bf16 values; same bits on a second call."""
+    import tamtr_amd.ops as ops
+    g = torch.Generator(device='cuda').manual_seed(M % 1000)
+    x = (torch.randn(M, N, device='cuda', generator=g) + 0.1).bfloat16()
+    a, b = ops.colsum(x), ops.colsum(x)
+    assert a.dtype == torch.float32 and a.shape == (N,) and torch.equal(a, b)
+    ref = x.double().sum(0)
+    err = float((a.double() - ref).abs().max())
+    assert err <= 1e-5 * float(x.double().abs().sum(0).max()), err       # fp32 accumulation over <= 264 rows per partial, then <= 2048 partials
