@@ -10,8 +10,10 @@
  *   - `dtype`: element type of the activation tensors marked (T): TAMTR_F32 or TAMTR_BF16.  Index/offset/weight
  *     side inputs and all accumulation are always fp32;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Functions only enqueue work: no
- *     allocation, no synchronisation, no globals - they are safe to call from several host threads on different
- *     streams and can be captured into a hipGraph;
+ *     allocation, no synchronisation, no mutable globals (two A/B switches, TAMTR_GEMM and TAMTR_SELFATTN_SCALAR, are read from the
+ *     environment ONCE, into constants; the LDS-size attribute of the kernels that need > 64 KB is set on every call, i.e. for whichever
+ *     device is current) - they are safe to call from several host threads on different streams and devices and can be captured into a
+ *     hipGraph;
  *   - return value: 0 = enqueued; TAMTR_EINVAL (bad argument), TAMTR_EUNSUP (shape/dtype outside what the kernels
  *     are built for), TAMTR_ELAUNCH (HIP reported a launch error).  Nothing is ever thrown across the ABI.
  */

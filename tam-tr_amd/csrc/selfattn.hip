@@ -529,8 +529,9 @@ __global__ __launch_bounds__(WAVE) void selfattn_mfma_dkv_kernel(const bf16_t* _
 }
 
 inline bool mfma_ok(const void* a, const void* b, const void* c, int dh, int ldq, int ldk, int ldv, int nh, int dtype) {
+  static const bool scalar_only = getenv("TAMTR_SELFATTN_SCALAR") != nullptr;   // A/B switch, read once when first used (not per call)
   return dtype == TAMTR_BF16 && dh == 64 && ((ldq | ldk | ldv | (nh * 64)) % 8) == 0 &&
-         (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) % 16) == 0 && !getenv("TAMTR_SELFATTN_SCALAR");
+         (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) % 16) == 0 && !scalar_only;
 }
 
 inline bool sa_ok(int B, int Q, int nh, int dh) { return B > 0 && Q > 0 && nh > 0 && B <= 65535 && nh <= 65535 && dh > 0; }

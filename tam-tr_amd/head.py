@@ -24,7 +24,9 @@ class ManbaWorldDecoder(nn.Module):
                  dims=(128, 256, 512), drop_path=(0.1, 0.1, 0.1), embed=512, with_bn=False):
         super().__init__()
         if with_bn:
-            raise NotImplementedError('BNContrastiveHeadMLP is not used by TAMTR.yaml and is not built')
+            # (nn/modules/block.py:544-570: its forward hands a 3-D [B, C, Q] tensor to nn.BatchNorm2d, which raises for anything but 4-D
+            # input - the reference's with_bn=True head cannot run either; TAMTR.yaml leaves it False)
+            raise NotImplementedError('with_bn=True (BNContrastiveHeadMLP) is not built: not used by TAMTR.yaml, and not runnable in the reference')
         self.hidden_dim, self.nhead, self.nl, self.nc = hd, nh, len(ch), nc
         self.num_queries, self.num_decoder_layers = nq, ndl
         self.input_proj = nn.ModuleList(nn.Sequential(nn.Conv2d(c, hd, 1, bias=False), batchnorm(hd)) for c in ch)

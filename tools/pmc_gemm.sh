@@ -10,6 +10,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pass3 -- python3 tools/gemm
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pass4 -- python3 tools/gemm_only.py > $O/log4.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 tools/gemm_only.py > $O/log5.txt 2>&1
 python3 tools/pmc_summary.py $O linear_bf16
+python3 tools/pmc_gemm_json.py $O > gpurun_out/gemm_pmc.json
 python3 - <<'PY'
 import csv, glob
 f = glob.glob('gpurun_out/pmc_gemm/trace/*/*kernel_stats.csv')[0]
