@@ -17,8 +17,9 @@ if [ "$1" = 1 ]; then
   step prof 500 bash -c 'bash tools/prof_step.sh r03 > gpurun_out/r03_prof_step.log 2>&1'; head -12 gpurun_out/prof_step_r03.txt | cut -c1-170
 else
   step pmc 600 bash -c 'bash tools/pmc_gemm.sh > gpurun_out/r03_gemm_pmc.txt 2>&1'; tail -8 gpurun_out/r03_gemm_pmc.txt | cut -c1-160; head -12 gpurun_out/gemm_pmc.json
+  rm -rf gpurun_out/pmc_gemm   # raw counter / trace CSVs: tens of MB, summarised above (gpurun copies back at most 64 MiB)
   step bench1280 500 bash -c 'python bench.py --imgsz 1280 --batch 8 --no-cpu-baseline > gpurun_out/r03_bench_1280_bs8.json 2> gpurun_out/r03_bench_1280_bs8.err'; grep -E "timed|captured" gpurun_out/r03_bench_1280_bs8.err | cut -c1-200
   step benchdet 700 bash -c 'TAMTR_DETERMINISTIC=1 python bench.py --no-cpu-baseline --steps 5 --warmup 2 > gpurun_out/r03_bench_deterministic.json 2> gpurun_out/r03_bench_deterministic.err'; grep -E "timed|captured|graph vs" gpurun_out/r03_bench_deterministic.err | cut -c1-260
   step bench2rank 500 bash -c 'TAMTR_BENCH_ALLOW_GLOO=1 TAMTR_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r03_bench_2rank_gloo.json 2> gpurun_out/r03_bench_2rank_gloo.err'; grep -E "launch|timed" gpurun_out/r03_bench_2rank_gloo.err | cut -c1-260
-  step trainfiles 500 bash -c 'python tools/train.py --synthetic 640 --batch 16 --workers 14 --epochs 3 --save-dir gpurun_out/r03_train_run > gpurun_out/r03_train_from_files.txt 2>&1'; tail -4 gpurun_out/r03_train_from_files.txt | cut -c1-300
+  step trainfiles 500 bash -c 'python tools/train.py --synthetic 640 --batch 16 --workers 14 --epochs 3 --save-dir /tmp/r03_train_run > gpurun_out/r03_train_from_files.txt 2>&1'; tail -4 gpurun_out/r03_train_from_files.txt | cut -c1-300
 fi
