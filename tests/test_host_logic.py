@@ -299,8 +299,8 @@ def test_deterministic_switch_and_no_tunableop(tmp_path):
     env.pop('PYTORCH_TUNABLEOP_ENABLED', None)
     out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-1500:]
-    # (benchmark True: the timed search among the DETERMINISTIC solvers - the heuristic alone falls back to naive kernels, 17 s per step)
-    assert out.stdout.split() == ['deterministic', 'True', 'True', '1', 'True', 'None'], out.stdout
+    # (benchmark False: no timed search - one came back with a solver set that was not bitwise reproducible, tuning.py)
+    assert out.stdout.split() == ['deterministic', 'True', 'False', '1', 'True', 'None'], out.stdout
     for path in ('bench.py', 'tools/train.py', 'tools/val.py', 'tam-tr_amd/__init__.py', 'tam-tr_amd/tuning.py', 'tam-tr_amd/engine.py'):
         text = open(os.path.join(ROOT, path)).read()
         assert 'TUNABLEOP_ENABLED' not in text and 'tunable.enable' not in text, path
