@@ -99,13 +99,9 @@ int tamtr_msdeform_attn_bwd(const void* gout, const void* value, const int32_t* 
  *      grid_sample backward is the atomic scatter this replaces).  Per (image, head, level) the Q*P*4 bilinear corners are sorted
  *      by destination row in LDS and every row sums its run.  gvalue rows have pitch ldg elements (M*D for a plain [B,L,M,D]
  *      tensor).  Limits: Q*P*4 <= 8192, D % 8 == 0, D <= 256, H*W < 2^19 - 1 per level; TAMTR_EUNSUP otherwise.
- *      ws: caller workspace of tamtr_msdeform_bwd_ws_bytes(...) bytes (16-byte aligned), or NULL.  With it (and M * D / 8 lanes dividing a
- *      wave: the MEH shape 8 x 64 is exactly one) the sorted runs go through the workspace and every TOKEN ROW - all heads - is stored as
- *      one contiguous piece; without it a workgroup per head stores 128-byte pieces at the row pitch (same values, slower).
  */
-long long tamtr_msdeform_bwd_ws_bytes(int B, int L, int M, int D, int Q, int nl, int P);
 int tamtr_msdeform_attn_bwd_sorted(const void* gout, const void* value, const int32_t* shapes_host, const float* loc,
-                                   const float* aw, void* gvalue, float* gloc, float* gaw, void* ws, int B, int L, int M, int D, int Q,
+                                   const float* aw, void* gvalue, float* gloc, float* gaw, int B, int L, int M, int D, int Q,
                                    int nl, int P, long long ldg, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------

@@ -28,8 +28,7 @@ _SIGS = {
     'tamtr_maxsigmoid_gate_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     'tamtr_msdeform_attn_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'tamtr_msdeform_attn_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    'tamtr_msdeform_bwd_ws_bytes': [_I] * 7,
-    'tamtr_msdeform_attn_bwd_sorted': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _LL, _I, _P],
+    'tamtr_msdeform_attn_bwd_sorted': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _LL, _I, _P],
     'tamtr_contrastive_logits_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'tamtr_contrastive_logits_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'tamtr_contrastive_bwd_slabs': [_I],
@@ -79,7 +78,6 @@ _SIGS = {
     'tamtr_ln_gate_bwd': [_P, _P, _P, _LL, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _P],
     'tamtr_dwconv_silu_cross_bwd': [_P, _P, _LL, _P, _P, _P, _LL, _P, _I, _I, _I, _I, _I, _P],
 }
-_RESTYPES = {'tamtr_msdeform_bwd_ws_bytes': c_longlong}   # everything else returns int (status, version or a count)
 EXPORTS = tuple(_SIGS)
 _lib = None
 
@@ -95,7 +93,7 @@ def lib():
         for name, args in _SIGS.items():
             fn = getattr(h, name)  # AttributeError here == header/library mismatch
             fn.argtypes = args
-            fn.restype = _RESTYPES.get(name, c_int)
+            fn.restype = c_int
         if h.tamtr_abi_version() != ABI_VERSION:
             raise TamtrHipError(f'libtamtr_hip.so ABI {h.tamtr_abi_version()} != expected {ABI_VERSION}: rebuild')
         _lib = h

@@ -181,14 +181,21 @@ struct SliceTab {
   int first[MAXL + 1];  // prefix sums of the slices per level; first[nl] = slices in total
 };
 
-template <typename ET, int LPR>  // LPR lanes per row, 8 channels each
+// STAGE: the Q x D block of gout that this (image, head) reads is copied into LDS first (37 KB at Q = 292, D = 64, bf16).  Without it
+// every corner of a row's run costs a dependent global load (key -> corner -> gout row: ~1.5 us each, one after the other in the row's
+// 8 lanes): at 36 corners per lane group on the two coarse levels the kernel spent most of its 355 us waiting for those, not storing.
+constexpr int MSDA_FIXED_LDS = MSDA_MAX_KEYS * 8 + ((MSDA_SLICE_ROWS + 2) * 2 + 15) / 16 * 16;   // keys | weights | first-key table
+
+template <typename ET, int LPR, bool STAGE>  // LPR lanes per row, 8 channels each
 __global__ __launch_bounds__(MSDA_SORT_THREADS) void msda_gvalue_sorted_kernel(const ET* __restrict__ gout, const float* __restrict__ loc,
                                                                                 const float* __restrict__ aw, ET* __restrict__ gvalue,
                                                                                 Levels lv, SliceTab tab, int B, int L, int M, int D, int Q,
                                                                                 int nl, int P, int NS, long long ldg) {
-  __shared__ uint32_t keys[MSDA_MAX_KEYS];
-  __shared__ float wts[MSDA_MAX_KEYS];
-  __shared__ uint16_t first_key[MSDA_SLICE_ROWS + 2];
+  extern __shared__ __attribute__((aligned(16))) unsigned char msda_lds[];
+  uint32_t* keys = reinterpret_cast<uint32_t*>(msda_lds);
+  float* wts = reinterpret_cast<float*>(msda_lds + MSDA_MAX_KEYS * 4);
+  uint16_t* first_key = reinterpret_cast<uint16_t*>(msda_lds + MSDA_MAX_KEYS * 8);
+  ET* sg = reinterpret_cast<ET*>(msda_lds + MSDA_FIXED_LDS);   // [Q][D] (STAGE only)
   const int tid = threadIdx.x;
   // workgroup id -> (image, slice, head), XCD-aware: the hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so
   // id = xcd + 8 * (m + M * t) puts the M heads of one (image, slice) on ONE XCD, back to back in dispatch order.  Their stores are the M
@@ -207,6 +214,13 @@ __global__ __launch_bounds__(MSDA_SORT_THREADS) void msda_gvalue_sorted_kernel(c
   const int per = (rows + nsl - 1) / nsl;
   const int lo = (sl - tab.first[l]) * per;
   const int hi = min(lo + per, rows);
+  if (STAGE) {  // gout[b, :, m, :] -> LDS, 16 bytes per thread and trip (consumed only after the barriers of the sort)
+    const int vpr = D * (int)sizeof(ET) / 16;   // 16-byte pieces per query row
+    for (int i = tid; i < Q * vpr; i += MSDA_SORT_THREADS) {
+      const int q = i / vpr, v = i - q * vpr;
+      reinterpret_cast<uint4*>(sg)[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(gout + (((size_t)b * Q + q) * M + m) * D) + v * 16);
+    }
+  }
   // ---- the level's corners of this (image, head)
   const int n_pts = Q * P;
   for (int e = tid; e < n_pts; e += MSDA_SORT_THREADS) {
@@ -272,9 +286,11 @@ __global__ __launch_bounds__(MSDA_SORT_THREADS) void msda_gvalue_sorted_kernel(c
       const int q = idx / (4 * P);
       float gv[8];
       if (sizeof(ET) == 2) {
-        VecLd<bf16_t, 8>::ld(reinterpret_cast<const bf16_t*>(gout) + gb + (size_t)q * M * D, gv);
+        VecLd<bf16_t, 8>::ld(STAGE ? reinterpret_cast<const bf16_t*>(sg) + q * D + (act ? d0 : 0)
+                                   : reinterpret_cast<const bf16_t*>(gout) + gb + (size_t)q * M * D, gv);
       } else {
-        const float* gp = reinterpret_cast<const float*>(gout) + gb + (size_t)q * M * D;
+        const float* gp = STAGE ? reinterpret_cast<const float*>(sg) + q * D + (act ? d0 : 0)
+                                : reinterpret_cast<const float*>(gout) + gb + (size_t)q * M * D;
         float lo4[4], hi4[4];
         Elt<float>::ld4(gp, lo4);
         Elt<float>::ld4(gp + 4, hi4);
@@ -294,141 +310,6 @@ __global__ __launch_bounds__(MSDA_SORT_THREADS) void msda_gvalue_sorted_kernel(c
         Elt<float>::st4(op + 4, hi4);
       }
     }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// The same sum with WHOLE TOKEN ROWS as the unit of output (M * D / 8 <= 64 lanes per row: the MEH shape 8 x 64 is exactly one wave).
-// A workgroup per head (above) stores 128-byte pieces at 1 KB stride and HBM takes them at 1.5 TB/s; here the sorting and the writing
-// are two kernels:
-//   msda_sort_kernel      per (image, head, level): the corners' keys sorted in LDS as above, then written out - sorted keys, weights by
-//                         corner index, and for every row of the level the position of its first key (uint16) - into a caller workspace
-//   msda_gvalue_rows_kernel  a wave owns a token row (or 64 / lanes-per-row rows): lane group h reads head h's run [first, next) for that row,
-//                         adds weight x gout in key order and the wave stores the row's M * D elements as ONE contiguous piece; the
-//                         run bounds of the wave's next row are requested before the current one is summed.
-// Workspace (bytes): keys u32 [B, M, nl, NS] | weights f32 [B, M, nl, NS] | first-key u16 [B, M, L + nl] (one end sentinel per level).
-__global__ __launch_bounds__(MSDA_SORT_THREADS) void msda_sort_kernel(const float* __restrict__ loc, const float* __restrict__ aw,
-                                                                       uint32_t* __restrict__ gkeys, float* __restrict__ gwts,
-                                                                       uint16_t* __restrict__ gfirst, Levels lv, int L, int M, int Q, int nl,
-                                                                       int P, int NS) {
-  __shared__ uint32_t keys[MSDA_MAX_KEYS];
-  __shared__ float wts[MSDA_MAX_KEYS];
-  const int tid = threadIdx.x;
-  const int l = blockIdx.x, m = blockIdx.y, b = blockIdx.z;
-  const int H = lv.H[l], W = lv.W[l];
-  const int rows = H * W;
-  const int n_pts = Q * P;
-  for (int e = tid; e < n_pts; e += MSDA_SORT_THREADS) {
-    const int q = e / P, p = e - q * P;
-    const size_t at = ((((size_t)b * Q + q) * M + m) * nl + l) * P + p;
-    const float2 xy = *reinterpret_cast<const float2*>(loc + at * 2);
-    const float a = aw[at];
-    const float x = xy.x * W - 0.5f, y = xy.y * H - 0.5f;
-    const float xf = floorf(x), yf = floorf(y);
-    const float fx = x - xf, fy = y - yf;
-    const int x0 = (int)fminf(fmaxf(xf, -2.f), (float)W + 1.f), y0 = (int)fminf(fmaxf(yf, -2.f), (float)H + 1.f);
-    const bool fin = (x == x) & (y == y);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int xi = x0 + (c & 1), yi = y0 + (c >> 1);
-      const bool ok = fin & (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H);
-      const int idx = e * 4 + c;
-      keys[idx] = ok ? (((uint32_t)(yi * W + xi) << MSDA_IDX_BITS) | (uint32_t)idx) : 0xffffffffu;
-      wts[idx] = ((c & 1) ? fx : 1.f - fx) * ((c >> 1) ? fy : 1.f - fy) * a;
-    }
-  }
-  for (int i = n_pts * 4 + tid; i < NS; i += MSDA_SORT_THREADS) { keys[i] = 0xffffffffu; wts[i] = 0.f; }
-  __syncthreads();
-  for (int k = 2; k <= NS; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (NS >> 1); t += MSDA_SORT_THREADS) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int ix = i | j;
-        const uint32_t ka = keys[i], kb = keys[ix];
-        const bool up = (i & k) == 0;
-        if ((ka > kb) == up) { keys[i] = kb; keys[ix] = ka; }
-      }
-      __syncthreads();
-    }
-  }
-  const size_t kb = (((size_t)b * M + m) * nl + l) * NS;
-  for (int i = tid; i < NS; i += MSDA_SORT_THREADS) { gkeys[kb + i] = keys[i]; gwts[kb + i] = wts[i]; }
-  uint16_t* fk = gfirst + ((size_t)b * M + m) * (L + nl) + lv.start[l] + l;
-  for (int r = tid; r <= rows; r += MSDA_SORT_THREADS) {   // rows + 1 entries: the last one closes the level's last row
-    const uint32_t want = (uint32_t)r << MSDA_IDX_BITS;
-    int a0 = 0, n = NS;
-    while (n > 0) {
-      const int h = n >> 1;
-      if (keys[a0 + h] < want) { a0 += h + 1; n -= h + 1; } else n = h;
-    }
-    fk[r] = (uint16_t)a0;
-  }
-}
-
-template <typename ET, int LPH>  // LPH = D / 8 lanes per head
-__global__ __launch_bounds__(256) void msda_gvalue_rows_kernel(const ET* __restrict__ gout, const uint32_t* __restrict__ gkeys,
-                                                               const float* __restrict__ gwts, const uint16_t* __restrict__ gfirst,
-                                                               ET* __restrict__ gvalue, Levels lv, long long n_rows, int L, int M, int D,
-                                                               int Q, int nl, int P, int NS, long long ldg) {
-  const int lpr = M * LPH;                  // lanes per token row (divides 64)
-  const int rpw = WAVE / lpr;               // rows per wave
-  const int lane = threadIdx.x % WAVE;
-  const long long wave_id = (long long)blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE, n_waves = (long long)gridDim.x * (256 / WAVE);
-  const int rw = lane / lpr, ll = lane % lpr;
-  const int head = ll / LPH, part = ll % LPH;
-  // run bounds of (row, head): two uint16 from the head's first-key table
-  auto bounds = [&](long long row, int& s, int& e, int& l, int& b) {
-    const bool ok = row < n_rows;
-    const long long rr = ok ? row : 0;
-    b = (int)(rr / L);
-    const int t = (int)(rr - (long long)b * L);
-    l = 0;
-    for (int i = 1; i < nl; ++i) l += t >= lv.start[i];
-    const uint16_t* fk = gfirst + ((size_t)b * M + head) * (L + nl) + t + l;
-    s = fk[0];
-    e = ok ? fk[1] : s;
-  };
-  long long row = wave_id * rpw + rw;
-  int s, e, l, b;
-  bounds(row, s, e, l, b);
-  for (; row - rw < n_rows; row += n_waves * rpw) {   // (wave-uniform trip count: the rows of a wave leave together)
-    const long long nrow = row + n_waves * rpw;
-    int ns, ne, nlv, nb;
-    bounds(nrow, ns, ne, nlv, nb);                     // next row's bounds in flight behind this row's sum
-    float acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    const size_t kb = (((size_t)b * M + head) * nl + l) * NS;
-    const size_t gb = ((size_t)b * Q * M + head) * D + part * 8;
-    for (int i = s; i < e; ++i) {
-      const int idx = (int)(gkeys[kb + i] & (MSDA_MAX_KEYS - 1));
-      const float w = gwts[kb + idx];
-      const int q = idx / (4 * P);
-      float gv[8];
-      if (sizeof(ET) == 2) {
-        VecLd<bf16_t, 8>::ld(reinterpret_cast<const bf16_t*>(gout) + gb + (size_t)q * M * D, gv);
-      } else {
-        const float* gp = reinterpret_cast<const float*>(gout) + gb + (size_t)q * M * D;
-        float lo4[4], hi4[4];
-        Elt<float>::ld4(gp, lo4);
-        Elt<float>::ld4(gp + 4, hi4);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { gv[t] = lo4[t]; gv[4 + t] = hi4[t]; }
-      }
-#pragma unroll
-      for (int t = 0; t < 8; ++t) acc[t] = fmaf(w, gv[t], acc[t]);
-    }
-    if (row < n_rows) {
-      if (sizeof(ET) == 2) {
-        VecLd<bf16_t, 8>::st(reinterpret_cast<bf16_t*>(gvalue) + (size_t)row * ldg + head * D + part * 8, acc);
-      } else {
-        float* op = reinterpret_cast<float*>(gvalue) + (size_t)row * ldg + head * D + part * 8;
-        const float lo4[4] = {acc[0], acc[1], acc[2], acc[3]}, hi4[4] = {acc[4], acc[5], acc[6], acc[7]};
-        Elt<float>::st4(op, lo4);
-        Elt<float>::st4(op + 4, hi4);
-      }
-    }
-    s = ns; e = ne; l = nlv; b = nb;
   }
 }
 
@@ -511,24 +392,9 @@ extern "C" int tamtr_msdeform_attn_bwd(const void* gout, const void* value, cons
 // Deterministic backward: gloc / gaw as above (no scatter), gvalue by the sorted segmented sum - written ONCE per element in the
 // value's dtype (no zero fill by the caller, no float atomics, bitwise reproducible).  ldg: token pitch of gvalue in elements
 // (M*D when it is its own [B,L,M,D] tensor; larger when it is a column block of a wider [B*L, ldg] matrix).
-static int msda_ns(int Q, int P) {
-  int NS = 64;
-  while (NS < Q * P * 4) NS <<= 1;
-  return NS;
-}
-
-// bytes of the workspace of tamtr_msdeform_attn_bwd_sorted (0: shape not supported by the whole-row path; pass ws = NULL then)
-extern "C" long long tamtr_msdeform_bwd_ws_bytes(int B, int L, int M, int D, int Q, int nl, int P) {
-  if (B <= 0 || L <= 0 || M <= 0 || D <= 0 || Q <= 0 || nl <= 0 || P <= 0 || (long long)Q * P * 4 > MSDA_MAX_KEYS || D % 8) return 0;
-  const int lpr = M * (D / 8);
-  if (lpr > WAVE || WAVE % lpr) return 0;
-  const long long NS = msda_ns(Q, P);
-  return (long long)B * M * nl * NS * 8 + (((long long)B * M * (L + nl) * 2 + 15) / 16) * 16;
-}
-
 extern "C" int tamtr_msdeform_attn_bwd_sorted(const void* gout, const void* value, const int32_t* shapes_host, const float* loc,
-                                              const float* aw, void* gvalue, float* gloc, float* gaw, void* ws, int B, int L, int M, int D,
-                                              int Q, int nl, int P, long long ldg, int dtype, void* stream) {
+                                              const float* aw, void* gvalue, float* gloc, float* gaw, int B, int L, int M, int D, int Q,
+                                              int nl, int P, long long ldg, int dtype, void* stream) {
   if (!gout || !value || !shapes_host || !loc || !aw || !gvalue || !gloc || !gaw || B <= 0 || L <= 0 || M <= 0 || D <= 0 ||
       Q <= 0 || P <= 0 || ldg < (long long)M * D)
     return TAMTR_EINVAL;
@@ -545,7 +411,8 @@ extern "C" int tamtr_msdeform_attn_bwd_sorted(const void* gout, const void* valu
     if (rows >= (1ll << (32 - MSDA_IDX_BITS)) - 1) return TAMTR_EUNSUP;
     tab.first[l + 1] = tab.first[l] + (int)((rows + MSDA_SLICE_ROWS - 1) / MSDA_SLICE_ROWS);
   }
-  const int NS = msda_ns(Q, P);
+  int NS = 64;
+  while (NS < Q * P * 4) NS <<= 1;
   hipStream_t s = (hipStream_t)stream;
   {  // d/d(loc), d/d(weight): the gather half of the old kernel
 #define GO(ET, LPG)                                                                                                       \
@@ -561,39 +428,28 @@ extern "C" int tamtr_msdeform_attn_bwd_sorted(const void* gout, const void* valu
 #undef PICK
 #undef GO
   }
-  if (ws && tamtr_msdeform_bwd_ws_bytes(B, L, M, D, Q, nl, P) > 0 && ((uintptr_t)ws % 16) == 0) {
-    // whole token rows: sort per (image, head, level) into the workspace, then one contiguous M * D store per row
-    uint32_t* gkeys = (uint32_t*)ws;
-    float* gwts = (float*)(gkeys + (size_t)B * M * nl * NS);
-    uint16_t* gfirst = (uint16_t*)(gwts + (size_t)B * M * nl * NS);
-    hipLaunchKernelGGL(msda_sort_kernel, dim3((unsigned)nl, (unsigned)M, (unsigned)B), dim3(MSDA_SORT_THREADS), 0, s, loc, aw, gkeys, gwts,
-                       gfirst, lv, L, M, Q, nl, P, NS);
-    const long long n_rows = (long long)B * L;
-    const int rpw = WAVE / (M * (D / 8));
-    const long long want = (n_rows + 4 * rpw - 1) / (4 * rpw);   // workgroups if every wave took one row group
-    const unsigned wgs = (unsigned)(want < 8192 ? want : 8192);  // ~66 rows per wave at the MEH size: enough to pipeline the bounds
-#define GOR(ET, LPH)                                                                                                          \
-  hipLaunchKernelGGL((msda_gvalue_rows_kernel<ET, LPH>), dim3(wgs), dim3(256), 0, s, (const ET*)gout, gkeys, gwts, gfirst, (ET*)gvalue, lv, \
-                     n_rows, L, M, D, Q, nl, P, NS, ldg)
-#define PICKR(ET)                                                                                                             \
-  switch (D / 8) { case 1: GOR(ET, 1); break; case 2: GOR(ET, 2); break; case 4: GOR(ET, 4); break; case 8: GOR(ET, 8); break;  \
-                   case 16: GOR(ET, 16); break; case 32: GOR(ET, 32); break; default: return TAMTR_EUNSUP; }
-    if (dtype == TAMTR_F32) { PICKR(float) } else { PICKR(bf16_t) }
-#undef PICKR
-#undef GOR
-    return tamtr_launch_status();
-  }
   const long long pairs = ((long long)B * tab.first[nl] + 7) / 8 * 8;   // (image, slice) pairs, padded to the 8 XCDs
   if (pairs * M > 0x7fffffffLL) return TAMTR_EUNSUP;
   dim3 grid((unsigned)(pairs * M));
-#define GO(ET, LPR)                                                                                                          \
-  hipLaunchKernelGGL((msda_gvalue_sorted_kernel<ET, LPR>), grid, dim3(MSDA_SORT_THREADS), 0, s, (const ET*)gout, loc, aw, (ET*)gvalue, lv, \
-                     tab, B, L, M, D, Q, nl, P, NS, ldg)
+  // gout of one (image, head) staged in LDS when it fits next to the sort (one workgroup per CU then: 16 waves)
+  const size_t stage_bytes = (size_t)Q * D * (dtype == TAMTR_BF16 ? 2 : 4);
+  const bool stage = MSDA_FIXED_LDS + stage_bytes <= 150 * 1024 && (D * (dtype == TAMTR_BF16 ? 2 : 4)) % 16 == 0;
+  const size_t lds = MSDA_FIXED_LDS + (stage ? stage_bytes : 0);
+#define GO1(ET, LPR, ST)                                                                                                     \
+  {                                                                                                                          \
+    if (lds > 64 * 1024 &&                                                                                                   \
+        hipFuncSetAttribute((const void*)msda_gvalue_sorted_kernel<ET, LPR, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+      return TAMTR_ELAUNCH;                                                                                                  \
+    hipLaunchKernelGGL((msda_gvalue_sorted_kernel<ET, LPR, ST>), grid, dim3(MSDA_SORT_THREADS), lds, s, (const ET*)gout, loc, aw, (ET*)gvalue, \
+                       lv, tab, B, L, M, D, Q, nl, P, NS, ldg);                                                              \
+  }
+#define GO(ET, LPR) { if (stage) GO1(ET, LPR, true) else GO1(ET, LPR, false) }
 #define PICK(ET)                                                                                                             \
-  if (D <= 8) GO(ET, 1); else if (D <= 16) GO(ET, 2); else if (D <= 32) GO(ET, 4); else if (D <= 64) GO(ET, 8);              \
-  else if (D <= 128) GO(ET, 16); else GO(ET, 32)
-  if (dtype == TAMTR_F32) { PICK(float); } else { PICK(bf16_t); }
+  if (D <= 8) GO(ET, 1) else if (D <= 16) GO(ET, 2) else if (D <= 32) GO(ET, 4) else if (D <= 64) GO(ET, 8)                  \
+  else if (D <= 128) GO(ET, 16) else GO(ET, 32)
+  if (dtype == TAMTR_F32) { PICK(float) } else { PICK(bf16_t) }
 #undef PICK
 #undef GO
+#undef GO1
   return tamtr_launch_status();
 }

@@ -331,13 +331,6 @@ def deterministic():
     return _os.environ.get('TAMTR_DETERMINISTIC') == '1' or torch.are_deterministic_algorithms_enabled()
 
 
-_MSDA_PER_HEAD = _os.environ.get('TAMTR_MSDA_PER_HEAD') == '1'   # A/B switch: the workgroup-per-head store pattern of the first version
-
-
-def _msda_ws_bytes(B, L, M, D, Q, nl, P):
-    return int(_lib.lib().tamtr_msdeform_bwd_ws_bytes(B, L, M, D, Q, nl, P))
-
-
 def msda_sorted_ok(Q, P, D):
     return Q * P * 4 <= 8192 and D % 8 == 0 and D <= 256
 
@@ -371,10 +364,8 @@ class _MSDeformCore(torch.autograd.Function):
             # ordered segmented sum (csrc/msdeform.hip): every element of the value gradient written once, in the value's dtype -
             # no 1.1 GB fp32 zero fill, no float atomics, no cast pass, and the same bits on every run
             gvalue = torch.empty(B, L, M, D, device=value.device, dtype=value.dtype)
-            nws = _msda_ws_bytes(B, L, M, D, Q, nl, P)   # > 0: whole token rows are written (sorted runs pass through this workspace)
-            ws = torch.empty(nws, device=value.device, dtype=torch.uint8) if nws and not _MSDA_PER_HEAD else None
             call('tamtr_msdeform_attn_bwd_sorted', ptr(gout), ptr(value), ctypes.cast(sh, ctypes.c_void_p), ptr(loc32), ptr(aw32),
-                 ptr(gvalue), ptr(gloc), ptr(gaw), ptr(ws), B, L, M, D, Q, nl, P, M * D, dtype_code(value), stream_ptr())
+                 ptr(gvalue), ptr(gloc), ptr(gaw), B, L, M, D, Q, nl, P, M * D, dtype_code(value), stream_ptr())
             return gvalue, None, gloc.to(loc_dt), gaw.to(aw_dt)
         if deterministic():
             raise _lib.TamtrHipError(f'deterministic mode: the deformable-attention backward has no atomics-free kernel for Q*P*4 = {Q * P * 4} > 8192 '
