@@ -181,6 +181,63 @@ struct SliceTab {
   int first[MAXL + 1];  // prefix sums of the slices per level; first[nl] = slices in total
 };
 
+// ---- sort of exactly 8192 keys by 1024 threads, 8 keys per thread (thread t holds positions 8 t .. 8 t + 7).  The same bitonic network as
+// the plain LDS loop in the kernel, but only its strides >= 512 (partner in another wave: 10 of the 91 passes) go through LDS and a
+// barrier; strides 8 .. 256 are lane exchanges inside the wave (ds_bpermute, no barrier) and strides 4, 2, 1 stay inside the thread.
+// Measured on the MEH shape: the LDS loop was 158 us of the kernel's ~355 us (tools/build_msda_variant.sh ablations).
+template <int J>
+__device__ __forceinline__ void cx_in_thread(uint32_t (&k)[8], bool up_t, int kk) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if ((i & J) == 0) {
+      const bool up = kk >= 8 ? up_t : ((i & kk) == 0);
+      const uint32_t a = k[i], b = k[i | J];
+      const uint32_t lo = min(a, b), hi = max(a, b);
+      k[i] = up ? lo : hi;
+      k[i | J] = up ? hi : lo;
+    }
+  }
+}
+
+__device__ __forceinline__ void bitonic_sort_8192(uint32_t* __restrict__ keys, int tid) {
+  uint32_t k[8];
+  {
+    const uint4 a = *reinterpret_cast<const uint4*>(keys + tid * 8), b = *reinterpret_cast<const uint4*>(keys + tid * 8 + 4);
+    k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+  }
+  cx_in_thread<1>(k, false, 2);
+  cx_in_thread<2>(k, false, 4);
+  cx_in_thread<1>(k, false, 4);
+  for (int kk = 8; kk <= 8192; kk <<= 1) {
+    const bool up_t = (tid & (kk >> 3)) == 0;   // direction of this thread's 8 positions in stage kk
+    for (int j = kk >> 1; j >= 8; j >>= 1) {
+      const int dt = j >> 3;                    // partner thread = tid ^ dt
+      uint32_t pv[8];
+      if (dt >= WAVE) {                         // another wave: through LDS (wave-uniform branch)
+        __syncthreads();
+        *reinterpret_cast<uint4*>(keys + tid * 8) = make_uint4(k[0], k[1], k[2], k[3]);
+        *reinterpret_cast<uint4*>(keys + tid * 8 + 4) = make_uint4(k[4], k[5], k[6], k[7]);
+        __syncthreads();
+        const uint4 a = *reinterpret_cast<const uint4*>(keys + (tid ^ dt) * 8), b = *reinterpret_cast<const uint4*>(keys + (tid ^ dt) * 8 + 4);
+        pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w; pv[4] = b.x; pv[5] = b.y; pv[6] = b.z; pv[7] = b.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pv[i] = (uint32_t)__shfl_xor((int)k[i], dt, WAVE);
+      }
+      const bool keep_min = ((tid & dt) == 0) == up_t;   // the lower position of a pair keeps the minimum in an ascending block
+#pragma unroll
+      for (int i = 0; i < 8; ++i) k[i] = keep_min ? min(k[i], pv[i]) : max(k[i], pv[i]);
+    }
+    cx_in_thread<4>(k, up_t, kk);
+    cx_in_thread<2>(k, up_t, kk);
+    cx_in_thread<1>(k, up_t, kk);
+  }
+  __syncthreads();
+  *reinterpret_cast<uint4*>(keys + tid * 8) = make_uint4(k[0], k[1], k[2], k[3]);
+  *reinterpret_cast<uint4*>(keys + tid * 8 + 4) = make_uint4(k[4], k[5], k[6], k[7]);
+  __syncthreads();
+}
+
 // STAGE: the Q x D block of gout that this (image, head) reads is copied into LDS first (37 KB at Q = 292, D = 64, bf16).  Without it
 // every corner of a row's run costs a dependent global load (key -> corner -> gout row: ~1.5 us each, one after the other in the row's
 // 8 lanes): at 36 corners per lane group on the two coarse levels the kernel spent most of its 355 us waiting for those, not storing.
@@ -245,7 +302,11 @@ __global__ __launch_bounds__(MSDA_SORT_THREADS) void msda_gvalue_sorted_kernel(c
   }
   for (int i = n_pts * 4 + tid; i < NS; i += MSDA_SORT_THREADS) keys[i] = 0xffffffffu;
   __syncthreads();
-  // ---- bitonic sort of NS keys, ascending
+  // ---- bitonic sort of NS keys, ascending   (MSDA_ABL_*: timing-only builds of tools/build_msda_variant.sh, results are wrong)
+#ifndef MSDA_ABL_NOSORT
+  if (NS == MSDA_MAX_KEYS) {
+    bitonic_sort_8192(keys, tid);
+  } else
   for (int k = 2; k <= NS; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int t = tid; t < (NS >> 1); t += MSDA_SORT_THREADS) {
@@ -258,6 +319,7 @@ __global__ __launch_bounds__(MSDA_SORT_THREADS) void msda_gvalue_sorted_kernel(c
       __syncthreads();
     }
   }
+#endif
   // ---- first key of every row of the slice (and of the row after it)
   for (int r = lo + tid; r <= hi; r += MSDA_SORT_THREADS) {
     const uint32_t want = (uint32_t)r << MSDA_IDX_BITS;
@@ -275,8 +337,15 @@ __global__ __launch_bounds__(MSDA_SORT_THREADS) void msda_gvalue_sorted_kernel(c
   const bool act = d0 < D;
   const size_t gb = (size_t)b * Q * M * D + (size_t)m * D + (act ? d0 : 0);
   ET* const ob = gvalue + ((size_t)b * L + lv.start[l]) * ldg + (size_t)m * D + (act ? d0 : 0);
+#ifdef MSDA_ABL_NOEMIT
+  if (lo >= 0) return;
+#endif
   for (int r = lo + g; r < hi; r += MSDA_SORT_THREADS / LPR) {
+#ifdef MSDA_ABL_NORUNS
+    const int s = 0, e = 0;
+#else
     const int s = first_key[r - lo], e = first_key[r - lo + 1];
+#endif
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
