@@ -170,12 +170,14 @@ __global__ __launch_bounds__(MSDA_THREADS) void msda_bwd_kernel(const ET* __rest
 //   index; corners off the map get the all-ones key), sorts the keys (bitonic, in LDS), finds every row's run of keys by binary
 //   search, and then walks its rows: a group of D/8 lanes owns a row, adds weight * gout[b, q, m, :] over the row's run IN KEY
 //   ORDER (= a fixed order: bitwise reproducible) and stores the row - zeros for the (majority of) rows nobody sampled.
-//   Row slices (<= MSDA_SLICE_ROWS rows) only spread the store traffic over more workgroups; each re-sorts its level's keys
-//   (~10 us against ~0.8 MB of stores).
+//   Row slices (<= MSDA_SLICE_ROWS rows) only spread the emission over more workgroups; each re-sorts its level's keys.
 constexpr int MSDA_SORT_THREADS = 1024;
 constexpr int MSDA_MAX_KEYS = 8192;      // corners per (image, head, level): Q * P * 4
 constexpr int MSDA_IDX_BITS = 13;
-constexpr int MSDA_SLICE_ROWS = 6400;
+#ifndef MSDA_SLICE
+#define MSDA_SLICE 12800   // measured at the MEH shape (tools/build_msda_variant.sh): 3200: 482, 6400: 399, 12800: 383, 25600: 416 us fwd+bwd
+#endif
+constexpr int MSDA_SLICE_ROWS = MSDA_SLICE;
 
 struct SliceTab {
   int first[MAXL + 1];  // prefix sums of the slices per level; first[nl] = slices in total
