@@ -7,9 +7,12 @@
 //   forward : a group of D/VEC lanes owns one (b, q, head); each lane carries VEC channels (16-B loads), walks the
 //             nl*P samples x 4 bilinear corners and accumulates in registers -> gather-bound (L2 / Infinity-Cache / HBM
 //             row fetches), no LDS, no atomics;
-//   backward: one lane per channel so that every float-atomic wave-instruction on grad_value covers whole contiguous
-//             256-B (D=64) / 128-B (D=32) row segments - the full-rate atomic shape on gfx950 - while d/d(loc) and
-//             d/d(weight) are reduced across the group with xor-shuffles (no LDS).
+//   backward (round 3, tamtr_msdeform_attn_bwd_sorted): no atomics - d/d(loc), d/d(weight) in the forward's lane layout with
+//             xor-shuffle sums (msda_bwd_locaw_kernel); d/d(value) as a sorted segmented sum written once per element in the value's
+//             dtype (msda_gvalue_sorted_kernel: keys sorted in registers / LDS per (image, head, level), every row sums its run);
+//   backward (rounds 1-2, tamtr_msdeform_attn_bwd, kept as the reference the tests compare with): one lane per channel so that
+//             every float-atomic wave-instruction on grad_value covers whole contiguous 256-B (D=64) / 128-B (D=32) row segments
+//             - the full-rate atomic shape on gfx950 - d/d(loc) and d/d(weight) reduced across the group with xor-shuffles.
 // Bilinear convention == grid_sample(align_corners=False, padding zeros): pixel coords x = loc_x*W - 0.5; a corner
 // outside the map contributes 0 to the value and to every gradient.
 #include "common.h"
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(MSDA_THREADS) void msda_fwd_kernel(const ET* __rest
 }
 
 // one lane per channel (LPG = min(64, pow2ceil(D)) lanes per item; D > 64 loops)
-template <typename ET, int LPG, bool SCATTER>
+template <typename ET, int LPG>
 __global__ __launch_bounds__(MSDA_THREADS) void msda_bwd_kernel(const ET* __restrict__ gout, const ET* __restrict__ value,
                                                                  const float* __restrict__ loc, const float* __restrict__ aw,
                                                                  float* __restrict__ gvalue, float* __restrict__ gloc,
@@ -138,10 +141,8 @@ __global__ __launch_bounds__(MSDA_THREADS) void msda_bwd_kernel(const ET* __rest
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           if (okc[c]) {  // group-uniform
-            if (SCATTER) {
-              const float w = ((c & 1) ? fx : 1.f - fx) * ((c >> 1) ? fy : 1.f - fy);
-              atomicAdd(gvalue + oc[c], w * a * g);
-            }
+            const float w = ((c & 1) ? fx : 1.f - fx) * ((c >> 1) ? fy : 1.f - fy);
+            atomicAdd(gvalue + oc[c], w * a * g);
           } else {
             vc[c] = 0.f;
           }
@@ -151,6 +152,70 @@ __global__ __launch_bounds__(MSDA_THREADS) void msda_bwd_kernel(const ET* __rest
         s_x = fmaf(g, (1.f - fy) * (vc[1] - vc[0]) + fy * (vc[3] - vc[2]), s_x);
         s_y = fmaf(g, (1.f - fx) * (vc[2] - vc[0]) + fx * (vc[3] - vc[1]), s_y);
       }
+      s_aw = group_sum<LPG>(s_aw);
+      s_x = group_sum<LPG>(s_x);
+      s_y = group_sum<LPG>(s_y);
+      if (gl == 0) {
+        gaw[(size_t)gid * nl * P + l * P + p] = s_aw;
+        *reinterpret_cast<float2*>(gloc + ((size_t)gid * nl * P + l * P + p) * 2) = make_float2(s_x * a * W, s_y * a * H);
+      }
+    }
+  }
+}
+
+// d/d(loc), d/d(weight) alone (the backward's gather half once d/d(value) has its own kernel): the forward's lane layout - LPG lanes per
+// (b, q, head) item, VEC channels and 16-byte loads each - instead of one lane per channel, which was the shape the float atomics wanted.
+template <typename ET, int VEC, int LPG>
+__global__ __launch_bounds__(MSDA_THREADS) void msda_bwd_locaw_kernel(const ET* __restrict__ gout, const ET* __restrict__ value,
+                                                                       const float* __restrict__ loc, const float* __restrict__ aw,
+                                                                       float* __restrict__ gloc, float* __restrict__ gaw, Levels lv,
+                                                                       int n_items, int L, int M, int D, int Q, int nl, int P) {
+  const int gid = (blockIdx.x * MSDA_THREADS + threadIdx.x) / LPG;
+  const int gl = threadIdx.x % LPG;
+  if (gid >= n_items) return;  // whole groups leave together
+  const int d0 = gl * VEC;
+  const bool act = d0 < D;
+  const int m = gid % M;
+  const int b = (gid / M) / Q;
+  const float* lp = loc + (size_t)gid * nl * P * 2;
+  const float* ap = aw + (size_t)gid * nl * P;
+  const ET* vb = value + ((size_t)b * L * M + m) * D + (act ? d0 : 0);
+  const size_t tok = (size_t)M * D;
+  float g[VEC];
+  VecLd<ET, VEC>::ld(gout + (size_t)gid * D + (act ? d0 : 0), g);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) g[i] = act ? g[i] : 0.f;
+  for (int l = 0; l < nl; ++l) {
+    const int H = lv.H[l], W = lv.W[l];
+    const ET* vl = vb + (size_t)lv.start[l] * tok;
+    for (int p = 0; p < P; ++p) {
+      const float2 xy = *reinterpret_cast<const float2*>(lp + (l * P + p) * 2);
+      const float a = ap[l * P + p];
+      const float x = xy.x * W - 0.5f, y = xy.y * H - 0.5f;
+      const float xf = floorf(x), yf = floorf(y);
+      const float fx = x - xf, fy = y - yf;
+      const int x0 = (int)xf, y0 = (int)yf;
+      // the four corners' dot products with gout go out together (clamped addresses, zero factor for corners off the map)
+      float dc[4];
+      float vv[4][VEC];
+      bool okc[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int xi = x0 + (c & 1), yi = y0 + (c >> 1);
+        okc[c] = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H);
+        VecLd<ET, VEC>::ld(vl + (size_t)(min(max(yi, 0), H - 1) * W + min(max(xi, 0), W - 1)) * tok, vv[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) d = fmaf(g[i], vv[c][i], d);
+        dc[c] = okc[c] ? d : 0.f;
+      }
+      // v(x,y) = (1-fy)((1-fx) v00 + fx v01) + fy((1-fx) v10 + fx v11);  dc = <gout, {v00, v01, v10, v11}>
+      float s_aw = (1.f - fy) * ((1.f - fx) * dc[0] + fx * dc[1]) + fy * ((1.f - fx) * dc[2] + fx * dc[3]);
+      float s_x = (1.f - fy) * (dc[1] - dc[0]) + fy * (dc[3] - dc[2]);
+      float s_y = (1.f - fx) * (dc[2] - dc[0]) + fx * (dc[3] - dc[1]);
       s_aw = group_sum<LPG>(s_aw);
       s_x = group_sum<LPG>(s_x);
       s_y = group_sum<LPG>(s_y);
@@ -447,7 +512,7 @@ extern "C" int tamtr_msdeform_attn_bwd(const void* gout, const void* value, cons
   {                                                                                                                       \
     const int per_blk = MSDA_THREADS / LPG;                                                                               \
     dim3 grid((unsigned)((n_items + per_blk - 1) / per_blk));                                                             \
-    hipLaunchKernelGGL((msda_bwd_kernel<ET, LPG, true>), grid, dim3(MSDA_THREADS), 0, s, (const ET*)gout, (const ET*)value, loc, aw, \
+    hipLaunchKernelGGL((msda_bwd_kernel<ET, LPG>), grid, dim3(MSDA_THREADS), 0, s, (const ET*)gout, (const ET*)value, loc, aw, \
                        gvalue, gloc, gaw, lv, (int)n_items, L, M, D, Q, nl, P);                                           \
   }
 #define PICK(ET)                                                                                           \
@@ -485,19 +550,24 @@ extern "C" int tamtr_msdeform_attn_bwd_sorted(const void* gout, const void* valu
   int NS = 64;
   while (NS < Q * P * 4) NS <<= 1;
   hipStream_t s = (hipStream_t)stream;
-  {  // d/d(loc), d/d(weight): the gather half of the old kernel
-#define GO(ET, LPG)                                                                                                       \
+  {  // d/d(loc), d/d(weight): the gather half, in the forward's vector layout
+#define GOL(ET, VEC, LPG)                                                                                                 \
   {                                                                                                                       \
     const int per_blk = MSDA_THREADS / LPG;                                                                               \
-    dim3 grid((unsigned)((n_items + per_blk - 1) / per_blk));                                                             \
-    hipLaunchKernelGGL((msda_bwd_kernel<ET, LPG, false>), grid, dim3(MSDA_THREADS), 0, s, (const ET*)gout, (const ET*)value, loc, aw, \
-                       (float*)nullptr, gloc, gaw, lv, (int)n_items, L, M, D, Q, nl, P);                                  \
+    dim3 g1((unsigned)((n_items + per_blk - 1) / per_blk));                                                               \
+    hipLaunchKernelGGL((msda_bwd_locaw_kernel<ET, VEC, LPG>), g1, dim3(MSDA_THREADS), 0, s, (const ET*)gout, (const ET*)value, loc, aw, \
+                       gloc, gaw, lv, (int)n_items, L, M, D, Q, nl, P);                                                   \
   }
-#define PICK(ET)                                                                                           \
-  if (D <= 8) GO(ET, 8) else if (D <= 16) GO(ET, 16) else if (D <= 32) GO(ET, 32) else GO(ET, 64)
-    if (dtype == TAMTR_F32) { PICK(float) } else { PICK(bf16_t) }
-#undef PICK
-#undef GO
+    if (dtype == TAMTR_F32) {
+      const int lanes = D / 4;
+      if (lanes <= 4) GOL(float, 4, 4) else if (lanes <= 8) GOL(float, 4, 8) else if (lanes <= 16) GOL(float, 4, 16)
+      else if (lanes <= 32) GOL(float, 4, 32) else GOL(float, 4, 64)
+    } else {
+      const int lanes = D / 8;
+      if (lanes <= 4) GOL(bf16_t, 8, 4) else if (lanes <= 8) GOL(bf16_t, 8, 8) else if (lanes <= 16) GOL(bf16_t, 8, 16)
+      else GOL(bf16_t, 8, 32)
+    }
+#undef GOL
   }
   const long long pairs = ((long long)B * tab.first[nl] + 7) / 8 * 8;   // (image, slice) pairs, padded to the 8 XCDs
   if (pairs * M > 0x7fffffffLL) return TAMTR_EUNSUP;

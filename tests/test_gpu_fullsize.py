@@ -316,7 +316,9 @@ def test_msdeform_backward_is_bit_reproducible_and_matches_the_atomic_kernel(pkg
     gl2, ga2 = torch.empty_like(loc), torch.empty_like(aw)
     _lib.call('tamtr_msdeform_attn_bwd', P(gout), P(value), ctypes.cast(sh, ctypes.c_void_p), P(loc), P(aw), P(gv32), P(gl2), P(ga2),
               B, L, M, Dh, Q, 3, 4, _lib.BF16, _lib.stream_ptr())
-    assert torch.equal(a[1], gl2) and torch.equal(a[2], ga2)            # the gather half is the same code
+    # d/d(loc), d/d(weight): the same sums in another lane layout (8 channels per lane instead of 1) - fp32 accumulation-order noise only
+    assert_close(a[1], gl2, 1e-4, 1e-4 * float(gl2.abs().max()), 'g_loc vs the atomic kernel\'s gather half')
+    assert_close(a[2], ga2, 1e-4, 1e-4 * float(ga2.abs().max()), 'g_aw vs the atomic kernel\'s gather half')
     scale = float(gv32.abs().max())
     assert_close(a[0].float(), gv32, 2 ** -7, 2e-3 * scale, 'sorted vs atomic g_value (bf16 store)')
     assert float((a[0].float() != 0).float().mean()) < 0.6              # most rows are never sampled: written as zeros, not left unwritten
