@@ -135,10 +135,55 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_cross_bwd_kernel(const floa
     const int c = i / 10, k = i - c * 10;
     s_w[c][k] = k < 9 ? wgt[(size_t)(d0 + c) * 9 + k] : (bias ? bias[d0 + c] : 0.f);
   }
+  // (DW_ABL_*: timing-only builds of tools/build_variant.sh dwconv; their results are wrong)
+#ifndef DW_ABL_NOX
   stage_tile<T, CB, 2, XP>(x, xs, b, d0, h0, w0, H, W, s_x);
+#endif
   // gradient tile = row-major plane (lanes along x) + column-major plane (lanes along y: its contiguous axis).  Loads go out in
   // batches of 7 with clamped addresses and a 0/1 factor instead of a branch: hipcc ends a conditional block that contains a load with
   // s_waitcnt vmcnt(0), which made a thread's 21 loads per plane 21 serial round trips (71 % of the wave cycles were waits, round 2 PMC).
+#ifndef DW_ABL_NOG
+  if ((W & 3) == 0 && (H & 3) == 0) {
+    // Aligned 16-byte loads: a tile row of the gradient (18 values starting one pixel left of the tile) is covered by the 6 aligned float4
+    // at [w0 - 4, w0 + 20); the scalar version below issued 21 dependent-free but narrow loads per thread and plane and moved the two planes
+    // at 2 TB/s (420 us of the kernel's ~990 at level 0, measured by ablation: profiles/r03_dwconv_backward.txt).  7 loads per thread and
+    // plane, all in flight together; values outside the image or outside the 18-wide window are dropped when they are written to LDS.
+    constexpr int NV = 6, ITEMS_V = CB * GS * NV, N_ITV = (ITEMS_V + DW_THREADS - 1) / DW_THREADS;
+#pragma unroll
+    for (int plane = 0; plane < 2; ++plane) {
+      const float* gp = g2 + ((size_t)(b * 2 + plane) * D + d0) * L;
+      float4 v[N_ITV];
+#pragma unroll
+      for (int k = 0; k < N_ITV; ++k) {
+        const int it = min((int)threadIdx.x + k * DW_THREADS, ITEMS_V - 1);
+        const int c = it / (GS * NV), r = it - c * (GS * NV), line = r / NV, q = r - line * NV;
+        // plane 0: line = tile row (h), vectors along w;  plane 1 (column-major map): line = tile column (w), vectors along h
+        const int fixed = (plane == 0 ? h0 : w0) + line - 1, base = (plane == 0 ? w0 : h0) - 4 + 4 * q;
+        const int nfix = plane == 0 ? H : W, nrun = plane == 0 ? W : H;
+        const bool ok = fixed >= 0 && fixed < nfix && base >= 0 && base + 3 < nrun;
+        const float4 t = *reinterpret_cast<const float4*>(gp + (size_t)c * L + (size_t)min(max(fixed, 0), nfix - 1) * nrun + min(max(base, 0), nrun - 4));
+        const float f = ok ? 1.f : 0.f;
+        v[k] = make_float4(t.x * f, t.y * f, t.z * f, t.w * f);
+      }
+      if (plane == 1) __syncthreads();   // plane 0 is complete in LDS before plane 1 is added onto it
+#pragma unroll
+      for (int k = 0; k < N_ITV; ++k) {
+        const int it = threadIdx.x + k * DW_THREADS;
+        if (it < ITEMS_V) {
+          const int c = it / (GS * NV), r = it - c * (GS * NV), line = r / NV, q = r - line * NV;
+          const float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int pos = 4 * q + j - 3;   // position inside the 18-wide window
+            if (pos >= 0 && pos < GS) {
+              if (plane == 0) s_g[c][line][pos] = e[j];
+              else s_g[c][pos][line] += e[j];
+            }
+          }
+        }
+      }
+    }
+  } else {
   {
     constexpr int N_IT = (CB * GS * GS + DW_THREADS - 1) / DW_THREADS, GB = 7;
     static_assert(N_IT % GB == 0, "batches cover the tile");
@@ -190,11 +235,14 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_cross_bwd_kernel(const floa
       }
     }
   }
+  }
+#endif
   __syncthreads();
   // times SiLU'(conv) with the conv recomputed from the staged input.
   // 16 threads per channel walk its 18 x 18 halo pixels: the nine inputs loaded for the conv are exactly the factors of
   // d(weight) for that pixel, so the per-(channel, tap) sums ride along in registers (core pixels only) and are combined over
   // the 16 threads at the end - no separate pass over the tile.
+#ifndef DW_ABL_NOSILU
   {
     static_assert(DW_THREADS == CB * 16, "16 threads per channel");
     const int c = threadIdx.x / 16, sub = threadIdx.x % 16;
@@ -232,6 +280,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_cross_bwd_kernel(const floa
       for (int k9 = 0; k9 < 10; ++k9) o[k9] = dwk[k9];
     }
   }
+#endif
   __syncthreads();
   // d(input) on the core: transposed 3x3 of dL/d(conv)
   const int ty = threadIdx.x / TS, tx = threadIdx.x % TS;

@@ -240,7 +240,7 @@ constexpr int MSDA_SORT_THREADS = 1024;
 constexpr int MSDA_MAX_KEYS = 8192;      // corners per (image, head, level): Q * P * 4
 constexpr int MSDA_IDX_BITS = 13;
 #ifndef MSDA_SLICE
-#define MSDA_SLICE 12800   // measured at the MEH shape (tools/build_msda_variant.sh): 3200: 482, 6400: 399, 12800: 383, 25600: 416 us fwd+bwd
+#define MSDA_SLICE 12800   // measured at the MEH shape (tools/build_variant.sh msdeform): 3200: 482, 6400: 399, 12800: 383, 25600: 416 us fwd+bwd
 #endif
 constexpr int MSDA_SLICE_ROWS = MSDA_SLICE;
 
@@ -251,7 +251,7 @@ struct SliceTab {
 // ---- sort of exactly 8192 keys by 1024 threads, 8 keys per thread (thread t holds positions 8 t .. 8 t + 7).  The same bitonic network as
 // the plain LDS loop in the kernel, but only its strides >= 512 (partner in another wave: 10 of the 91 passes) go through LDS and a
 // barrier; strides 8 .. 256 are lane exchanges inside the wave (ds_bpermute, no barrier) and strides 4, 2, 1 stay inside the thread.
-// Measured on the MEH shape: the LDS loop was 158 us of the kernel's ~355 us (tools/build_msda_variant.sh ablations).
+// Measured on the MEH shape: the LDS loop was 158 us of the kernel's ~355 us (tools/build_variant.sh msdeform ablations).
 template <int J>
 __device__ __forceinline__ void cx_in_thread(uint32_t (&k)[8], bool up_t, int kk) {
 #pragma unroll
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(MSDA_SORT_THREADS) void msda_gvalue_sorted_kernel(c
   }
   for (int i = n_pts * 4 + tid; i < NS; i += MSDA_SORT_THREADS) keys[i] = 0xffffffffu;
   __syncthreads();
-  // ---- bitonic sort of NS keys, ascending   (MSDA_ABL_*: timing-only builds of tools/build_msda_variant.sh, results are wrong)
+  // ---- bitonic sort of NS keys, ascending   (MSDA_ABL_*: timing-only builds of tools/build_variant.sh msdeform, results are wrong)
 #ifndef MSDA_ABL_NOSORT
   if (NS == MSDA_MAX_KEYS) {
     bitonic_sort_8192(keys, tid);
