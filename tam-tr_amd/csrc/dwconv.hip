@@ -20,7 +20,10 @@ namespace {
 
 constexpr int TS = 16;            // tile side (pixels)
 constexpr int DW_THREADS = TS * TS;
-constexpr int CB_FWD = 32, CB_BWD = 16;
+#ifndef DW_CB_BWD
+#define DW_CB_BWD 16
+#endif
+constexpr int CB_FWD = 32, CB_BWD = DW_CB_BWD;
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
 
@@ -185,8 +188,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_cross_bwd_kernel(const floa
     }
   } else {
   {
-    constexpr int N_IT = (CB * GS * GS + DW_THREADS - 1) / DW_THREADS, GB = 7;
-    static_assert(N_IT % GB == 0, "batches cover the tile");
+    constexpr int GB = 7, N_IT = ((CB * GS * GS + DW_THREADS - 1) / DW_THREADS + GB - 1) / GB * GB;   // whole batches (extra trips load a clamped item and write nothing)
     const float* gp = g2 + ((size_t)(b * 2 + 0) * D + d0) * L;
 #pragma unroll 1
     for (int k0 = 0; k0 < N_IT; k0 += GB) {
@@ -211,8 +213,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_cross_bwd_kernel(const floa
   }
   __syncthreads();
   {
-    constexpr int N_IT = (CB * GS * GS + DW_THREADS - 1) / DW_THREADS, GB = 7;
-    static_assert(N_IT % GB == 0, "batches cover the tile");
+    constexpr int GB = 7, N_IT = ((CB * GS * GS + DW_THREADS - 1) / DW_THREADS + GB - 1) / GB * GB;   // whole batches (extra trips load a clamped item and write nothing)
     const float* gp = g2 + ((size_t)(b * 2 + 1) * D + d0) * L;
 #pragma unroll 1
     for (int k0 = 0; k0 < N_IT; k0 += GB) {
@@ -244,14 +245,15 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_cross_bwd_kernel(const floa
   // the 16 threads at the end - no separate pass over the tile.
 #ifndef DW_ABL_NOSILU
   {
-    static_assert(DW_THREADS == CB * 16, "16 threads per channel");
-    const int c = threadIdx.x / 16, sub = threadIdx.x % 16;
+    constexpr int TPC = DW_THREADS / CB;   // threads per channel (16 at CB = 16)
+    static_assert(DW_THREADS % CB == 0 && TPC <= WAVE && (TPC & (TPC - 1)) == 0, "a power-of-two lane group per channel");
+    const int c = threadIdx.x / TPC, sub = threadIdx.x % TPC;
     float wk[9], dwk[10];
 #pragma unroll
     for (int k9 = 0; k9 < 9; ++k9) { wk[k9] = s_w[c][k9]; dwk[k9] = 0.f; }
     dwk[9] = 0.f;
     const float bc = s_w[c][9];
-    for (int r = sub; r < GS * GS; r += 16) {
+    for (int r = sub; r < GS * GS; r += TPC) {
       const int px = r / GS, py = r - px * GS;
       const int h = h0 + py - 1, w = w0 + px - 1;
       float g = 0.f;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_cross_bwd_kernel(const floa
       s_g[c][py][px] = g;
     }
 #pragma unroll
-    for (int k9 = 0; k9 < 10; ++k9) dwk[k9] = group_sum<16>(dwk[k9]);
+    for (int k9 = 0; k9 < 10; ++k9) dwk[k9] = group_sum<TPC>(dwk[k9]);
     if (sub == 0) {
       float* o = ws + (((size_t)b * tiles + blockIdx.x) * D + d0 + c) * 10;
 #pragma unroll
