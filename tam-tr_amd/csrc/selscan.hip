@@ -331,16 +331,14 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
   auto drow = [&](int d) { return delta + (((size_t)b * K + k) * Dk + min(d, Dk - 1)) * L; };
 
 #ifndef SCAN_FPRIO
-#define SCAN_FPRIO 2   // the same issue-fairness trick as in the backward (below); forward: 4 waves per SIMD, two per workgroup, so the
+#define SCAN_FPRIO 1   // the same issue-fairness trick as in the backward (below); forward: 4 waves per SIMD, two per workgroup, so the
 #endif                 // parity is taken from the slot PAIR.  Measured: off 5.04 ms, slot parity 5.03, slot-pair parity 4.89 (three levels)
 #if SCAN_FPRIO
   unsigned fhwid;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(fhwid));   // wave slot on its SIMD
 #endif
   for (int c = 0; c < nchunk; ++c) {
-#if SCAN_FPRIO == 1
-    if ((fhwid + c) & 1) asm volatile("s_setprio 2"); else asm volatile("s_setprio 0");
-#elif SCAN_FPRIO == 2
+#if SCAN_FPRIO
     if (((fhwid >> 1) + c) & 1) asm volatile("s_setprio 2"); else asm volatile("s_setprio 0");
 #endif
     __syncthreads();  // previous chunk's tiles fully consumed
@@ -525,7 +523,8 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
   const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
 #ifndef SCAN_PRIO
-#define SCAN_PRIO 1   // measured (tools/build_variant.sh selscan, profiles/r03_scan_priority.txt): 0 = off 15.89 ms, 1: 15.32, 2: 15.37, 3: 15.52, 4: 15.41 (three levels, backward op)
+#define SCAN_PRIO 1   // measured (profiles/r03_scan_priority.txt; three levels, backward op): off 15.89 ms, on 15.32; priority 3 instead of 2, per-row or
+                      // every-second-chunk alternation were no better (15.37 / 15.52 / 15.48)
 #endif
 #if SCAN_PRIO
   // Issue fairness between the two waves of a SIMD (they belong to two workgroups and never meet at a barrier): the hardware arbitrates
@@ -536,11 +535,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
 #endif
   for (int c = nchunk - 1; c >= 0; --c) {
 #if SCAN_PRIO
-#if SCAN_PRIO == 2
-    if ((hwid + c) & 1) asm volatile("s_setprio 3"); else asm volatile("s_setprio 0");
-#elif SCAN_PRIO == 1
     if ((hwid + c) & 1) asm volatile("s_setprio 2"); else asm volatile("s_setprio 0");
-#endif
 #endif
     __syncthreads();  // previous chunk's tiles fully consumed / flushed
     STAMP(0)  // 0: waiting at the chunk-top barrier
@@ -571,11 +566,6 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
 
 #pragma unroll 1
     for (int r = 0; r < nrow; ++r) {
-#if defined(SCAN_PRIO) && SCAN_PRIO == 3
-      if ((hwid + c + r) & 1) asm volatile("s_setprio 2"); else asm volatile("s_setprio 0");
-#elif defined(SCAN_PRIO) && SCAN_PRIO == 4
-      if ((hwid + c + (r >> 1)) & 1) asm volatile("s_setprio 2"); else asm volatile("s_setprio 0");
-#endif
       const int d = d0 + r, wr = wave * BWD_RPW + r;
       const size_t row = ((size_t)b * K + k) * Dk + d;
       lane = lane0;
