@@ -130,14 +130,28 @@ def _run(case, dtype, graph=False, forced=False):
     return out
 
 
-@pytest.mark.parametrize('mode', ['eager', 'graph'])
+@pytest.mark.parametrize('mode', ['eager', 'graph', 'deterministic'])
 def test_full_model_640_fp32_vs_oracle(pkg, case640, mode):
     """configs[0]'s workload (640^2, fp32) on the HIP path against the CPU oracle: loss, every one of the 12 terms, and the raw
     decoder box / class logits (nn/tasks.py:580-672) at 1e-3.  Denoising queries sit at fixed positions and are compared
     elementwise; the 100 selected queries are compared as row sets (top-k order among near-equal scores is device dependent).
     mode 'graph': the same comparison with the static part replayed from HIP graphs, i.e. the benchmarked execution mode."""
     c = case640
-    loss, items, terms, db, ds, eb, es, meta = _run(c, None, graph=mode == 'graph')
+    if mode == 'deterministic':   # MIOpen on its deterministic solvers, NCHW trunk: no run-to-run term in the comparison (see the atol below)
+        from tamtr_amd import tuning
+        keep = (torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark, torch.are_deterministic_algorithms_enabled(),
+                torch.is_deterministic_algorithms_warn_only_enabled())
+        try:
+            tuning.use_deterministic_convolutions()
+            c['model'].set_channels_last(False)
+            loss, items, terms, db, ds, eb, es, meta = _run(c, None)
+        finally:
+            c['model'].set_channels_last(True)
+            torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = keep[0], keep[1]
+            torch.use_deterministic_algorithms(keep[2], warn_only=keep[3])
+            os.environ.pop('MIOPEN_DEBUG_CONVOLUTION_DETERMINISTIC', None)
+    else:
+        loss, items, terms, db, ds, eb, es, meta = _run(c, None, graph=mode == 'graph')
     assert meta['dn_num_split'] == c['meta']['dn_num_split']
     n_dn = meta['dn_num_split'][0]
     assert n_dn == 192 and db.shape == (3, 2, 292, 4)          # the bench's Q = 292
@@ -149,7 +163,8 @@ def test_full_model_640_fp32_vs_oracle(pkg, case640, mode):
     assert_close(db[:, :, :n_dn], c['db'][:, :, :n_dn], 1e-3, 2e-4, 'dn boxes')
     # logits = 14.3 x cosine (+ bias): 4e-3 absolute is 3e-4 of the cosine; the float-atomic gather backward / MIOpen's split-K sums make the
     # last digits run-to-run dependent (one of 11 520 logits was 5e-5 over a 2e-3 floor once)
-    assert_close(ds[:, :, :n_dn], c['ds'][:, :, :n_dn], 1e-3, 4e-3, 'dn class logits')
+    # (in deterministic mode the floor is back at 2e-3: VERDICT r2 item 4)
+    assert_close(ds[:, :, :n_dn], c['ds'][:, :, :n_dn], 1e-3, 2e-3 if mode == 'deterministic' else 4e-3, 'dn class logits')
     for b in range(2):
         for l in range(3):
             got = torch.cat([db[l, b, n_dn:], ds[l, b, n_dn:] / 10], -1)
