@@ -73,6 +73,26 @@ int tamtr_maxsigmoid_gate_cl_fwd(const void* e, long long ld_e, const float* mea
                                  const float* bias, void* out, float* aw, int32_t* arg, int B, int nh, int hc, int HW, int T, float scale,
                                  int dtype, void* stream);
 
+/*      next-3: the value branch itself.  Replaces `self.proj_conv(x)` = Conv(c1, c2, k=3, s=1, act=False) = nn.Conv2d(3x3, stride 1,
+ *      pad 1, no bias) + nn.BatchNorm2d in training mode (ultralytics/nn/extra_modules/block.py:205,223; Conv: nn/modules/conv.py)
+ *      for channels-last bf16 maps: an implicit-GEMM MFMA convolution whose epilogue leaves the BatchNorm's batch statistics, to be
+ *      followed by tamtr_maxsigmoid_gate_cl_fwd, which applies the affine in its load.  Forward only (TIAGELAN discards the gate: SURVEY D2).
+ *      x   bf16 [B*H*W, C1] with row pitch ld_x elements (a channel slice of a wider NHWC map is fine; 16-byte aligned, ld_x % 8 == 0)
+ *      wpk bf16 [C1/32][9][C2][32]   the weight [C2][C1][3][3] repacked by tamtr_conv3x3_pack_weight (w: TAMTR_F32 or TAMTR_BF16)
+ *      y   bf16 [B*H*W, C2] packed   the RAW convolution output (fp32 accumulation, rounded once)
+ *      partials f32 [C2][S][3], S = tamtr_conv3x3_tiles(B, H, W): (count, mean, M2) of the stored values per pixel tile
+ *      mean_rstd f32 [C2][2] (batch mean, 1/sqrt(biased var + eps)); running_mean / running_var f32 [C2] or both NULL: updated with
+ *      `momentum` (unbiased variance), as nn.BatchNorm2d does.  mean_rstd NULL: convolution + partials only.
+ *      C1 % 32 == 0, C2 % 64 == 0.  tamtr_bn_finalize: the per-channel combine on its own (partials [C][S][3] -> mean_rstd, running update).
+ */
+int tamtr_conv3x3_tiles(int B, int H, int W);
+int tamtr_conv3x3_pack_weight(const void* w, void* wpk, int C1, int C2, int dtype, void* stream);
+int tamtr_conv3x3_cl_stats_fwd(const void* x, long long ld_x, const void* wpk, void* y, float* running_mean, float* running_var,
+                               float* mean_rstd, float* partials, int B, int H, int W, int C1, int C2, float eps, float momentum,
+                               void* stream);
+int tamtr_bn_finalize(const float* partials, float* mean_rstd, float* running_mean, float* running_var, int C, int S, float eps,
+                      float momentum, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * a-6  Multi-scale deformable attention core.  Replaces multi_scale_deformable_attn_pytorch,
  *      ultralytics/nn/modules/utils.py:42-89 (3x F.grid_sample(bilinear, zeros, align_corners=False) + weighted sum).

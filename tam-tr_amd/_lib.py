@@ -10,7 +10,7 @@ from ctypes import c_float, c_int, c_longlong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TAMTR_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libtamtr_hip.so')  # env override: kernel A/B experiments
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 F32, BF16 = 0, 1
 _ERR = {-1: 'TAMTR_EINVAL (bad argument)', -2: 'TAMTR_EUNSUP (shape/dtype outside what the kernels are built for)',
@@ -66,6 +66,10 @@ _SIGS = {
     'tamtr_bncl_blocks': [_LL, _I, _I],
     'tamtr_bncl_act_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _F, _F, _I, _I, _P],
     'tamtr_bncl_stats': [_P, _P, _P, _P, _P, _LL, _I, _F, _F, _I, _P],
+    'tamtr_bn_finalize': [_P, _P, _P, _P, _I, _I, _F, _F, _P],
+    'tamtr_conv3x3_tiles': [_I, _I, _I],
+    'tamtr_conv3x3_pack_weight': [_P, _P, _I, _I, _I, _P],
+    'tamtr_conv3x3_cl_stats_fwd': [_P, _LL, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P],
     'tamtr_maxsigmoid_gate_cl_fwd': [_P, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     'tamtr_bncl2_act_fwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _F, _F, _I, _I, _P],
     'tamtr_bncl2_act_bwd': [_P, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _P],

@@ -808,6 +808,16 @@ extern "C" int tamtr_bncl2_act_bwd(const void* gy, long long ldgy, const void* x
   return tamtr_launch_status();
 }
 
+// ---- per-channel combine alone, for a producer that leaves (count, mean, M2) partials itself (conv3x3.hip's epilogue): partials f32
+// [C][S][3] -> mean_rstd f32 [C][2] + the running-statistics update
+extern "C" int tamtr_bn_finalize(const float* partials, float* mean_rstd, float* running_mean, float* running_var, int C, int S, float eps,
+                                 float momentum, void* stream) {
+  if (!partials || !mean_rstd || C <= 0 || S <= 0 || (!running_mean) != (!running_var)) return TAMTR_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_THREADS), 0, (hipStream_t)stream, partials, mean_rstd, running_mean, running_var, S, eps,
+                     momentum);
+  return tamtr_launch_status();
+}
+
 // ---- batch statistics only (for a consumer that applies the normalisation itself: the channels-last gate, gate.hip):
 // mean_rstd f32 [C][2] of x [N, C] plus the running-statistics update; partials as for tamtr_bncl_act_fwd
 extern "C" int tamtr_bncl_stats(const void* x, float* running_mean, float* running_var, float* mean_rstd, float* partials, long long N, int C,

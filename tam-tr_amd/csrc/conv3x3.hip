@@ -1,0 +1,223 @@
+// conv3x3.hip - the value branch of the text gate: proj_conv = Conv2d(c, c, 3, stride 1, pad 1, no bias) followed by BatchNorm
+// (ultralytics/nn/extra_modules/block.py:205,223) as an implicit-GEMM MFMA kernel over channels-last bf16 maps,
+// with the BatchNorm's batch statistics taken in the epilogue.  The gate kernel (gate.hip: gate_cl_fwd_kernel) applies the affine
+// in its own load, so the branch is: this kernel -> one per-channel combine -> the gate.  Forward only: every TAM-TR instance of the
+// gate is the discarded evaluation of TIAGELAN, whose only live result is the running statistics.
+//
+// GEMM view: out[p][co] = sum over (tap, ci) of x[p + tap][ci] * w[co][ci][tap]; M = B*H*W pixels, N = C2, K = 9*C1.
+// A workgroup owns an 8 x 16 pixel tile x 64 output channels.  K is walked in chunks of 32 input channels: per chunk the 10 x 18
+// HALO tile of the input (11.5 KB) and the chunk's 9 x 64 x 32 weights (36.9 KB) are staged in LDS once and serve all nine taps -
+// the input map is read once per 64 output channels, never nine times.  Both LDS tiles hold 64-byte rows (32 bf16) whose four
+// 16-byte pieces are XOR-swizzled with bits 1-2 of the row index: the MFMA fragment reads (consecutive lanes = consecutive rows,
+// same piece) then spread over all banks without padding.  The next chunk's global loads are issued before the chunk's 36 MFMAs
+// per wave and written to LDS after them.
+// MFMA orientation: A = weights (m = output channel), B = pixels (n = pixel), so a lane ends up with 4 consecutive channels of
+// one pixel per accumulator group: 8-byte pieces of a [pixel][channel] LDS tile, from which the workgroup stores whole 128-byte
+// channel runs and sums the per-channel statistics of the values AS STORED (bf16-rounded, what a separate statistics pass over
+// the stored map would see).
+#include "common.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CV_TH = 8, CV_TW = 16;             // pixel tile
+constexpr int CV_HW = CV_TW + 2, CV_HH = CV_TH + 2;
+constexpr int CV_HALO = CV_HH * CV_HW;           // 180 halo pixels
+constexpr int CV_NT = 64;                        // output channels per workgroup
+constexpr int CV_CK = 32;                        // input channels per LDS stage
+constexpr int CV_THREADS = 256;
+constexpr int CV_XI = (CV_HALO * 4 + CV_THREADS - 1) / CV_THREADS;  // 16-byte halo pieces per thread (3)
+constexpr int CV_WI = 9 * CV_NT * 4 / CV_THREADS;                   // 16-byte weight pieces per thread (9)
+constexpr int CV_SX_BYTES = CV_HALO * 64;        // 11 520
+constexpr int CV_SW_BYTES = 9 * CV_NT * 64;      // 36 864
+
+// byte offset of 16-byte piece c (0..3) of 64-byte row r
+__device__ __forceinline__ int sw64(int r, int c) { return r * 64 + ((c ^ ((r >> 1) & 3)) << 4); }
+
+// w [C2][C1][3][3] (f32 or bf16) -> wpk bf16 [C1/32][9][C2][32]: a stage's rows (one tap, 64 channels) are contiguous 64-byte rows
+template <typename T>
+__global__ void conv3x3_pack_kernel(const T* __restrict__ w, bf16_t* __restrict__ wpk, int C1, int C2) {
+  const int total = 9 * C1 * C2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int ci_l = i % CV_CK, co = (i / CV_CK) % C2, tap = (i / (CV_CK * C2)) % 9, cc = i / (CV_CK * C2 * 9);
+    const int ci = cc * CV_CK + ci_l;
+    wpk[i] = f2bf(Elt<T>::ld(w + ((size_t)co * C1 + ci) * 9 + tap));
+  }
+}
+
+__global__ __launch_bounds__(CV_THREADS) void conv3x3_cl_kernel(const bf16_t* __restrict__ x, size_t ld_x, const bf16_t* __restrict__ wpk,
+                                                                 bf16_t* __restrict__ y, float* __restrict__ part, int H, int W, int C1,
+                                                                 int C2, int tiles_x, int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cv_smem[];
+  unsigned char* s_x = cv_smem;
+  unsigned char* s_w = cv_smem + CV_SX_BYTES;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE), lane = tid % WAVE, lr = lane & 31, lh = lane >> 5;
+  const int tile = blockIdx.x, n0 = blockIdx.y * CV_NT;
+  const int S = gridDim.x;
+  const int b = tile / (tiles_x * tiles_y), ty0 = ((tile / tiles_x) % tiles_y) * CV_TH, tx0 = (tile % tiles_x) * CV_TW;
+  const int nchunk = C1 / CV_CK;
+
+  // ---- staging plan of this thread (the same for every chunk): source element offsets (or -1: zero) and LDS byte offsets
+  long long xsrc[CV_XI];
+  int xdst[CV_XI];
+  bool xok[CV_XI];
+#pragma unroll
+  for (int j = 0; j < CV_XI; ++j) {
+    const int i = tid + j * CV_THREADS;
+    const int hp = min(i, CV_HALO * 4 - 1) >> 2, c = i & 3;
+    const int gy = ty0 + hp / CV_HW - 1, gx = tx0 + hp % CV_HW - 1;
+    const bool in = i < CV_HALO * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    // (a piece outside the image is loaded from the map's first pixel and replaced by zeros: no load sits under a branch)
+    xsrc[j] = in ? (long long)(((size_t)b * H + gy) * W + gx) * (long long)ld_x + c * 8 : 0;
+    xok[j] = in;
+    xdst[j] = i < CV_HALO * 4 ? sw64(hp, c) : -1;
+  }
+  // (staging written out as macros: arrays captured by reference in a lambda end up in scratch memory with this compiler)
+  u32x4 xr[CV_XI], wr[CV_WI];
+#define CV_FETCH(cc)                                                                                                         \
+  {                                                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < CV_XI; ++j) {                                                                      \
+      xr[j] = *reinterpret_cast<const u32x4*>(x + xsrc[j] + (cc) * CV_CK);                                                   \
+      if (!xok[j]) xr[j] = u32x4{0u, 0u, 0u, 0u};                                                                         \
+    }                                                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < CV_WI; ++j) {                                                                      \
+      const int i = tid + j * CV_THREADS, row = i >> 2, c = i & 3; /* row = tap * 64 + co */                                 \
+      wr[j] = *reinterpret_cast<const u32x4*>(wpk + (((size_t)(cc) * 9 + (row >> 6)) * C2 + n0 + (row & 63)) * CV_CK + c * 8); \
+    }                                                                                                                        \
+  }
+#define CV_COMMIT()                                                                                                          \
+  {                                                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < CV_XI; ++j)                                                                        \
+      if (xdst[j] >= 0) *reinterpret_cast<u32x4*>(s_x + xdst[j]) = xr[j];                                                    \
+    _Pragma("unroll") for (int j = 0; j < CV_WI; ++j) {                                                                      \
+      const int i = tid + j * CV_THREADS;                                                                                    \
+      *reinterpret_cast<u32x4*>(s_w + sw64(i >> 2, i & 3)) = wr[j];                                                          \
+    }                                                                                                                        \
+  }
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { acc[0][q] = 0.f; acc[1][q] = 0.f; }
+  // this lane's pixel in the halo tile (tap (0, 0)): wave w owns tile rows 2 w, 2 w + 1
+  const int hp0 = (2 * wave + (lr >> 4)) * CV_HW + (lr & 15);
+  const int wsw = (lr >> 1) & 3;  // swizzle key of the weight rows this lane reads (row = tap * 64 + 32 nb + lr)
+
+  CV_FETCH(0)
+  for (int cc = 0; cc < nchunk; ++cc) {
+    __syncthreads();  // previous chunk's fragments all read
+    CV_COMMIT()
+    __syncthreads();
+    if (cc + 1 < nchunk) CV_FETCH(cc + 1)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int hp = hp0 + (tap / 3) * CV_HW + tap % 3;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int c = 2 * ks + lh;
+        const s16x8 pf = *reinterpret_cast<const s16x8*>(s_x + sw64(hp, c));
+        const unsigned char* wrow = s_w + (tap * CV_NT + lr) * 64 + ((c ^ wsw) << 4);
+        const s16x8 w0 = *reinterpret_cast<const s16x8*>(wrow), w1 = *reinterpret_cast<const s16x8*>(wrow + 32 * 64);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, pf, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, pf, acc[1], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue.  D[i][j]: i = channel (q & 3) + 8 (q >> 2) + 4 lh (+ 32 nb), j = pixel lr of the wave's 32.
+  // LDS tile [128 pixels][64 channels] bf16 (128-byte rows, 16-byte pieces XOR-ed with pixel & 7) over the weight stage.
+  __syncthreads();
+  unsigned char* s_o = s_w;
+  {
+    const int p = 32 * wave + lr;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = 32 * nb + 8 * g + 4 * lh;
+        uint2 v;
+        v.x = (uint32_t)f2bf(acc[nb][4 * g]) | ((uint32_t)f2bf(acc[nb][4 * g + 1]) << 16);
+        v.y = (uint32_t)f2bf(acc[nb][4 * g + 2]) | ((uint32_t)f2bf(acc[nb][4 * g + 3]) << 16);
+        *reinterpret_cast<uint2*>(s_o + p * 128 + (((co >> 3) ^ (p & 7)) << 4) + (co & 7) * 2) = v;
+      }
+  }
+  __syncthreads();
+  // thread = (channel group j of 8, pixel t / 8 + 32 i): whole 128-byte channel runs per pixel; statistics of what is stored
+  const int j8 = tid & 7;
+  float sm[8], sq[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sm[k] = 0.f; sq[k] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = (tid >> 3) + 32 * i;  // tile pixel: row p / 16, column p % 16
+    const int gy = ty0 + (p >> 4), gx = tx0 + (p & 15);
+    const uint4 v = *reinterpret_cast<const uint4*>(s_o + p * 128 + ((j8 ^ (p & 7)) << 4));
+    if (gy < H && gx < W) {
+      *reinterpret_cast<uint4*>(y + (((size_t)b * H + gy) * W + gx) * C2 + n0 + 8 * j8) = v;
+      const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float a = __uint_as_float(u[k] << 16), c = __uint_as_float(u[k] & 0xffff0000u);
+        sm[2 * k] += a; sq[2 * k] = fmaf(a, a, sq[2 * k]);
+        sm[2 * k + 1] += c; sq[2 * k + 1] = fmaf(c, c, sq[2 * k + 1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int o = 8; o < WAVE; o <<= 1) { sm[k] += __shfl_xor(sm[k], o, WAVE); sq[k] += __shfl_xor(sq[k], o, WAVE); }
+  float* s_st = reinterpret_cast<float*>(s_x);  // [4 waves][64 channels][2]
+  if (lane < 8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      s_st[(wave * CV_NT + 8 * j8 + k) * 2] = sm[k];
+      s_st[(wave * CV_NT + 8 * j8 + k) * 2 + 1] = sq[k];
+    }
+  }
+  __syncthreads();
+  if (tid < CV_NT) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int w = 0; w < CV_THREADS / WAVE; ++w) { s += s_st[(w * CV_NT + tid) * 2]; q += s_st[(w * CV_NT + tid) * 2 + 1]; }
+    const float n = (float)(min(CV_TH, H - ty0) * min(CV_TW, W - tx0));
+    const float mean = s / n;
+    float* o = part + ((size_t)(n0 + tid) * S + tile) * 3;  // (count, mean, M2) of the tile, bn.hip's partial layout
+    o[0] = n; o[1] = mean; o[2] = fmaxf(q - s * mean, 0.f);
+  }
+}
+
+#undef CV_FETCH
+#undef CV_COMMIT
+
+}  // namespace
+
+extern "C" int tamtr_conv3x3_tiles(int B, int H, int W) { return B * ((H + CV_TH - 1) / CV_TH) * ((W + CV_TW - 1) / CV_TW); }
+
+extern "C" int tamtr_conv3x3_pack_weight(const void* w, void* wpk, int C1, int C2, int dtype, void* stream) {
+  if (!w || !wpk || C1 <= 0 || C2 <= 0) return TAMTR_EINVAL;
+  if (C1 % CV_CK || C2 % CV_NT) return TAMTR_EUNSUP;
+  hipStream_t s = (hipStream_t)stream;
+  const int total = 9 * C1 * C2, blocks = (total + 255) / 256;
+  if (dtype == TAMTR_F32) hipLaunchKernelGGL(conv3x3_pack_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)w, (bf16_t*)wpk, C1, C2);
+  else if (dtype == TAMTR_BF16) hipLaunchKernelGGL(conv3x3_pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)w, (bf16_t*)wpk, C1, C2);
+  else return TAMTR_EINVAL;
+  return tamtr_launch_status();
+}
+
+extern "C" int tamtr_conv3x3_cl_stats_fwd(const void* x, long long ld_x, const void* wpk, void* y, float* running_mean, float* running_var,
+                                          float* mean_rstd, float* partials, int B, int H, int W, int C1, int C2, float eps, float momentum,
+                                          void* stream) {
+  if (!x || !wpk || !y || !partials || B <= 0 || H <= 0 || W <= 0 || ld_x < C1) return TAMTR_EINVAL;
+  if (C1 % CV_CK || C2 % CV_NT || ld_x % 8 || ((uintptr_t)x | (uintptr_t)wpk | (uintptr_t)y) % 16) return TAMTR_EUNSUP;
+  const int tiles_y = (H + CV_TH - 1) / CV_TH, tiles_x = (W + CV_TW - 1) / CV_TW;
+  const long long S = (long long)B * tiles_x * tiles_y;
+  if (S > 0x7fffffffLL || C2 / CV_NT > 65535) return TAMTR_EUNSUP;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(conv3x3_cl_kernel, dim3((unsigned)S, C2 / CV_NT), dim3(CV_THREADS), CV_SX_BYTES + CV_SW_BYTES, s, (const bf16_t*)x,
+                     (size_t)ld_x, (const bf16_t*)wpk, (bf16_t*)y, partials, H, W, C1, C2, tiles_x, tiles_y);
+  if (hipGetLastError() != hipSuccess) return TAMTR_ELAUNCH;
+  if (!mean_rstd) return TAMTR_OK;
+  return tamtr_bn_finalize(partials, mean_rstd, running_mean, running_var, C2, (int)S, eps, momentum, stream);
+}

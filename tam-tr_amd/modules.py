@@ -44,6 +44,10 @@ class MaxSigmoidAttnBlock(nn.Module):
                 and pc.bn.training and pc.bn.affine and isinstance(pc.act, nn.Identity) and ops.gate_cl_ok(x, x.shape[1], self.nh)):
             # NHWC trunk, nothing to differentiate (TIAGELAN's discarded evaluation): the BatchNorm of proj_conv is applied
             # inside the gate kernel's load of the raw convolution output - no apply pass, no NCHW repacking (next-3)
+            if ops.conv3x3_cl_ok(x, pc.conv) and ops.bn_cl_ok(pc.conv.out_channels, x.dtype):
+                # bf16: the 3x3 convolution itself on the MFMA kernel of csrc/conv3x3.hip, batch statistics from its epilogue
+                v_raw, stats = ops.conv3x3_cl_stats(x, pc.conv, pc.bn)
+                return ops.maxsigmoid_gate_cl(x, gk, self.bias, v_raw, stats, pc.bn, self.nh, 1.0)
             v_raw = pc.conv(x)
             if ops.is_cl(v_raw) and v_raw.dtype == x.dtype and ops.bn_cl_ok(v_raw.shape[1], v_raw.dtype):
                 stats = ops.bn_stats_cl(v_raw.permute(0, 2, 3, 1).reshape(bs * h * w, -1), pc.bn)

@@ -10,6 +10,9 @@ import torch
 
 from . import _lib
 from ._lib import call, dtype_code, ptr, require_gpu, stream_ptr
+import os as _os
+
+_PROJ_CONV_LIB = _os.environ.get('TAMTR_PROJ_CONV') == 'miopen'   # A/B switch: the gate's 3x3 value convolution on the library
 
 _I, _F = ctypes.c_int, ctypes.c_float
 
@@ -297,6 +300,40 @@ def bn_stats_cl(x2d, bn):
     return mr
 
 
+def conv3x3_cl_ok(x, conv):
+    """What tamtr_conv3x3_cl_stats_fwd takes: a bf16 channels-last map (or a channel slice of one) into a plain 3x3 / stride 1 / pad 1
+    convolution without bias, C1 % 32 == 0, C2 % 64 == 0.  TAMTR_PROJ_CONV=miopen keeps the library convolution (A/B switch)."""
+    if _PROJ_CONV_LIB or not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4):
+        return False
+    ld = _cl_pitch(x)
+    return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and conv.padding_mode == 'zeros'
+            and conv.in_channels == x.shape[1] and conv.in_channels % 32 == 0 and conv.out_channels % 64 == 0
+            and ld and ld % 8 == 0 and x.data_ptr() % 16 == 0 and conv.weight.dtype in (torch.float32, torch.bfloat16))
+
+
+@torch.no_grad()
+def conv3x3_cl_stats(x, conv, bn):
+    """proj_conv of the text gate (block.py:205,223) without its BatchNorm's apply pass: returns (v_raw, mean_rstd) - the raw 3x3
+    convolution of the channels-last bf16 map x [B,C1,H,W] as [B,C2,H,W] channels-last bf16, and the BatchNorm's batch statistics
+    f32 [C2, 2], taken in the convolution's epilogue; the running statistics and the counter of `bn` are updated like a training-mode
+    forward.  Forward only (the discarded evaluation); feeds maxsigmoid_gate_cl."""
+    require_gpu(x)
+    B, C1, H, W = x.shape
+    C2 = conv.out_channels
+    w = _c(conv.weight)
+    wpk = torch.empty(9 * C1 * C2, device=x.device, dtype=torch.bfloat16)
+    call('tamtr_conv3x3_pack_weight', ptr(w), ptr(wpk), C1, C2, dtype_code(w), stream_ptr())
+    y = torch.empty((B, C2, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    mom = _bn_tick(bn)
+    mr = torch.empty(C2, 2, device=x.device, dtype=torch.float32)
+    part = torch.empty(C2 * _lib.lib().tamtr_conv3x3_tiles(B, H, W) * 3, device=x.device, dtype=torch.float32)
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    call('tamtr_conv3x3_cl_stats_fwd', ptr(x), _cl_pitch(x), ptr(wpk), ptr(y), ptr(rm), ptr(rv), ptr(mr), ptr(part), B, H, W, C1, C2,
+         float(bn.eps), float(mom), stream_ptr())
+    return y, mr
+
+
 @torch.no_grad()
 def maxsigmoid_gate_cl(e, gk, bias, v_raw, v_stats, v_bn, nh, scale=1.0):
     """Forward-only gate on channels-last operands with the value branch's BatchNorm (batch statistics v_stats from bn_stats_cl, affine
@@ -319,8 +356,6 @@ def maxsigmoid_gate(x, gk, bias, v, nh, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------------------ a-6 deformable core
-import os as _os
-
 _MSDA_ATOMICS = _os.environ.get('TAMTR_MSDA_ATOMICS') == '1'   # A/B switch: the round-1/2 float-atomic scatter
 
 

@@ -713,3 +713,39 @@ def test_colsum_bias_gradient_kernel(M, N):
     ref = x.double().sum(0)
     err = float((a.double() - ref).abs().max())
     assert err <= 1e-5 * float(x.double().abs().sum(0).max()), err       # fp32 accumulation over <= 264 rows per partial, then <= 2048 partials
+
+
+# ------------------------------------------------------------------------------------------------ next-3: proj_conv on MFMA
+@pytest.mark.parametrize('B,C,H,W,sliced', [(2, 64, 160, 160, True), (2, 128, 80, 80, True), (2, 256, 40, 40, True),
+                                            (1, 64, 13, 21, False), (3, 128, 8, 16, False), (1, 64, 320, 320, True)])
+def test_conv3x3_cl_stats_vs_fp32_conv(ops, B, C, H, W, sliced):
+    """tamtr_conv3x3_cl_stats_fwd (the gate's value branch, block.py:205,223: Conv2d 3x3 s1 p1 no bias + training BatchNorm
+    statistics) at the five TIAGELAN sites' shapes (640 px), the 1280 px level-0 shape and two ragged maps, against torch's CPU fp32
+    convolution of the same bf16 values.  Output: one bf16 rounding of an fp32 sum (2^-8 relative + accumulation-order noise);
+    statistics: exactly those of the stored values (double-precision check), the running update as nn.BatchNorm2d does it."""
+    torch.manual_seed(C + H)
+    wide = (rnd((B, 2 * C if sliced else C, H, W), 1) * 1.5).bfloat16()
+    conv = torch.nn.Conv2d(C, C, 3, 1, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.03)
+    with torch.no_grad():
+        conv.weight.copy_(rnd((C, C, 3, 3), 2, (9 * C) ** -0.5 * 2.0))
+        bn.running_mean.copy_(rnd((C,), 3, 0.1)); bn.running_var.copy_(1 + 0.1 * rnd((C,), 4).abs())
+    x_cpu = (wide.chunk(2, 1)[1] if sliced else wide).float()
+    ref = F.conv2d(x_cpu, conv.weight.detach().bfloat16().float(), padding=1)          # fp32, same bf16 operands
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    conv, bn = conv.cuda(), bn.cuda().train()
+    wd = wide.cuda().contiguous(memory_format=torch.channels_last)
+    x = wd.chunk(2, 1)[1] if sliced else wd
+    assert ops.conv3x3_cl_ok(x, conv)
+    y, mr = ops.conv3x3_cl_stats(x, conv, bn)
+    assert y.dtype == torch.bfloat16 and y.shape == (B, C, H, W) and y.is_contiguous(memory_format=torch.channels_last)
+    scale = float(ref.abs().max())
+    assert_close(y.float(), ref, 2 ** -7, 2e-3 * scale, 'conv output')
+    yd = y.float().cpu().double()
+    mean, var = yd.mean((0, 2, 3)), yd.var((0, 2, 3), unbiased=False)
+    assert_close(mr[:, 0], mean, 1e-4, 1e-5 * scale, 'batch mean')
+    assert_close(mr[:, 1], (var + 1e-3).rsqrt(), 1e-4, 0, 'batch rstd')
+    n = B * H * W
+    assert_close(bn.running_mean, 0.97 * rm0.double() + 0.03 * mean, 1e-5, 1e-6, 'running_mean')
+    assert_close(bn.running_var, 0.97 * rv0.double() + 0.03 * var * n / (n - 1), 1e-4, 1e-6, 'running_var')
+    assert int(bn.num_batches_tracked) == 1

@@ -157,8 +157,29 @@ def bench_lsap():
         print(f'lsap nq={nq} boxes/img={groups[0]} x {len(groups)} images: {a * 1e3:.0f} us avg, {mn * 1e3:.0f} us min (one launch, no host round trip)')
 
 
+def bench_projconv():
+    """The gate's value branch at the five TIAGELAN sites (three shapes, 16 images, bf16 channels-last slice of the cv1 output): the MFMA
+    kernel with the statistics in its epilogue against the library convolution + tamtr_bncl_stats."""
+    import torch.nn as nn
+    for C, S in [(64, 160), (128, 80), (256, 40)]:
+        wide = torch.randn(16, 2 * C, S, S, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last)
+        x = wide.chunk(2, 1)[1]
+        conv = nn.Conv2d(C, C, 3, 1, 1, bias=False).cuda()
+        bn = nn.BatchNorm2d(C, eps=1e-3, momentum=0.03).cuda().train()
+        flop = 2 * 9 * C * C * 16 * S * S
+        own, own_min = timeit(lambda: ops.conv3x3_cl_stats(x, conv, bn), n=20, warm=3)
+        w16 = conv.weight.detach().bfloat16().contiguous(memory_format=torch.channels_last)
+        def lib():
+            v = torch.nn.functional.conv2d(x, w16, padding=1)
+            return ops.bn_stats_cl(v.permute(0, 2, 3, 1).reshape(-1, C), bn)
+        torch.backends.cudnn.benchmark = True
+        libt, lib_min = timeit(lib, n=20, warm=3)
+        print(f'proj_conv {C} ch x {S}^2 x 16: own conv + stats {own * 1e3:.0f} us avg / {own_min * 1e3:.0f} min '
+              f'({flop / own_min / 1e9:.0f} TFLOP/s), library conv + stats kernel {libt * 1e3:.0f} us avg / {lib_min * 1e3:.0f} min')
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['all']
-    for name in ('scan', 'gemm', 'gate', 'msda', 'attn', 'cpam', 'dwconv', 'lsap'):
+    for name in ('scan', 'gemm', 'gate', 'msda', 'attn', 'cpam', 'dwconv', 'lsap', 'projconv'):
         if name in which or 'all' in which:
             globals()['bench_' + name]()
