@@ -45,6 +45,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+HBM_PEAK_GBS = 8000.0           # HBM3E, same guide ("~8 TB/s"); a device copy of the GEMM's 1.10 GB reaches 5.45 TB/s (profiles/r03_gemm_vs_copy.txt)
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 
@@ -91,6 +92,14 @@ class KernelTimer:
         ms = sorted(a.elapsed_time(b) for a, b, f in ev if f == top)
         avg = sum(ms) / len(ms)
         return {'launches': len(ms), 'avg_ms': avg, 'min_ms': ms[0], 'tflops': top / (avg * 1e-3) / 1e12}
+
+
+def _hbm_view(args, ks):
+    if args.dtype != 'bf16':
+        return None
+    M = args.batch * (args.imgsz // 4) ** 2 * 21 // 16
+    gbs = (M * 512 + M * 512) * 2 / (ks['avg_ms'] * 1e-3) / 1e9
+    return {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS}
 
 
 def gemm_traffic(args):
@@ -355,7 +364,10 @@ def main():
                 'bound': 'mfma', 'kernel': 'linear_bf16_wstat_kernel<512> (MEH value_proj x3 + enc_output and their dX, M=%d N=K=512)'
                                            % (args.batch * (args.imgsz // 4) ** 2 * 21 // 16),
                 'achieved': ks['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': ks['tflops'] / peak, 'traffic': gemm_traffic(args),
-                'avg_ms': ks['avg_ms'], 'launches': ks['launches']},
+                'avg_ms': ks['avg_ms'], 'launches': ks['launches'],
+                # the same launches priced against the OTHER roof (the shape sits at the chip's balance point: 256 flop/B against 312):
+                # algorithmic bytes (X read once + Y written once) per second over the 8 TB/s HBM peak
+                'hbm_view': _hbm_view(args, ks)},
         }
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.cpu_baseline_images, args.imgsz)

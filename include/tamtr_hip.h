@@ -174,8 +174,8 @@ int tamtr_selfattn_bwd(const void* go, const void* q, const void* k, const void*
  *      calls at ultralytics/nn/extra_modules/VManba/csms6s.py:257,267 (contract: vmamba.py:962-990), fp32:
  *          dt = softplus(delta + dbias);  h_t = exp(dt_t A) h_{t-1} + dt_t B_t u_t;  y_t = <C_t, h_t> + D u_t
  *      u, delta f32 [B, KD, L]; A f32 [KD, N]; Bm, Cm f32 [B, K, N, L]; D, dbias f32 [KD]; y f32 [B, KD, L].
- *      N == 16.  hstate f32 [B, KD, nchunk, N]: chunk-boundary states saved for _bwd, nchunk = ceil(L / chunk) with
- *      `chunk` returned by tamtr_selective_scan_chunk().
+ *      N == 16.  hstate f32 [B, KD, nchunk, N]: state checkpoints saved for _bwd (the state after every `chunk` steps),
+ *      nchunk = ceil(L / chunk) with `chunk` returned by tamtr_selective_scan_chunk() (64 since ABI 23).
  *      xmode = 0: plain contract above.  xmode = 1 ("cross-scan layout", K must be 4; replaces the 4x materialisation of
  *      CrossScan, csms6s.py:4-14): u is [B, 2, Dk, L] = (row-major, column-major) flattenings of the map, direction k reads
  *      u[:, k & 1]; directions k >= 2 are the reversed scans and walk EVERY time-indexed buffer (u, delta, B, C, y and the

@@ -31,6 +31,7 @@ namespace {
 constexpr int NS = 16;         // d_state
 constexpr int ITEMS = 4;       // time steps per lane
 constexpr int CHUNK = WAVE * ITEMS;
+constexpr int BLK = 16 * ITEMS;   // steps per 16-lane DPP row: the forward leaves a state checkpoint after every block (4 per chunk)
 constexpr int FWD_ROWS = 8;    // waves (= rows of one (b,k) group) per workgroup, forward
 constexpr int FWD_RPW = 4;     // rows per wave and chunk, forward (they share the staged tiles)
 constexpr int BWD_WAVES = 4;   // waves per workgroup, backward
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
                                                                       float* __restrict__ hstate, int K, int Dk, int L, int nchunk,
                                                                       int xmode, const float* __restrict__ dtr,
                                                                       const float* __restrict__ Wdt, int R) {
+  const int nblk = (L + BLK - 1) / BLK;  // checkpoints per row: hstate is [rows][nblk][NS]
   extern __shared__ __attribute__((aligned(16))) float smem[];  // B tile | C tile | dt factors | Wdt rows | row constants | carried h
   float(*sB)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(smem);
   float(*sC)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(smem + NS * CHUNK);
@@ -364,6 +366,12 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
       // delta_t = <Wdt[kd, :], dtr[:, t]>: the [B, 4*d_inner, L] delta tensor of the reference is never materialised
       if (DTR) dtproj_row(s_W + wr * RMAX, s_dtr, R, lane, dt);
       const float Dd = rdlane(par, 16), bias = rdlane(par, 17);
+      // checkpoints for the backward: the state after every 64-step block = what the last lane of each 16-lane row holds after its
+      // four steps; those four lanes store it themselves, state by state (byte offset of state 0; every other lane, and a block that
+      // starts beyond L, is dropped by the buffer's range check)
+      const __amdgpu_buffer_rsrc_t hs_rs = row_rsrc(hstate + row * (size_t)nblk * NS, nblk * NS);
+      const int blk = c * (CHUNK / BLK) + (lane >> 4);
+      const unsigned hs_off = ((lane & 15) == 15 && blk < nblk) ? (unsigned)blk * NS * 4 : OOB;
 #pragma unroll
       for (int i = 0; i < ITEMS; ++i) {
         dt[i] = softplus_f((t + i < L) ? dt[i] + bias : -1e30f);  // steps beyond L become the identity map (dt = 0: a = 1, b = 0)
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
       }
 #pragma unroll
       for (int n = 0; n < NS; n += 2) {
-        float a[2][ITEMS], bb[2][ITEMS], cc[2][ITEMS], A[2], Bv[2];
+        float a[2][ITEMS], bb[2][ITEMS], cc[2][ITEMS], A[2], Bv[2], hend[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float4 b4 = *reinterpret_cast<const float4*>(&sB[n + j][lane * ITEMS]);
@@ -401,14 +409,18 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
             yy[i] = fmaf(cc[j][i], hh, yy[i]);
           }
           write_lane(nh, rdlane(hh, WAVE - 1), n + j);  // state after the chunk
+          hend[j] = hh;
+        }
+        {  // the pair's two checkpoint values are neighbours in memory: one 8-byte store
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 w = {__builtin_bit_cast(unsigned, hend[0]), __builtin_bit_cast(unsigned, hend[1])};
+          __builtin_amdgcn_raw_buffer_store_b64(w, hs_rs, hs_off, n * 4, 0);
         }
         asm volatile("" : "+v"(yy[0]), "+v"(yy[1]), "+v"(yy[2]), "+v"(yy[3]), "+v"(nh));
         __builtin_amdgcn_sched_barrier(0);  // one pair's temporaries at a time
       }
       store4<VEC>(y + row * L, t, L, yy, rev);
       if (lane < NS) s_h[wr * NS + lane] = nh;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, nh), row_rsrc(hstate + (row * nchunk + c) * NS, NS),
-                                            lane < NS ? lane * 4 : OOB, 0, 0);
     }
   }
 }
@@ -438,15 +450,33 @@ __device__ __forceinline__ void bwd_fetch_row(const float* __restrict__ u, const
   uu = load4_issue<VEC>(xmode ? u + prow * L : u + row * L, t, L, rev);
   g = load4_issue<VEC>((xmode & 2) ? gy + prow * L : gy + row * L, t, L, rev);
 }
-// the row's small operands in ONE register: lane n < 16: A[kd][n]; lane 16: D[kd]; lane 17: delta bias; lanes 32..47: the
-// state entering chunk c (c > 0).  Read back per state with v_readlane (wave-uniform operands of the VALU ops).
+// the row's small operands in ONE register: lane n < 16: A[kd][n]; lane 16: D[kd]; lane 17: delta bias.  Read back per state with
+// v_readlane (wave-uniform operands of the VALU ops).
 __device__ __forceinline__ float bwd_fetch_param(const float* __restrict__ Am, const float* __restrict__ Dv, const float* __restrict__ dbias,
-                                                 const float* __restrict__ hstate, int kd, size_t row, int nchunk, int c, int lane) {
+                                                 int kd, int lane) {
   const float* p = Am + (size_t)kd * NS + (lane & (NS - 1));
   if (lane == 16) p = Dv + kd;
   if (lane == 17) p = dbias + kd;
-  if (lane >= 32 && lane < 48 && c > 0) p = hstate + (row * nchunk + (c - 1)) * NS + (lane - 32);
-  return *p;  // (lanes 32..47 hold A again when c == 0: the reader substitutes zero)
+  return *p;
+}
+// the four checkpoints a (row, chunk) needs, ONE coalesced 256-byte load: lane (r, j) gets state j ENTERING the 64-step block that DPP
+// row r works on (time runs against the lanes in the backward: row r holds block 3 - r of the chunk), i.e. the forward's checkpoint
+// after block c * 4 + (3 - r) - 1.  Block 0 of the sequence starts from zero (selected by the reader, address clamped here), a block
+// that starts beyond L is never looked at with a non-zero weight (clamped too).
+__device__ __forceinline__ float bwd_fetch_ck(const float* __restrict__ hstate, size_t row, int nblk, int c, int lane) {
+  const int g = c * (CHUNK / BLK) + (3 - (lane >> 4)) - 1;
+  return hstate[(row * nblk + min(max(g, 0), nblk - 1)) * NS + (lane & (NS - 1))];
+}
+// v[lane - k] inside each 16-lane row (k is a constant after unrolling: the switch folds); lanes without a source get `old`
+template <int K>
+__device__ __forceinline__ float row_shr_k(float old, float v) { return dpp<0x110 + K, 0xf>(old, v); }
+__device__ __forceinline__ float row_shr(float old, float v, int k) {
+  switch (k) {
+#define RS(K) case K: return row_shr_k<K>(old, v);
+    RS(1) RS(2) RS(3) RS(4) RS(5) RS(6) RS(7) RS(8) RS(9) RS(10) RS(11) RS(12) RS(13) RS(14) RS(15)
+#undef RS
+  }
+  return v;  // k == 0
 }
 
 // In-kernel phase timing (diagnostic build only: -DSCAN_STAMP through tools/build_scan_variant.sh; tools/scan_stamps.py reads the
@@ -465,20 +495,26 @@ __device__ __forceinline__ float bwd_fetch_param(const float* __restrict__ Am, c
   {                                                                                                                   \
     float4 ob[4], oc[4];                                                                                              \
     _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                                \
-      ob[jj] = add ? *reinterpret_cast<const float4*>(&s_dB[4 * q + jj][lane * ITEMS]) : make_float4(0.f, 0.f, 0.f, 0.f); \
-      oc[jj] = add ? *reinterpret_cast<const float4*>(&s_dC[4 * q + jj][lane * ITEMS]) : make_float4(0.f, 0.f, 0.f, 0.f); \
+      ob[jj] = add ? *reinterpret_cast<const float4*>(&s_dB[4 * q + jj][tl * ITEMS]) : make_float4(0.f, 0.f, 0.f, 0.f); \
+      oc[jj] = add ? *reinterpret_cast<const float4*>(&s_dC[4 * q + jj][tl * ITEMS]) : make_float4(0.f, 0.f, 0.f, 0.f); \
     }                                                                                                                 \
     _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                                \
       ob[jj].x += accB[4 * q + jj][0]; ob[jj].y += accB[4 * q + jj][1]; ob[jj].z += accB[4 * q + jj][2]; ob[jj].w += accB[4 * q + jj][3]; \
       oc[jj].x += accC[4 * q + jj][0]; oc[jj].y += accC[4 * q + jj][1]; oc[jj].z += accC[4 * q + jj][2]; oc[jj].w += accC[4 * q + jj][3]; \
     }                                                                                                                 \
     _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                                \
-      *reinterpret_cast<float4*>(&s_dB[4 * q + jj][lane * ITEMS]) = ob[jj];                                           \
-      *reinterpret_cast<float4*>(&s_dC[4 * q + jj][lane * ITEMS]) = oc[jj];                                           \
+      *reinterpret_cast<float4*>(&s_dB[4 * q + jj][tl * ITEMS]) = ob[jj];                                           \
+      *reinterpret_cast<float4*>(&s_dC[4 * q + jj][tl * ITEMS]) = oc[jj];                                           \
     }                                                                                                                 \
   }
 
 // Backward: BWD_WAVES waves x BWD_RPW rows each = BWD_ROWS rows of one (b, k) group per workgroup.
+// TIME RUNS AGAINST THE LANES here (lane l holds steps 4 (63 - l) .. of the chunk): the scan that has to cross the whole wave - dL/dh,
+// which needs everything later in time - is then a PREFIX scan over the lanes, for which DPP has all six levels (row_shr 1..8,
+// row_bcast 15 / 31), and the recomputation of h only has to cover one 16-lane row, because the forward left a checkpoint every 64
+// steps: four row_shl levels, the checkpoint entering at the row's last lane.  (Until round 3 time ran with the lanes, h was a
+// six-level prefix scan from the chunk's entry state and dL/dh a suffix scan whose two cross-row levels have no DPP mode: 6
+// v_readlane, 4 scalar compositions and 6 selects per state, ~20 of the ~155 vector instructions per state and row-chunk.)
 // SETS: 16-value sets of d(Wdt) factors per row (0: materialised delta, no dt projection; 1: rank <= 16; 2: rank <= 32)
 // GD16: d(delta) is written as bf16 (dt-projection variant in bf16 mode: it is only the operand of gdtr = Wdt^T gdelta, whose result
 // the caller rounds to bf16 anyway; halves the 5.9 GB per step that this workspace is written and read)
@@ -490,6 +526,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
     float* __restrict__ wsB, float* __restrict__ wsC, int K, int Dk, int L,
     int nchunk, size_t slab_elems, int xmode, const float* __restrict__ dtr, const float* __restrict__ Wdt, int R) {
   constexpr bool DTR = SETS > 0;
+  const int nblk = (L + BLK - 1) / BLK;  // hstate is [rows][nblk][NS]: the state after every 64-step block
   // one dynamic LDS array: B tile | C tile (the dB/dC fold tile aliases them) | rank-R dt factors | Wdt rows | per-row sums | carry
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float(*sB)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(smem);
@@ -544,14 +581,16 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
     // vmcnt with the prefetches)
     lane = lane0;
     asm volatile("" : "+v"(lane));
-    int t = c * CHUNK + lane * ITEMS;
+    int tl = WAVE - 1 - lane;  // this lane's place in time: steps 4 tl .. 4 tl + 3 of the chunk
+    int t = c * CHUNK + tl * ITEMS;
     // first row's streams: requested before the staging, consumed after it (row index clamped: always issued, never under a branch)
     Raw4 n_uu, n_g, n_dl;
-    float n_par;
+    float n_par, n_ck;
     {
       const int dd = min(d0, dlast);
       bwd_fetch_row<VEC>(u, gy, b, K, k, Dk, dd, L, t, rev, xmode, n_uu, n_g);
-      n_par = bwd_fetch_param(Am, Dv, dbias, hstate, k * Dk + dd, ((size_t)b * K + k) * Dk + dd, nchunk, c, lane);
+      n_par = bwd_fetch_param(Am, Dv, dbias, k * Dk + dd, lane);
+      n_ck = bwd_fetch_ck(hstate, ((size_t)b * K + k) * Dk + dd, nblk, c, lane);
       n_dl = n_uu;
       if (!DTR) n_dl = load4_issue<VEC>(delta + (((size_t)b * K + k) * Dk + dd) * L, t, L, rev);
     }
@@ -570,10 +609,13 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
       const size_t row = ((size_t)b * K + k) * Dk + d;
       lane = lane0;
       asm volatile("" : "+v"(lane));
-      t = c * CHUNK + lane * ITEMS;
-      const int rowi = lane >> 4;
+      tl = WAVE - 1 - lane;
+      t = c * CHUNK + tl * ITEMS;
       float uu[ITEMS], g[ITEMS], dt[ITEMS], dtu[ITEMS], S[ITEMS], ddtA[ITEMS];
       const float par = n_par;
+      // states entering this lane's 64-step block, lane (r, j): state j (zero for the first block of the sequence)
+      const float ck = (c > 0 || lane < 48) ? n_ck : 0.f;
+      const float m15 = (lane & 15) == 15 ? 1.f : 0.f;  // the lane of each row that comes first in time
       {
         float dl[ITEMS];
         load4_take<VEC>(n_uu, uu, rev);
@@ -584,10 +626,11 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
         {  // next row's streams, in flight behind this row's arithmetic
           const int dn = min(d + 1, dlast);
           bwd_fetch_row<VEC>(u, gy, b, K, k, Dk, dn, L, t, rev, xmode, n_uu, n_g);
-          n_par = bwd_fetch_param(Am, Dv, dbias, hstate, k * Dk + dn, ((size_t)b * K + k) * Dk + dn, nchunk, c, lane);
+          n_par = bwd_fetch_param(Am, Dv, dbias, k * Dk + dn, lane);
+          n_ck = bwd_fetch_ck(hstate, ((size_t)b * K + k) * Dk + dn, nblk, c, lane);
           if (!DTR) n_dl = load4_issue<VEC>(delta + (((size_t)b * K + k) * Dk + dn) * L, t, L, rev);
         }
-        if (DTR) dtproj_row(s_W + wr * RMAX, s_dtr, R, lane, dl);
+        if (DTR) dtproj_row(s_W + wr * RMAX, s_dtr, R, tl, dl);
         const float bias = rdlane(par, 17);
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
@@ -599,7 +642,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
       const float par2 = par * LOG2E;  // lanes < 16: A * log2(e), the exponent scale of exp2; d(dt) below is summed in that scale
       STAMP(2)  // 2: row prologue: next row's requests, dt projection, softplus
       float dAv[8];  // dA_n + dA_{n+8} after the first reduction step (pair_sum32)
-      float4 nb4 = *reinterpret_cast<const float4*>(&sB[0][lane * ITEMS]), nc4 = *reinterpret_cast<const float4*>(&sC[0][lane * ITEMS]);
+      float4 nb4 = *reinterpret_cast<const float4*>(&sB[0][tl * ITEMS]), nc4 = *reinterpret_cast<const float4*>(&sC[0][tl * ITEMS]);
       // a_t * dL/dh_t entering from the next chunk, lane n holds state n's; the new one is assembled lane by lane (v_writelane)
       const float cry = s_carry[wr * NS + (lane & (NS - 1))];
       float ncry = 0.f;
@@ -607,12 +650,12 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
       for (int n = 0; n < NS; ++n) {
         const float4 b4 = nb4, c4 = nc4;  // requested one state ahead: at two waves per SIMD the LDS latency is not covered otherwise
         if (n + 1 < NS) {
-          nb4 = *reinterpret_cast<const float4*>(&sB[n + 1][lane * ITEMS]);
-          nc4 = *reinterpret_cast<const float4*>(&sC[n + 1][lane * ITEMS]);
+          nb4 = *reinterpret_cast<const float4*>(&sB[n + 1][tl * ITEMS]);
+          nc4 = *reinterpret_cast<const float4*>(&sC[n + 1][tl * ITEMS]);
         }
         const float bb[ITEMS] = {b4.x, b4.y, b4.z, b4.w}, cc[ITEMS] = {c4.x, c4.y, c4.z, c4.w};
         float a[ITEMS], hh[ITEMS], bu[ITEMS], cg[ITEMS];
-        const float A2 = rdlane(par2, n), h0 = c > 0 ? rdlane(par, 32 + n) : 0.f;  // A2 = A[kd][n] * log2(e); chunk 0 starts from h = 0
+        const float A2 = rdlane(par2, n);  // A[kd][n] * log2(e)
         // ---- h inside the chunk (same arithmetic as the forward) and the in-lane part of the dL/dh recurrence
         //      gh_i = cc_i g_i + a_{i+1} gh_{i+1}
 #pragma unroll
@@ -624,27 +667,22 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
         float A = a[0], Bv = bu[0];
 #pragma unroll
         for (int i = 1; i < ITEMS; ++i) { Bv = fmaf(a[i], Bv, bu[i]); A *= a[i]; }
-        // a of the next lane's first step; the chunk's last step takes `carry` (= a * gh of the next chunk) with factor 1
-        const float alast = next_lane(1.f, a[0]);
+        // the block's entry state joins at the lane that comes first in time (lane 15 of the row): from there on Bv is the state itself
+        const float h0 = row_shr(0.f, ck, 15 - n);  // lane 15 of each row: state n of the row's checkpoint (elsewhere: finite, times 0)
+        Bv = fmaf(A * m15, h0, Bv);
+        // a of the first step of the lane that follows in time (lane - 1); the chunk's last step (lane 0) takes `carry` (= a * gh of
+        // the next chunk) with factor 1
+        const float alast = prev_lane(1.f, a[0]);
         float SA = alast, SB = cg[ITEMS - 1];
 #pragma unroll
         for (int i = ITEMS - 2; i >= 0; --i) { SB = fmaf(a[i + 1], SB, cg[i]); SA *= a[i + 1]; }
-        prefix_and_row_suffix_scan(A, Bv, SA, SB);
-        {  // cross-row levels of the suffix scan: the three row totals (lanes 16, 32, 48) as scalars, composed and selected by row
-          const float a1 = rdlane(SA, 16), b1 = rdlane(SB, 16), a2 = rdlane(SA, 32), b2 = rdlane(SB, 32), a3 = rdlane(SA, 48), b3 = rdlane(SB, 48);
-          const float a23 = a2 * a3, b23 = fmaf(a2, b3, b2);
-          const float a123 = a1 * a23, b123 = fmaf(a1, b23, b1);
-          const float pa = rowi == 0 ? a123 : rowi == 1 ? a23 : rowi == 2 ? a3 : 1.f;
-          const float pb = rowi == 0 ? b123 : rowi == 1 ? b23 : rowi == 2 ? b3 : 0.f;
-          SB = fmaf(SA, pb, SB);
-          SA *= pa;
-        }
-        const float EA = prev_lane(1.f, A), EB = prev_lane(0.f, Bv);
-        const float hin = fmaf(EA, h0, EB);  // h_{t-1} of this lane's first step
+        // dL/dh: inclusive prefix scan over the whole wave (lanes 0 .. l = everything later in time); h: the four levels inside the row
+        prefix_and_row_suffix_scan(SA, SB, A, Bv);
+        const float hin = dpp<0x101, 0xf>(h0, Bv);  // h_{t-1} of this lane's first step: the state after lane + 1 (row_shl:1), the checkpoint at lane 15
         hh[0] = fmaf(a[0], hin, bu[0]);
 #pragma unroll
         for (int i = 1; i < ITEMS; ++i) hh[i] = fmaf(a[i], hh[i - 1], bu[i]);
-        const float XA = next_lane(1.f, SA), XB = next_lane(0.f, SB);
+        const float XA = prev_lane(1.f, SA), XB = prev_lane(0.f, SB);
         float gh = fmaf(XA, rdlane(cry, n), XB);  // gh of the step right after this lane's last one (already times its a)
         float dA_n = 0.f;
 #pragma unroll
@@ -657,8 +695,8 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
           accB[n][i] = fmaf(gh, dtu[i], accB[n][i]);
           accC[n][i] = fmaf(g[i], hh[i], accC[n][i]);
         }
-        // a_t * gh_t of this chunk's first step (lane 0), for the previous chunk
-        write_lane(ncry, rdlane(a[0] * gh, 0), n);
+        // a_t * gh_t of this chunk's first step (lane 63), for the previous chunk
+        write_lane(ncry, rdlane(a[0] * gh, WAVE - 1), n);
         if (n < 8) dAv[n] = dA_n; else dAv[n - 8] = pair_sum32(dAv[n - 8], dA_n);
         // the state's updates happen HERE (the asm makes the accumulators opaque at this point), and nothing crosses the fence
         asm volatile("" : "+v"(accB[n][0]), "+v"(accB[n][1]), "+v"(accB[n][2]), "+v"(accB[n][3]), "+v"(accC[n][0]), "+v"(accC[n][1]),
@@ -690,7 +728,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
       const int slot = (lane >> 2) & 15;
       const bool writer = (lane & 3) == 0;
       auto fac = [&](int q) -> float {  // (branch-free: a factor index past the rank reads row 0 and is replaced by zero)
-        const float4 f = *reinterpret_cast<const float4*>(&s_dtr[q < R ? q : 0][lane * ITEMS]);
+        const float4 f = *reinterpret_cast<const float4*>(&s_dtr[q < R ? q : 0][tl * ITEMS]);
         const float v = fmaf(gd[0], f.x, fmaf(gd[1], f.y, fmaf(gd[2], f.z, gd[3] * f.w)));
         return q < R ? v : 0.f;
       };
@@ -737,6 +775,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
     float(*s_dC)[CHUNK] = sC;
     lane = lane0;
     asm volatile("" : "+v"(lane));
+    tl = WAVE - 1 - lane;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < BWD_WAVES; ++j) {
@@ -893,7 +932,7 @@ __global__ __launch_bounds__(256) void dtproj_gdtr_kernel(const float* __restric
 
 }  // namespace
 
-extern "C" int tamtr_selective_scan_chunk(void) { return CHUNK; }
+extern "C" int tamtr_selective_scan_chunk(void) { return BLK; }  // the checkpoint interval: hstate is [B, KD, ceil(L / this), N]
 extern "C" int tamtr_selective_scan_bwd_slabs(int Dk) { return Dk > 0 ? (Dk + BWD_ROWS - 1) / BWD_ROWS : 0; }
 
 static int scan_fwd_launch(const float* u, const float* delta, const float* dtr, const float* Wdt, int R, const float* A,

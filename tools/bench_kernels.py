@@ -68,6 +68,11 @@ def bench_gemm():
           f'{2 * M * N * K / ka / 1e9:.0f} TFLOP/s, {(M * K + M * N) * 2 / ka / 1e6:.0f} GB/s algorithmic')
     a, mn = timeit(lambda: torch.nn.functional.linear(x, w16, b.bfloat16()), n=10)
     print(f'torch/hipBLASLt same shape: {a * 1e3:.0f} us avg, {2 * M * N * K / a / 1e9:.0f} TFLOP/s')
+    # what the same bytes cost as a pure stream (X read once, Y written once - the GEMM's algorithmic traffic): a device copy of X
+    y = torch.empty_like(x)
+    a, mn = timeit(lambda: y.copy_(x), n=20, warm=3)
+    print(f'copy of X into a buffer of its size (the same 1.10 GB: {M * K * 2 / 1e6:.0f} MB read + {M * N * 2 / 1e6:.0f} MB written): '
+          f'{a * 1e3:.0f} us avg / {mn * 1e3:.0f} min = {(M * K + M * N) * 2 / a / 1e6:.0f} GB/s')
 
 
 def bench_gate():
