@@ -122,6 +122,10 @@ __device__ __forceinline__ float dpp(float old, float src) {
 }
 // value of the previous lane (lane 0 keeps `old`): wave_shr:1
 __device__ __forceinline__ float prev_lane(float old, float v) { return dpp<0x138, 0xf>(old, v); }
+// value of the previous lane, zero in lane 0 (bound_ctrl: no register has to be preset for the lane without a source)
+__device__ __forceinline__ float prev_lane0(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
 // value of the next lane (lane 63 keeps `old`): wave_shl:1
 __device__ __forceinline__ float next_lane(float old, float v) { return dpp<0x130, 0xf>(old, v); }
 __device__ __forceinline__ float rdlane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
@@ -160,6 +164,18 @@ __device__ __forceinline__ void prefix_scan_x2(float& A0, float& B0, float& A1, 
                "s_nop 1"
                : "+v"(A0), "+v"(B0), "+v"(A1), "+v"(B1));
 }
+// the same when only the B parts are used afterwards (the entry state has been folded in at lane 0): the last level leaves A alone
+#define LVLB(b, a, c) "v_fmac_f32_dpp %" #b ", %" #b ", %" #a " " c "\n\t"
+__device__ __forceinline__ void prefix_scan_x2_b(float& A0, float& B0, float& A1, float& B1) {
+  asm volatile("s_nop 1\n\t"
+               LVL(1, 0, "row_shr:1 " FULL) LVL(3, 2, "row_shr:1 " FULL) LVL(1, 0, "row_shr:2 " FULL) LVL(3, 2, "row_shr:2 " FULL)
+               LVL(1, 0, "row_shr:4 " FULL) LVL(3, 2, "row_shr:4 " FULL) LVL(1, 0, "row_shr:8 " FULL) LVL(3, 2, "row_shr:8 " FULL)
+               LVL(1, 0, "row_bcast:15 row_mask:0xa bank_mask:0xf") LVL(3, 2, "row_bcast:15 row_mask:0xa bank_mask:0xf")
+               LVLB(1, 0, "row_bcast:31 row_mask:0xc bank_mask:0xf") LVLB(3, 2, "row_bcast:31 row_mask:0xc bank_mask:0xf")
+               "s_nop 1"
+               : "+v"(A0), "+v"(B0), "+v"(A1), "+v"(B1));
+}
+#undef LVLB
 // (pA, pB): inclusive PREFIX scan over the wave; (sA, sB): the four in-row levels (row_shl 1,2,4,8) of the inclusive SUFFIX scan
 // (later map applied first) - its two cross-row levels have no DPP mode and are done by the caller
 __device__ __forceinline__ void prefix_and_row_suffix_scan(float& pA, float& pB, float& sA, float& sB) {
@@ -170,6 +186,19 @@ __device__ __forceinline__ void prefix_and_row_suffix_scan(float& pA, float& pB,
                LVL(1, 0, "row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
                : "+v"(pA), "+v"(pB), "+v"(sA), "+v"(sB));
 }
+// the backward's pair: (pA, pB) inclusive PREFIX scan over the wave, (sA, sB) the four in-row SUFFIX levels - and only the B parts are
+// used afterwards (both chains have had their entry value folded in at their first lane), so the last level of each chain leaves its
+// A part alone
+#define LVLB(b, a, c) "v_fmac_f32_dpp %" #b ", %" #b ", %" #a " " c "\n\t"
+__device__ __forceinline__ void prefix_and_row_suffix_scan_b(float& pA, float& pB, float& sA, float& sB) {
+  asm volatile("s_nop 1\n\t"
+               LVL(1, 0, "row_shr:1 " FULL) LVL(3, 2, "row_shl:1 " FULL) LVL(1, 0, "row_shr:2 " FULL) LVL(3, 2, "row_shl:2 " FULL)
+               LVL(1, 0, "row_shr:4 " FULL) LVL(3, 2, "row_shl:4 " FULL) LVL(1, 0, "row_shr:8 " FULL) LVLB(3, 2, "row_shl:8 " FULL)
+               LVL(1, 0, "row_bcast:15 row_mask:0xa bank_mask:0xf") "s_nop 0\n\t"
+               LVLB(1, 0, "row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
+               : "+v"(pA), "+v"(pB), "+v"(sA), "+v"(sB));
+}
+#undef LVLB
 #undef LVL
 #undef FULL
 
@@ -366,6 +395,7 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
       // delta_t = <Wdt[kd, :], dtr[:, t]>: the [B, 4*d_inner, L] delta tensor of the reference is never materialised
       if (DTR) dtproj_row(s_W + wr * RMAX, s_dtr, R, lane, dt);
       const float Dd = rdlane(par, 16), bias = rdlane(par, 17);
+      const float m0 = lane == 0 ? 1.f : 0.f;
       // checkpoints for the backward: the state after every 64-step block = what the last lane of each 16-lane row holds after its
       // four steps; those four lanes store it themselves, state by state (byte offset of state 0; every other lane, and a block that
       // starts beyond L, is dropped by the buffer's range check)
@@ -380,7 +410,7 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
       }
 #pragma unroll
       for (int n = 0; n < NS; n += 2) {
-        float a[2][ITEMS], bb[2][ITEMS], cc[2][ITEMS], A[2], Bv[2], hend[2];
+        float a[2][ITEMS], bb[2][ITEMS], cc[2][ITEMS], A[2], Bv[2], hend[2], hin[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float4 b4 = *reinterpret_cast<const float4*>(&sB[n + j][lane * ITEMS]);
@@ -397,12 +427,13 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
           Bv[j] = bb[j][0];
 #pragma unroll
           for (int i = 1; i < ITEMS; ++i) { Bv[j] = fmaf(a[j][i], Bv[j], bb[j][i]); A[j] *= a[j][i]; }
+          hin[j] = rdlane(hc, n + j);               // state entering the chunk: joins at lane 0, from there on Bv is the state itself
+          Bv[j] = fmaf(A[j] * m0, hin[j], Bv[j]);
         }
-        prefix_scan_x2(A[0], Bv[0], A[1], Bv[1]);
+        prefix_scan_x2_b(A[0], Bv[0], A[1], Bv[1]);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const float EA = prev_lane(1.f, A[j]), EB = prev_lane(0.f, Bv[j]);
-          float hh = fmaf(EA, rdlane(hc, n + j), EB);  // state entering this lane's first step
+          float hh = fmaf(m0, hin[j], prev_lane0(Bv[j]));  // state entering this lane's first step (lane 0: the chunk's)
 #pragma unroll
           for (int i = 0; i < ITEMS; ++i) {
             hh = fmaf(a[j][i], hh, bb[j][i]);
@@ -616,6 +647,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
       // states entering this lane's 64-step block, lane (r, j): state j (zero for the first block of the sequence)
       const float ck = (c > 0 || lane < 48) ? n_ck : 0.f;
       const float m15 = (lane & 15) == 15 ? 1.f : 0.f;  // the lane of each row that comes first in time
+      const float m0 = lane == 0 ? 1.f : 0.f;           // the lane that comes last in time: where the next chunk's carry enters
       {
         float dl[ITEMS];
         load4_take<VEC>(n_uu, uu, rev);
@@ -664,26 +696,28 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
           bu[i] = dtu[i] * bb[i];
           cg[i] = cc[i] * g[i];
         }
-        float A = a[0], Bv = bu[0];
+        const float P = a[1] * a[2] * a[3];  // shared by the two maps of the lane: h -> A h + Bv (A = a0 P) and gh -> SA gh + SB (SA = alast P)
+        float A = a[0] * P, Bv = bu[0];
 #pragma unroll
-        for (int i = 1; i < ITEMS; ++i) { Bv = fmaf(a[i], Bv, bu[i]); A *= a[i]; }
+        for (int i = 1; i < ITEMS; ++i) Bv = fmaf(a[i], Bv, bu[i]);
         // the block's entry state joins at the lane that comes first in time (lane 15 of the row): from there on Bv is the state itself
         const float h0 = row_shr(0.f, ck, 15 - n);  // lane 15 of each row: state n of the row's checkpoint (elsewhere: finite, times 0)
         Bv = fmaf(A * m15, h0, Bv);
-        // a of the first step of the lane that follows in time (lane - 1); the chunk's last step (lane 0) takes `carry` (= a * gh of
-        // the next chunk) with factor 1
-        const float alast = prev_lane(1.f, a[0]);
-        float SA = alast, SB = cg[ITEMS - 1];
+        // the next chunk's carry (= a * gh of its first step) joins at the lane that comes last in time (lane 0), as part of that
+        // lane's last step; nothing else enters there, so its `alast` - a of the first step of the lane that follows in time
+        // (lane - 1) - may be the zero that a lane without a DPP source gets for free
+        cg[ITEMS - 1] = fmaf(m0, rdlane(cry, n), cg[ITEMS - 1]);
+        const float alast = prev_lane0(a[0]);
+        float SA = alast * P, SB = cg[ITEMS - 1];
 #pragma unroll
-        for (int i = ITEMS - 2; i >= 0; --i) { SB = fmaf(a[i + 1], SB, cg[i]); SA *= a[i + 1]; }
+        for (int i = ITEMS - 2; i >= 0; --i) SB = fmaf(a[i + 1], SB, cg[i]);
         // dL/dh: inclusive prefix scan over the whole wave (lanes 0 .. l = everything later in time); h: the four levels inside the row
-        prefix_and_row_suffix_scan(SA, SB, A, Bv);
+        prefix_and_row_suffix_scan_b(SA, SB, A, Bv);
         const float hin = dpp<0x101, 0xf>(h0, Bv);  // h_{t-1} of this lane's first step: the state after lane + 1 (row_shl:1), the checkpoint at lane 15
         hh[0] = fmaf(a[0], hin, bu[0]);
 #pragma unroll
         for (int i = 1; i < ITEMS; ++i) hh[i] = fmaf(a[i], hh[i - 1], bu[i]);
-        const float XA = prev_lane(1.f, SA), XB = prev_lane(0.f, SB);
-        float gh = fmaf(XA, rdlane(cry, n), XB);  // gh of the step right after this lane's last one (already times its a)
+        float gh = prev_lane0(SB);  // gh of the step right after this lane's last one (lane 0: nothing, its alast is 0)
         float dA_n = 0.f;
 #pragma unroll
         for (int i = ITEMS - 1; i >= 0; --i) {
