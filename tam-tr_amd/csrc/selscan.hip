@@ -31,7 +31,20 @@ namespace {
 constexpr int NS = 16;         // d_state
 constexpr int ITEMS = 4;       // time steps per lane
 constexpr int CHUNK = WAVE * ITEMS;
-constexpr int BLK = 16 * ITEMS;   // steps per 16-lane DPP row: the forward leaves a state checkpoint after every block (4 per chunk)
+// Checkpoints the forward leaves for the backward.  SCAN_CKPT = 64 (default): the state after every 16-lane DPP row (64 steps),
+// [row][block][16], 1 byte per step and row; the backward rebuilds the lanes' entry states from there with a four-level in-row scan.
+// SCAN_CKPT = 4 (A/B build, tools/build_scan_variant.sh ck4 -DSCAN_CKPT=4): the state after EVERY lane's four steps, 16 L bytes per row
+// (4 x the row's u), stored [row][state pair][lane-block][2] so that a wave's store / load of one pair is one contiguous 512-byte run;
+// the backward then READS the state entering each lane instead of recomputing it.  Measured (profiles/r03_scan_checkpoints.txt): 13 % fewer
+// vector instructions in the backward (27.2 against 31.1 lane-operations per step and state) but only 2 % less time, and the forward pays
+// 13 % for the 6.7 GB of stores at level 0 - bytes were not the cheap side of the trade after all; not the default.
+#ifndef SCAN_CKPT
+#define SCAN_CKPT 64
+#endif
+constexpr bool CKL = SCAN_CKPT == ITEMS;
+constexpr int BLK = CKL ? ITEMS : 16 * ITEMS;   // checkpoint interval in steps
+static_assert(SCAN_CKPT == ITEMS || SCAN_CKPT == 16 * ITEMS, "checkpoint per lane or per DPP row");
+struct Raw2 { float v[2]; };
 constexpr int FWD_ROWS = 8;    // waves (= rows of one (b,k) group) per workgroup, forward
 constexpr int FWD_RPW = 4;     // rows per wave and chunk, forward (they share the staged tiles)
 constexpr int BWD_WAVES = 4;   // waves per workgroup, backward
@@ -197,6 +210,15 @@ __device__ __forceinline__ void prefix_and_row_suffix_scan_b(float& pA, float& p
                LVL(1, 0, "row_bcast:15 row_mask:0xa bank_mask:0xf") "s_nop 0\n\t"
                LVLB(1, 0, "row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
                : "+v"(pA), "+v"(pB), "+v"(sA), "+v"(sB));
+}
+// one chain: inclusive PREFIX scan over the wave, B part only after the last level (one s_nop per level covers the VALU-write ->
+// DPP-read distance that the second chain's instructions used to fill)
+__device__ __forceinline__ void prefix_scan_b(float& A, float& B) {
+  asm volatile("s_nop 1\n\t"
+               LVL(1, 0, "row_shr:1 " FULL) "s_nop 0\n\t" LVL(1, 0, "row_shr:2 " FULL) "s_nop 0\n\t" LVL(1, 0, "row_shr:4 " FULL) "s_nop 0\n\t"
+               LVL(1, 0, "row_shr:8 " FULL) "s_nop 0\n\t" LVL(1, 0, "row_bcast:15 row_mask:0xa bank_mask:0xf") "s_nop 0\n\t"
+               LVLB(1, 0, "row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
+               : "+v"(A), "+v"(B));
 }
 #undef LVLB
 #undef LVL
@@ -396,12 +418,13 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
       if (DTR) dtproj_row(s_W + wr * RMAX, s_dtr, R, lane, dt);
       const float Dd = rdlane(par, 16), bias = rdlane(par, 17);
       const float m0 = lane == 0 ? 1.f : 0.f;
-      // checkpoints for the backward: the state after every 64-step block = what the last lane of each 16-lane row holds after its
-      // four steps; those four lanes store it themselves, state by state (byte offset of state 0; every other lane, and a block that
-      // starts beyond L, is dropped by the buffer's range check)
+      // checkpoints for the backward (SCAN_CKPT above): what a lane holds after its four steps, stored by the lane itself, a state pair
+      // at a time - every lane, or the last lane of each 16-lane row (a lane / block that starts beyond L, and in the second form every
+      // other lane, is dropped by the buffer's range check)
       const __amdgpu_buffer_rsrc_t hs_rs = row_rsrc(hstate + row * (size_t)nblk * NS, nblk * NS);
-      const int blk = c * (CHUNK / BLK) + (lane >> 4);
-      const unsigned hs_off = ((lane & 15) == 15 && blk < nblk) ? (unsigned)blk * NS * 4 : OOB;
+      const int blk = CKL ? c * WAVE + lane : c * (CHUNK / BLK) + (lane >> 4);
+      const unsigned hs_off = CKL ? (blk < nblk ? (unsigned)blk * 8 : OOB)
+                                  : (((lane & 15) == 15 && blk < nblk) ? (unsigned)blk * NS * 4 : OOB);
 #pragma unroll
       for (int i = 0; i < ITEMS; ++i) {
         dt[i] = softplus_f((t + i < L) ? dt[i] + bias : -1e30f);  // steps beyond L become the identity map (dt = 0: a = 1, b = 0)
@@ -445,7 +468,7 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
         {  // the pair's two checkpoint values are neighbours in memory: one 8-byte store
           typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
           const u32x2 w = {__builtin_bit_cast(unsigned, hend[0]), __builtin_bit_cast(unsigned, hend[1])};
-          __builtin_amdgcn_raw_buffer_store_b64(w, hs_rs, hs_off, n * 4, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(w, hs_rs, hs_off, CKL ? (n / 2) * nblk * 8 : n * 4, 0);
         }
         asm volatile("" : "+v"(yy[0]), "+v"(yy[1]), "+v"(yy[2]), "+v"(yy[3]), "+v"(nh));
         __builtin_amdgcn_sched_barrier(0);  // one pair's temporaries at a time
@@ -497,6 +520,16 @@ __device__ __forceinline__ float bwd_fetch_param(const float* __restrict__ Am, c
 __device__ __forceinline__ float bwd_fetch_ck(const float* __restrict__ hstate, size_t row, int nblk, int c, int lane) {
   const int g = c * (CHUNK / BLK) + (3 - (lane >> 4)) - 1;
   return hstate[(row * nblk + min(max(g, 0), nblk - 1)) * NS + (lane & (NS - 1))];
+}
+// SCAN_CKPT = 4: state pair p entering lane-block gb (= the forward's checkpoint after lane-block gb - 1; gb = 0 starts from zero, which
+// is what the range check returns for the dropped access): issue only, the pair is consumed a whole row later
+__device__ __forceinline__ Raw2 bwd_issue_ck(const float* __restrict__ hstate, size_t row, int nlb, int gb, int p) {
+  const __amdgpu_buffer_rsrc_t rs = row_rsrc(hstate + row * (size_t)nlb * NS, nlb * NS);
+  const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, (gb >= 1 && gb <= nlb) ? (unsigned)(gb - 1) * 8 : OOB, p * nlb * 8, 0);
+  static_assert(sizeof(v) == sizeof(Raw2), "64-bit buffer load");
+  Raw2 r;
+  __builtin_memcpy(r.v, &v, sizeof(r.v));
+  return r;
 }
 // v[lane - k] inside each 16-lane row (k is a constant after unrolling: the switch folds); lanes without a source get `old`
 template <int K>
@@ -616,12 +649,17 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
     int t = c * CHUNK + tl * ITEMS;
     // first row's streams: requested before the staging, consumed after it (row index clamped: always issued, never under a branch)
     Raw4 n_uu, n_g, n_dl;
-    float n_par, n_ck;
+    float n_par, n_ck = 0.f;
+    Raw2 hck[NS / 2];  // SCAN_CKPT = 4: the 16 states entering this lane's four steps, for the row about to be worked on (see below)
     {
       const int dd = min(d0, dlast);
       bwd_fetch_row<VEC>(u, gy, b, K, k, Dk, dd, L, t, rev, xmode, n_uu, n_g);
       n_par = bwd_fetch_param(Am, Dv, dbias, k * Dk + dd, lane);
-      n_ck = bwd_fetch_ck(hstate, ((size_t)b * K + k) * Dk + dd, nblk, c, lane);
+      if (!CKL) n_ck = bwd_fetch_ck(hstate, ((size_t)b * K + k) * Dk + dd, nblk, c, lane);
+      if (CKL) {
+#pragma unroll
+        for (int p = 0; p < NS / 2; ++p) hck[p] = bwd_issue_ck(hstate, ((size_t)b * K + k) * Dk + dd, nblk, c * WAVE + tl, p);
+      }
       n_dl = n_uu;
       if (!DTR) n_dl = load4_issue<VEC>(delta + (((size_t)b * K + k) * Dk + dd) * L, t, L, rev);
     }
@@ -645,8 +683,10 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
       float uu[ITEMS], g[ITEMS], dt[ITEMS], dtu[ITEMS], S[ITEMS], ddtA[ITEMS];
       const float par = n_par;
       // states entering this lane's 64-step block, lane (r, j): state j (zero for the first block of the sequence)
-      const float ck = (c > 0 || lane < 48) ? n_ck : 0.f;
+      const float ck = (c > 0 || lane < 48) ? n_ck : 0.f;   // (SCAN_CKPT = 64 only)
       const float m15 = (lane & 15) == 15 ? 1.f : 0.f;  // the lane of each row that comes first in time
+      const size_t nrow_ck = ((size_t)b * K + k) * Dk + min(d + 1, dlast);  // SCAN_CKPT = 4: the row whose checkpoints are requested during this one
+      Raw2 hnx[2] = {{{0.f, 0.f}}, {{0.f, 0.f}}};
       const float m0 = lane == 0 ? 1.f : 0.f;           // the lane that comes last in time: where the next chunk's carry enters
       {
         float dl[ITEMS];
@@ -659,7 +699,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
           const int dn = min(d + 1, dlast);
           bwd_fetch_row<VEC>(u, gy, b, K, k, Dk, dn, L, t, rev, xmode, n_uu, n_g);
           n_par = bwd_fetch_param(Am, Dv, dbias, k * Dk + dn, lane);
-          n_ck = bwd_fetch_ck(hstate, ((size_t)b * K + k) * Dk + dn, nblk, c, lane);
+          if (!CKL) n_ck = bwd_fetch_ck(hstate, ((size_t)b * K + k) * Dk + dn, nblk, c, lane);
           if (!DTR) n_dl = load4_issue<VEC>(delta + (((size_t)b * K + k) * Dk + dn) * L, t, L, rev);
         }
         if (DTR) dtproj_row(s_W + wr * RMAX, s_dtr, R, tl, dl);
@@ -696,24 +736,39 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
           bu[i] = dtu[i] * bb[i];
           cg[i] = cc[i] * g[i];
         }
-        const float P = a[1] * a[2] * a[3];  // shared by the two maps of the lane: h -> A h + Bv (A = a0 P) and gh -> SA gh + SB (SA = alast P)
-        float A = a[0] * P, Bv = bu[0];
-#pragma unroll
-        for (int i = 1; i < ITEMS; ++i) Bv = fmaf(a[i], Bv, bu[i]);
-        // the block's entry state joins at the lane that comes first in time (lane 15 of the row): from there on Bv is the state itself
-        const float h0 = row_shr(0.f, ck, 15 - n);  // lane 15 of each row: state n of the row's checkpoint (elsewhere: finite, times 0)
-        Bv = fmaf(A * m15, h0, Bv);
+        const float P = a[1] * a[2] * a[3];
         // the next chunk's carry (= a * gh of its first step) joins at the lane that comes last in time (lane 0), as part of that
         // lane's last step; nothing else enters there, so its `alast` - a of the first step of the lane that follows in time
         // (lane - 1) - may be the zero that a lane without a DPP source gets for free
         cg[ITEMS - 1] = fmaf(m0, rdlane(cry, n), cg[ITEMS - 1]);
         const float alast = prev_lane0(a[0]);
-        float SA = alast * P, SB = cg[ITEMS - 1];
+        float SA = alast * P, SB = cg[ITEMS - 1];  // the lane's map gh -> SA gh + SB
 #pragma unroll
         for (int i = ITEMS - 2; i >= 0; --i) SB = fmaf(a[i + 1], SB, cg[i]);
-        // dL/dh: inclusive prefix scan over the whole wave (lanes 0 .. l = everything later in time); h: the four levels inside the row
-        prefix_and_row_suffix_scan_b(SA, SB, A, Bv);
-        const float hin = dpp<0x101, 0xf>(h0, Bv);  // h_{t-1} of this lane's first step: the state after lane + 1 (row_shl:1), the checkpoint at lane 15
+        float hin_;
+        if (CKL) {
+          // h_{t-1} of this lane's first step: read, not recomputed.  dL/dh: inclusive prefix scan over the whole wave (lanes 0 .. l =
+          // everything later in time)
+          hin_ = hck[n / 2].v[n & 1];
+          prefix_scan_b(SA, SB);
+          // this pair's registers are free: the NEXT row's pair goes into them and has the rest of this row to arrive.  The last two
+          // pairs would be requested at the very end of the row (and the row's first instructions wait for every load issued before
+          // them): theirs are requested early, into two spare pairs, and moved over when the row is done
+          if ((n & 1) && n / 2 < NS / 2 - 2) hck[n / 2] = bwd_issue_ck(hstate, nrow_ck, nblk, c * WAVE + tl, n / 2);
+          if (n == 1) hnx[0] = bwd_issue_ck(hstate, nrow_ck, nblk, c * WAVE + tl, NS / 2 - 2);
+          if (n == 3) hnx[1] = bwd_issue_ck(hstate, nrow_ck, nblk, c * WAVE + tl, NS / 2 - 1);
+        } else {
+          // h: the lane's map h -> A h + Bv (A = a0 P); the block's entry state joins at the lane that comes first in time (lane 15 of
+          // the row): from there on Bv is the state itself; four in-row levels, fused with the six of dL/dh
+          float A = a[0] * P, Bv = bu[0];
+#pragma unroll
+          for (int i = 1; i < ITEMS; ++i) Bv = fmaf(a[i], Bv, bu[i]);
+          const float h0 = row_shr(0.f, ck, 15 - n);  // lane 15 of each row: state n of the row's checkpoint (elsewhere: finite, times 0)
+          Bv = fmaf(A * m15, h0, Bv);
+          prefix_and_row_suffix_scan_b(SA, SB, A, Bv);
+          hin_ = dpp<0x101, 0xf>(h0, Bv);  // the state after lane + 1 (row_shl:1), the checkpoint at lane 15
+        }
+        const float hin = hin_;
         hh[0] = fmaf(a[0], hin, bu[0]);
 #pragma unroll
         for (int i = 1; i < ITEMS; ++i) hh[i] = fmaf(a[i], hh[i - 1], bu[i]);
@@ -739,6 +794,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
                           "+v"(dAv[n & 7]), "+v"(ncry));
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (CKL) { hck[NS / 2 - 2] = hnx[0]; hck[NS / 2 - 1] = hnx[1]; }
       STAMP(3)  // 3: the 16 states
       if (lane < NS) s_carry[wr * NS + lane] = ncry;
       // ---- after the states: du = D gy + dt S;  d(dt) = sum_n da_n A_n + u S;  d(delta) = d(dt) * sigmoid(delta + bias)
