@@ -10,7 +10,7 @@
  *   - `dtype`: element type of the activation tensors marked (T): TAMTR_F32 or TAMTR_BF16.  Index/offset/weight
  *     side inputs and all accumulation are always fp32;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Functions only enqueue work: no
- *     allocation, no synchronisation, no mutable globals (two A/B switches, TAMTR_GEMM and TAMTR_SELFATTN_SCALAR, are read from the
+ *     allocation, no synchronisation, no mutable globals (three A/B switches, TAMTR_GEMM, TAMTR_SELFATTN_SCALAR and TAMTR_SCAN_FWD4, are read from the
  *     environment ONCE, into constants; the LDS-size attribute of the kernels that need > 64 KB is set on every call, i.e. for whichever
  *     device is current) - they are safe to call from several host threads on different streams and devices and can be captured into a
  *     hipGraph;

@@ -26,6 +26,8 @@
 //     read per state with v_readlane, new carries are assembled with v_writelane: no LDS round trips, no branches.
 #include "common.h"
 
+constexpr int CHUNK_DEFAULT = 64 * 4;
+
 namespace {
 
 constexpr int NS = 16;         // d_state
@@ -268,8 +270,9 @@ __device__ __forceinline__ void reduce8x2(float (&x)[8], float (&y)[8]) {
 // ---- cooperative load of `rows` time-indexed rows ([rows][L] in global memory) of the chunk starting at step t0 into LDS
 // ([rows][CHUNK], step order, zero beyond L).  PER float4s per thread are requested together and only then written: the
 // loads' latency is paid once per call, not once per float4.
-template <int THREADS, int PER>
-__device__ __forceinline__ void stage_rows_vec(const float* __restrict__ P, int rows, int t0, int L, float (*s)[CHUNK], bool rev, int tid) {
+template <int THREADS, int PER, int CH = CHUNK>
+__device__ __forceinline__ void stage_rows_vec(const float* __restrict__ P, int rows, int t0, int L, float (*s)[CH], bool rev, int tid) {
+  constexpr int CHUNK = CH;  // (the chunk length of the caller: 256 steps, or 512 in the forward with 8 steps per lane)
   const int total = rows * (CHUNK / 4);
   for (int base = 0; base < total; base += THREADS * PER) {
     float4 v[PER];
@@ -298,19 +301,20 @@ __device__ __forceinline__ void stage_rows_scalar(const float* __restrict__ P, i
     s[r][tt] = ok ? v : 0.f;
   }
 }
-template <int THREADS, bool VEC>
+template <int THREADS, bool VEC, int CH = CHUNK>
 __device__ __forceinline__ void stage_tiles(const float* __restrict__ Bp, const float* __restrict__ Cp, const float* __restrict__ Rp,
-                                            int R, int t0, int L, float (*sB)[CHUNK], float (*sC)[CHUNK], float (*s_dtr)[CHUNK], bool rev) {
+                                            int R, int t0, int L, float (*sB)[CH], float (*sC)[CH], float (*s_dtr)[CH], bool rev) {
+  constexpr int CHUNK = CH;
   // the thread index through an opaque copy: everything derived from it (source offsets, LDS addresses) is recomputed per call
   // instead of being hoisted out of the chunk loop and held - or spilled - across the row loop
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
   if (VEC) {
     constexpr int PER = NS * (CHUNK / 4) / THREADS;  // 4 (256 threads) or 2 (512)
-    stage_rows_vec<THREADS, PER>(Bp, NS, t0, L, sB, rev, tid);
-    stage_rows_vec<THREADS, PER>(Cp, NS, t0, L, sC, rev, tid);
-    if (Rp) stage_rows_vec<THREADS, PER>(Rp, R, t0, L, s_dtr, rev, tid);
-  } else {
+    stage_rows_vec<THREADS, PER, CH>(Bp, NS, t0, L, sB, rev, tid);
+    stage_rows_vec<THREADS, PER, CH>(Cp, NS, t0, L, sC, rev, tid);
+    if (Rp) stage_rows_vec<THREADS, PER, CH>(Rp, R, t0, L, s_dtr, rev, tid);
+  } else if constexpr (CH == ::CHUNK_DEFAULT) {
     stage_rows_scalar<THREADS>(Bp, NS, t0, L, sB, rev, tid);
     stage_rows_scalar<THREADS>(Cp, NS, t0, L, sC, rev, tid);
     if (Rp) stage_rows_scalar<THREADS>(Rp, R, t0, L, s_dtr, rev, tid);
@@ -320,6 +324,33 @@ __device__ __forceinline__ void stage_tiles(const float* __restrict__ Bp, const 
 // acc[i] += sum_q W[q] * s_dtr[q][4*lane + i]: the factors are walked in blocks of 8 so that the 8 tile reads (and the two
 // broadcast reads of the weights) of a block are in flight together; a runtime-R loop of single reads paid one LDS round trip
 // per factor (~300 cycles each with every wave of the CU doing the same)
+// the same for a lane that holds 8 steps (the forward with 512-step chunks): two 16-byte reads per factor
+__device__ __forceinline__ void dtproj_row8(const float* __restrict__ Wrow, const float (*s_dtr)[2 * CHUNK], int R, int lane, float (&acc)[8]) {
+  int q = 0;
+  for (; q + 4 <= R; q += 4) {
+    const float4 w0 = *reinterpret_cast<const float4*>(Wrow + q);
+    const float w[4] = {w0.x, w0.y, w0.z, w0.w};
+    float4 f[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f[j][0] = *reinterpret_cast<const float4*>(&s_dtr[q + j][lane * 8]);
+      f[j][1] = *reinterpret_cast<const float4*>(&s_dtr[q + j][lane * 8 + 4]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[0] = fmaf(w[j], f[j][0].x, acc[0]); acc[1] = fmaf(w[j], f[j][0].y, acc[1]);
+      acc[2] = fmaf(w[j], f[j][0].z, acc[2]); acc[3] = fmaf(w[j], f[j][0].w, acc[3]);
+      acc[4] = fmaf(w[j], f[j][1].x, acc[4]); acc[5] = fmaf(w[j], f[j][1].y, acc[5]);
+      acc[6] = fmaf(w[j], f[j][1].z, acc[6]); acc[7] = fmaf(w[j], f[j][1].w, acc[7]);
+    }
+  }
+  for (; q < R; ++q) {
+    const float w = Wrow[q];
+    const float4 f0 = *reinterpret_cast<const float4*>(&s_dtr[q][lane * 8]), f1 = *reinterpret_cast<const float4*>(&s_dtr[q][lane * 8 + 4]);
+    acc[0] = fmaf(w, f0.x, acc[0]); acc[1] = fmaf(w, f0.y, acc[1]); acc[2] = fmaf(w, f0.z, acc[2]); acc[3] = fmaf(w, f0.w, acc[3]);
+    acc[4] = fmaf(w, f1.x, acc[4]); acc[5] = fmaf(w, f1.y, acc[5]); acc[6] = fmaf(w, f1.z, acc[6]); acc[7] = fmaf(w, f1.w, acc[7]);
+  }
+}
 __device__ __forceinline__ void dtproj_row(const float* __restrict__ Wrow, const float (*s_dtr)[CHUNK], int R, int lane, float (&acc)[ITEMS]) {
   int q = 0;
   for (; q + 8 <= R; q += 8) {
@@ -342,28 +373,35 @@ __device__ __forceinline__ void dtproj_row(const float* __restrict__ Wrow, const
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-// FWD_ROWS waves x FWD_RPW rows each = rows of ONE (b, k) group per workgroup.  Per row and chunk the 16 states are walked in
+// NW waves x FWD_RPW rows each = rows of ONE (b, k) group per workgroup.  Per row and chunk the 16 states are walked in
 // PAIRS: the two prefix scans of a pair are independent and interleave in one fused-DPP statement.  Row constants (A * log2 e,
 // D, bias) and the carried state h live in two LDS words per lane-slot that a row reads into one VGPR each at its start.
-template <bool VEC, bool DTR>  // DTR: fused dt projection (delta formed in-kernel from dtr and Wdt) vs a materialised delta
-__global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float* __restrict__ u, const float* __restrict__ delta,
-                                                                      const float* __restrict__ Am, const float* __restrict__ Bm,
-                                                                      const float* __restrict__ Cm, const float* __restrict__ Dv,
-                                                                      const float* __restrict__ dbias, float* __restrict__ y,
-                                                                      float* __restrict__ hstate, int K, int Dk, int L, int nchunk,
-                                                                      int xmode, const float* __restrict__ dtr,
-                                                                      const float* __restrict__ Wdt, int R) {
-  const int nblk = (L + BLK - 1) / BLK;  // checkpoints per row: hstate is [rows][nblk][NS]
+// IT = steps per lane.  The eleven DPP instructions of a state's scan cost a wave the same whether its lanes hold 4 or 8 steps, and they
+// are 40 % of the forward's issue time at 4: the product runs IT = 8 (512-step chunks, 64 KB of B/C tiles: one workgroup of NW = 16
+// waves per CU instead of three of 8 - the same four waves per SIMD).  IT = 4 / NW = 8 remains for sequence lengths that are not a
+// multiple of 4 and for the SCAN_CKPT = 4 build.
+template <bool VEC, bool DTR, int IT, int NW>  // DTR: fused dt projection (delta formed in-kernel from dtr and Wdt) vs a materialised delta
+__global__ __launch_bounds__(NW* WAVE) void selscan_fwd_kernel(const float* __restrict__ u, const float* __restrict__ delta,
+                                                               const float* __restrict__ Am, const float* __restrict__ Bm,
+                                                               const float* __restrict__ Cm, const float* __restrict__ Dv,
+                                                               const float* __restrict__ dbias, float* __restrict__ y,
+                                                               float* __restrict__ hstate, int K, int Dk, int L, int nchunk,
+                                                               int xmode, const float* __restrict__ dtr,
+                                                               const float* __restrict__ Wdt, int R) {
+  static_assert(IT == ITEMS || (IT == 2 * ITEMS && VEC && !CKL), "4 steps per lane, or 8 on the vector path with row checkpoints");
+  constexpr int CH = WAVE * IT, H = IT / 4;   // chunk length; 16-byte groups per lane
+  constexpr int LPB = BLK / IT;               // lanes per checkpoint block
+  const int nblk = (L + BLK - 1) / BLK;       // checkpoints per row: hstate is [rows][nblk][NS]
   extern __shared__ __attribute__((aligned(16))) float smem[];  // B tile | C tile | dt factors | Wdt rows | row constants | carried h
-  float(*sB)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(smem);
-  float(*sC)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(smem + NS * CHUNK);
-  float(*s_dtr)[CHUNK] = reinterpret_cast<float(*)[CHUNK]>(smem + 2 * NS * CHUNK);
-  float* s_W = smem + 2 * NS * CHUNK + (size_t)R * CHUNK;  // [FWD_ROWS * FWD_RPW][RMAX]
-  float* s_par = s_W + FWD_ROWS * FWD_RPW * RMAX;          // [FWD_ROWS * FWD_RPW][32]: A * log2(e) | D | bias
-  float* s_h = s_par + FWD_ROWS * FWD_RPW * 32;            // [FWD_ROWS * FWD_RPW][NS]
+  float(*sB)[CH] = reinterpret_cast<float(*)[CH]>(smem);
+  float(*sC)[CH] = reinterpret_cast<float(*)[CH]>(smem + NS * CH);
+  float(*s_dtr)[CH] = reinterpret_cast<float(*)[CH]>(smem + 2 * NS * CH);
+  float* s_W = smem + 2 * NS * CH + (size_t)R * CH;  // [NW * FWD_RPW][RMAX]
+  float* s_par = s_W + NW * FWD_RPW * RMAX;          // [NW * FWD_RPW][32]: A * log2(e) | D | bias
+  float* s_h = s_par + NW * FWD_RPW * 32;            // [NW * FWD_RPW][NS]
   // (wave index as a provably uniform value: row pointers then live in SGPRs and the loads take SGPR base + lane offset)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE), lane = threadIdx.x % WAVE;
-  const int d0 = (blockIdx.x * FWD_ROWS + wave) * FWD_RPW;
+  const int d0 = (blockIdx.x * NW + wave) * FWD_RPW;
   const int bk = blockIdx.y, k = bk % K, b = bk / K;
   // cross-scan layout (xmode): u is [B, 2, Dk, L] (k & 1 picks the row-major / column-major copy) and directions k >= 2
   // walk every time-indexed buffer back to front
@@ -395,61 +433,77 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
     if (((fhwid >> 1) + c) & 1) asm volatile("s_setprio 2"); else asm volatile("s_setprio 0");
 #endif
     __syncthreads();  // previous chunk's tiles fully consumed
-    const int t = c * CHUNK + lane * ITEMS;
+    const int t = c * CH + lane * IT;
     // first row's streams: requested before the staging, consumed after it
-    Raw4 n_uu = load4_issue<VEC>(urow(d0), t, L, rev), n_dl = n_uu;
-    if (!DTR) n_dl = load4_issue<VEC>(drow(d0), t, L, rev);
-    stage_tiles<FWD_ROWS * WAVE, VEC>(Bp, Cp, Rp, R, c * CHUNK, L, sB, sC, s_dtr, rev);
+    Raw4 n_uu[H], n_dl[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      n_uu[h] = load4_issue<VEC>(urow(d0), t + 4 * h, L, rev);
+      n_dl[h] = n_uu[h];
+      if (!DTR) n_dl[h] = load4_issue<VEC>(drow(d0), t + 4 * h, L, rev);
+    }
+    stage_tiles<NW * WAVE, VEC, CH>(Bp, Cp, Rp, R, c * CH, L, sB, sC, s_dtr, rev);
     __syncthreads();
 #pragma unroll 1
     for (int r = 0; r < nrow; ++r) {
       const int d = d0 + r, wr = wave * FWD_RPW + r;
       const size_t row = ((size_t)b * K + k) * Dk + d;
-      float uu[ITEMS], dt[ITEMS], dtu[ITEMS], yy[ITEMS];
-      load4_take<VEC>(n_uu, uu, rev);
-      load4_take<VEC>(n_dl, dt, rev);
-      if (DTR) dt[0] = dt[1] = dt[2] = dt[3] = 0.f;
-      n_uu = load4_issue<VEC>(urow(d + 1), t, L, rev);  // next row's streams, in flight behind this row's arithmetic
-      if (!DTR) n_dl = load4_issue<VEC>(drow(d + 1), t, L, rev);
+      float uu[IT], dt[IT], dtu[IT], yy[IT];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float q4[ITEMS];
+        load4_take<VEC>(n_uu[h], q4, rev);
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) uu[4 * h + i] = q4[i];
+        load4_take<VEC>(n_dl[h], q4, rev);
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) dt[4 * h + i] = DTR ? 0.f : q4[i];
+        n_uu[h] = load4_issue<VEC>(urow(d + 1), t + 4 * h, L, rev);  // next row's streams, in flight behind this row's arithmetic
+        if (!DTR) n_dl[h] = load4_issue<VEC>(drow(d + 1), t + 4 * h, L, rev);
+      }
       const float par = s_par[wr * 32 + (lane & 31)];
       const float hc = s_h[wr * NS + (lane & (NS - 1))];  // state entering the chunk, lane n holds state n
       float nh = 0.f;
       // delta_t = <Wdt[kd, :], dtr[:, t]>: the [B, 4*d_inner, L] delta tensor of the reference is never materialised
-      if (DTR) dtproj_row(s_W + wr * RMAX, s_dtr, R, lane, dt);
+      if constexpr (DTR && IT == ITEMS) dtproj_row(s_W + wr * RMAX, s_dtr, R, lane, dt);
+      if constexpr (DTR && IT != ITEMS) dtproj_row8(s_W + wr * RMAX, s_dtr, R, lane, dt);
       const float Dd = rdlane(par, 16), bias = rdlane(par, 17);
       const float m0 = lane == 0 ? 1.f : 0.f;
-      // checkpoints for the backward (SCAN_CKPT above): what a lane holds after its four steps, stored by the lane itself, a state pair
-      // at a time - every lane, or the last lane of each 16-lane row (a lane / block that starts beyond L, and in the second form every
+      // checkpoints for the backward (SCAN_CKPT above): what a lane holds after its last step, stored by the lane itself, a state pair
+      // at a time - every lane, or the last lane of each 64-step block (a lane / block that starts beyond L, and in the second form every
       // other lane, is dropped by the buffer's range check)
       const __amdgpu_buffer_rsrc_t hs_rs = row_rsrc(hstate + row * (size_t)nblk * NS, nblk * NS);
-      const int blk = CKL ? c * WAVE + lane : c * (CHUNK / BLK) + (lane >> 4);
+      const int blk = CKL ? c * WAVE + lane : c * (CH / BLK) + lane / LPB;
       const unsigned hs_off = CKL ? (blk < nblk ? (unsigned)blk * 8 : OOB)
-                                  : (((lane & 15) == 15 && blk < nblk) ? (unsigned)blk * NS * 4 : OOB);
+                                  : ((lane % LPB == LPB - 1 && blk < nblk) ? (unsigned)blk * NS * 4 : OOB);
 #pragma unroll
-      for (int i = 0; i < ITEMS; ++i) {
+      for (int i = 0; i < IT; ++i) {
         dt[i] = softplus_f((t + i < L) ? dt[i] + bias : -1e30f);  // steps beyond L become the identity map (dt = 0: a = 1, b = 0)
         dtu[i] = dt[i] * uu[i];
         yy[i] = Dd * uu[i];
       }
 #pragma unroll
       for (int n = 0; n < NS; n += 2) {
-        float a[2][ITEMS], bb[2][ITEMS], cc[2][ITEMS], A[2], Bv[2], hend[2], hin[2];
+        float a[2][IT], bb[2][IT], cc[2][IT], A[2], Bv[2], hend[2], hin[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const float4 b4 = *reinterpret_cast<const float4*>(&sB[n + j][lane * ITEMS]);
-          const float4 c4 = *reinterpret_cast<const float4*>(&sC[n + j][lane * ITEMS]);
-          const float A2 = rdlane(par, n + j);
-          bb[j][0] = b4.x; bb[j][1] = b4.y; bb[j][2] = b4.z; bb[j][3] = b4.w;
-          cc[j][0] = c4.x; cc[j][1] = c4.y; cc[j][2] = c4.z; cc[j][3] = c4.w;
 #pragma unroll
-          for (int i = 0; i < ITEMS; ++i) {
+          for (int h = 0; h < H; ++h) {
+            const float4 b4 = *reinterpret_cast<const float4*>(&sB[n + j][lane * IT + 4 * h]);
+            const float4 c4 = *reinterpret_cast<const float4*>(&sC[n + j][lane * IT + 4 * h]);
+            bb[j][4 * h] = b4.x; bb[j][4 * h + 1] = b4.y; bb[j][4 * h + 2] = b4.z; bb[j][4 * h + 3] = b4.w;
+            cc[j][4 * h] = c4.x; cc[j][4 * h + 1] = c4.y; cc[j][4 * h + 2] = c4.z; cc[j][4 * h + 3] = c4.w;
+          }
+          const float A2 = rdlane(par, n + j);
+#pragma unroll
+          for (int i = 0; i < IT; ++i) {
             a[j][i] = __builtin_amdgcn_exp2f(dt[i] * A2);
             bb[j][i] *= dtu[i];
           }
           A[j] = a[j][0];
           Bv[j] = bb[j][0];
 #pragma unroll
-          for (int i = 1; i < ITEMS; ++i) { Bv[j] = fmaf(a[j][i], Bv[j], bb[j][i]); A[j] *= a[j][i]; }
+          for (int i = 1; i < IT; ++i) { Bv[j] = fmaf(a[j][i], Bv[j], bb[j][i]); A[j] *= a[j][i]; }
           hin[j] = rdlane(hc, n + j);               // state entering the chunk: joins at lane 0, from there on Bv is the state itself
           Bv[j] = fmaf(A[j] * m0, hin[j], Bv[j]);
         }
@@ -458,7 +512,7 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
         for (int j = 0; j < 2; ++j) {
           float hh = fmaf(m0, hin[j], prev_lane0(Bv[j]));  // state entering this lane's first step (lane 0: the chunk's)
 #pragma unroll
-          for (int i = 0; i < ITEMS; ++i) {
+          for (int i = 0; i < IT; ++i) {
             hh = fmaf(a[j][i], hh, bb[j][i]);
             yy[i] = fmaf(cc[j][i], hh, yy[i]);
           }
@@ -470,10 +524,15 @@ __global__ __launch_bounds__(FWD_ROWS* WAVE) void selscan_fwd_kernel(const float
           const u32x2 w = {__builtin_bit_cast(unsigned, hend[0]), __builtin_bit_cast(unsigned, hend[1])};
           __builtin_amdgcn_raw_buffer_store_b64(w, hs_rs, hs_off, CKL ? (n / 2) * nblk * 8 : n * 4, 0);
         }
-        asm volatile("" : "+v"(yy[0]), "+v"(yy[1]), "+v"(yy[2]), "+v"(yy[3]), "+v"(nh));
+        if constexpr (IT == ITEMS) asm volatile("" : "+v"(yy[0]), "+v"(yy[1]), "+v"(yy[2]), "+v"(yy[3]), "+v"(nh));
+        else asm volatile("" : "+v"(yy[0]), "+v"(yy[1]), "+v"(yy[2]), "+v"(yy[3]), "+v"(yy[IT - 4]), "+v"(yy[IT - 3]), "+v"(yy[IT - 2]), "+v"(yy[IT - 1]), "+v"(nh));
         __builtin_amdgcn_sched_barrier(0);  // one pair's temporaries at a time
       }
-      store4<VEC>(y + row * L, t, L, yy, rev);
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float q4[ITEMS] = {yy[4 * h], yy[4 * h + 1], yy[4 * h + 2], yy[4 * h + 3]};
+        store4<VEC>(y + row * L, t + 4 * h, L, q4, rev);
+      }
       if (lane < NS) s_h[wr * NS + lane] = nh;
     }
   }
@@ -1033,16 +1092,32 @@ static int scan_fwd_launch(const float* u, const float* delta, const float* dtr,
     return TAMTR_EINVAL;
   if (xmode != 0 && xmode != 1) return TAMTR_EINVAL;
   if (N != NS || (long long)B * K > 65535 || (xmode && K != 4) || (dtr && (R < 1 || R > RMAX))) return TAMTR_EUNSUP;
-  const int nchunk = (L + CHUNK - 1) / CHUNK;
-  dim3 grid((Dk + FWD_ROWS * FWD_RPW - 1) / (FWD_ROWS * FWD_RPW), B * K);
   hipStream_t s = (hipStream_t)stream;
   if (!dtr) R = 0;
-  const size_t dyn = ((size_t)2 * NS * CHUNK + (size_t)R * CHUNK + (size_t)FWD_ROWS * FWD_RPW * (RMAX + 32 + NS)) * sizeof(float);
-#define LAUNCH_FWD(VEC, DTR)                                                                                                          \
-  hipLaunchKernelGGL((selscan_fwd_kernel<VEC, DTR>), grid, dim3(FWD_ROWS * WAVE), dyn, s, u, delta, A, Bm, Cm, D, dbias, y, hstate, K, Dk, \
-                     L, nchunk, xmode, dtr, Wdt, R)
-  if (L % 4 == 0) { if (dtr) LAUNCH_FWD(true, true); else LAUNCH_FWD(true, false); }
-  else { if (dtr) LAUNCH_FWD(false, true); else LAUNCH_FWD(false, false); }
+  // 8 steps per lane (512-step chunks, 16 waves) on the vector path; 4 steps / 8 waves for L % 4 != 0, the SCAN_CKPT = 4 build and TAMTR_SCAN_FWD4=1
+  static const bool fwd4 = [] { const char* e = getenv("TAMTR_SCAN_FWD4"); return e && e[0] == '1'; }();  // read once (A/B switch)
+  // ... and only where 512-step chunks do not pad the sequence much more than 256-step ones (L = 1600: 2048 against 1792 steps, measured
+  // 0.87 against 0.78 ms; L = 25600 / 6400: 2.46 against 2.80 ms, 1.26 against 1.34 ms - profiles/r03_scan_forward_it8.txt)
+  const long long pad8 = (L + 2 * CHUNK - 1) / (2 * CHUNK) * (2LL * CHUNK), pad4 = (L + CHUNK - 1) / CHUNK * (long long)CHUNK;
+  const bool it8 = L % 4 == 0 && !CKL && !fwd4 && pad8 * 16 <= pad4 * 17;
+  const int ch = it8 ? 2 * CHUNK : CHUNK, nw = it8 ? 2 * FWD_ROWS : FWD_ROWS;
+  const int nchunk = (L + ch - 1) / ch;
+  dim3 grid((Dk + nw * FWD_RPW - 1) / (nw * FWD_RPW), B * K);
+  const size_t dyn = ((size_t)2 * NS * ch + (size_t)R * ch + (size_t)nw * FWD_RPW * (RMAX + 32 + NS)) * sizeof(float);
+#define LAUNCH_FWD(VEC, DTR, IT, NW)                                                                                                   \
+  {                                                                                                                                    \
+    auto kern = selscan_fwd_kernel<VEC, DTR, IT, NW>;                                                                                  \
+    if (dyn > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess)  \
+      return TAMTR_ELAUNCH; /* (per call: the attribute belongs to the current device) */                                              \
+    hipLaunchKernelGGL(kern, grid, dim3(NW * WAVE), dyn, s, u, delta, A, Bm, Cm, D, dbias, y, hstate, K, Dk, L, nchunk, xmode, dtr, Wdt, R); \
+  }
+  if constexpr (!CKL) {
+    if (it8) { if (dtr) LAUNCH_FWD(true, true, 2 * ITEMS, 2 * FWD_ROWS) else LAUNCH_FWD(true, false, 2 * ITEMS, 2 * FWD_ROWS) }
+  }
+  if (!it8) {
+    if (L % 4 == 0) { if (dtr) LAUNCH_FWD(true, true, ITEMS, FWD_ROWS) else LAUNCH_FWD(true, false, ITEMS, FWD_ROWS) }
+    else { if (dtr) LAUNCH_FWD(false, true, ITEMS, FWD_ROWS) else LAUNCH_FWD(false, false, ITEMS, FWD_ROWS) }
+  }
 #undef LAUNCH_FWD
   return tamtr_launch_status();
 }
