@@ -33,20 +33,12 @@ namespace {
 constexpr int NS = 16;         // d_state
 constexpr int ITEMS = 4;       // time steps per lane
 constexpr int CHUNK = WAVE * ITEMS;
-// Checkpoints the forward leaves for the backward.  SCAN_CKPT = 64 (default): the state after every 16-lane DPP row (64 steps),
-// [row][block][16], 1 byte per step and row; the backward rebuilds the lanes' entry states from there with a four-level in-row scan.
-// SCAN_CKPT = 4 (A/B build, tools/build_scan_variant.sh ck4 -DSCAN_CKPT=4): the state after EVERY lane's four steps, 16 L bytes per row
-// (4 x the row's u), stored [row][state pair][lane-block][2] so that a wave's store / load of one pair is one contiguous 512-byte run;
-// the backward then READS the state entering each lane instead of recomputing it.  Measured (profiles/r03_scan_checkpoints.txt): 13 % fewer
-// vector instructions in the backward (27.2 against 31.1 lane-operations per step and state) but only 2 % less time, and the forward pays
-// 13 % for the 6.7 GB of stores at level 0 - bytes were not the cheap side of the trade after all; not the default.
-#ifndef SCAN_CKPT
-#define SCAN_CKPT 64
-#endif
-constexpr bool CKL = SCAN_CKPT == ITEMS;
-constexpr int BLK = CKL ? ITEMS : 16 * ITEMS;   // checkpoint interval in steps
-static_assert(SCAN_CKPT == ITEMS || SCAN_CKPT == 16 * ITEMS, "checkpoint per lane or per DPP row");
-struct Raw2 { float v[2]; };
+// Checkpoints the forward leaves for the backward: the state after every 16-lane DPP row of the backward (64 steps), hstate
+// [row][block][16], 1 byte per step and row.  The backward rebuilds the states entering its lanes from there with four in-row scan levels.
+// Two denser forms were built and measured in round 3 and removed (profiles/r03_scan_checkpoints.txt): a checkpoint per LANE, read instead
+// of rebuilt (13 % fewer vector instructions in the backward, 2 % less time, forward +13 % for 6.7 GB of stores at level 0), and one per
+// QUAD of lanes (two scan levels instead of four: four DPP instructions fewer per state, the same time to the microsecond).
+constexpr int BLK = 16 * ITEMS;   // checkpoint interval in steps
 constexpr int FWD_ROWS = 8;    // waves (= rows of one (b,k) group) per workgroup, forward
 constexpr int FWD_RPW = 4;     // rows per wave and chunk, forward (they share the staged tiles)
 constexpr int BWD_WAVES = 4;   // waves per workgroup, backward
@@ -213,15 +205,6 @@ __device__ __forceinline__ void prefix_and_row_suffix_scan_b(float& pA, float& p
                LVLB(1, 0, "row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
                : "+v"(pA), "+v"(pB), "+v"(sA), "+v"(sB));
 }
-// one chain: inclusive PREFIX scan over the wave, B part only after the last level (one s_nop per level covers the VALU-write ->
-// DPP-read distance that the second chain's instructions used to fill)
-__device__ __forceinline__ void prefix_scan_b(float& A, float& B) {
-  asm volatile("s_nop 1\n\t"
-               LVL(1, 0, "row_shr:1 " FULL) "s_nop 0\n\t" LVL(1, 0, "row_shr:2 " FULL) "s_nop 0\n\t" LVL(1, 0, "row_shr:4 " FULL) "s_nop 0\n\t"
-               LVL(1, 0, "row_shr:8 " FULL) "s_nop 0\n\t" LVL(1, 0, "row_bcast:15 row_mask:0xa bank_mask:0xf") "s_nop 0\n\t"
-               LVLB(1, 0, "row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
-               : "+v"(A), "+v"(B));
-}
 #undef LVLB
 #undef LVL
 #undef FULL
@@ -379,7 +362,7 @@ __device__ __forceinline__ void dtproj_row(const float* __restrict__ Wrow, const
 // IT = steps per lane.  The eleven DPP instructions of a state's scan cost a wave the same whether its lanes hold 4 or 8 steps, and they
 // are 40 % of the forward's issue time at 4: the product runs IT = 8 (512-step chunks, 64 KB of B/C tiles: one workgroup of NW = 16
 // waves per CU instead of three of 8 - the same four waves per SIMD).  IT = 4 / NW = 8 remains for sequence lengths that are not a
-// multiple of 4 and for the SCAN_CKPT = 4 build.
+// multiple of 4.
 template <bool VEC, bool DTR, int IT, int NW>  // DTR: fused dt projection (delta formed in-kernel from dtr and Wdt) vs a materialised delta
 __global__ __launch_bounds__(NW* WAVE) void selscan_fwd_kernel(const float* __restrict__ u, const float* __restrict__ delta,
                                                                const float* __restrict__ Am, const float* __restrict__ Bm,
@@ -388,7 +371,7 @@ __global__ __launch_bounds__(NW* WAVE) void selscan_fwd_kernel(const float* __re
                                                                float* __restrict__ hstate, int K, int Dk, int L, int nchunk,
                                                                int xmode, const float* __restrict__ dtr,
                                                                const float* __restrict__ Wdt, int R) {
-  static_assert(IT == ITEMS || (IT == 2 * ITEMS && VEC && !CKL), "4 steps per lane, or 8 on the vector path with row checkpoints");
+  static_assert(IT == ITEMS || (IT == 2 * ITEMS && VEC), "4 steps per lane, or 8 on the vector path");
   constexpr int CH = WAVE * IT, H = IT / 4;   // chunk length; 16-byte groups per lane
   constexpr int LPB = BLK / IT;               // lanes per checkpoint block
   const int nblk = (L + BLK - 1) / BLK;       // checkpoints per row: hstate is [rows][nblk][NS]
@@ -469,13 +452,12 @@ __global__ __launch_bounds__(NW* WAVE) void selscan_fwd_kernel(const float* __re
       if constexpr (DTR && IT != ITEMS) dtproj_row8(s_W + wr * RMAX, s_dtr, R, lane, dt);
       const float Dd = rdlane(par, 16), bias = rdlane(par, 17);
       const float m0 = lane == 0 ? 1.f : 0.f;
-      // checkpoints for the backward (SCAN_CKPT above): what a lane holds after its last step, stored by the lane itself, a state pair
-      // at a time - every lane, or the last lane of each 64-step block (a lane / block that starts beyond L, and in the second form every
-      // other lane, is dropped by the buffer's range check)
+      // checkpoints for the backward (BLK above): what the last lane of each BLK-step block holds after its last step, stored by
+      // that lane itself, a state pair at a time (a block that starts beyond L, and every other lane, is dropped by the buffer's range
+      // check)
       const __amdgpu_buffer_rsrc_t hs_rs = row_rsrc(hstate + row * (size_t)nblk * NS, nblk * NS);
-      const int blk = CKL ? c * WAVE + lane : c * (CH / BLK) + lane / LPB;
-      const unsigned hs_off = CKL ? (blk < nblk ? (unsigned)blk * 8 : OOB)
-                                  : ((lane % LPB == LPB - 1 && blk < nblk) ? (unsigned)blk * NS * 4 : OOB);
+      const int blk = c * (CH / BLK) + lane / LPB;
+      const unsigned hs_off = (lane % LPB == LPB - 1 && blk < nblk) ? (unsigned)blk * NS * 4 : OOB;
 #pragma unroll
       for (int i = 0; i < IT; ++i) {
         dt[i] = softplus_f((t + i < L) ? dt[i] + bias : -1e30f);  // steps beyond L become the identity map (dt = 0: a = 1, b = 0)
@@ -522,7 +504,7 @@ __global__ __launch_bounds__(NW* WAVE) void selscan_fwd_kernel(const float* __re
         {  // the pair's two checkpoint values are neighbours in memory: one 8-byte store
           typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
           const u32x2 w = {__builtin_bit_cast(unsigned, hend[0]), __builtin_bit_cast(unsigned, hend[1])};
-          __builtin_amdgcn_raw_buffer_store_b64(w, hs_rs, hs_off, CKL ? (n / 2) * nblk * 8 : n * 4, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(w, hs_rs, hs_off, n * 4, 0);
         }
         if constexpr (IT == ITEMS) asm volatile("" : "+v"(yy[0]), "+v"(yy[1]), "+v"(yy[2]), "+v"(yy[3]), "+v"(nh));
         else asm volatile("" : "+v"(yy[0]), "+v"(yy[1]), "+v"(yy[2]), "+v"(yy[3]), "+v"(yy[IT - 4]), "+v"(yy[IT - 3]), "+v"(yy[IT - 2]), "+v"(yy[IT - 1]), "+v"(nh));
@@ -579,16 +561,6 @@ __device__ __forceinline__ float bwd_fetch_param(const float* __restrict__ Am, c
 __device__ __forceinline__ float bwd_fetch_ck(const float* __restrict__ hstate, size_t row, int nblk, int c, int lane) {
   const int g = c * (CHUNK / BLK) + (3 - (lane >> 4)) - 1;
   return hstate[(row * nblk + min(max(g, 0), nblk - 1)) * NS + (lane & (NS - 1))];
-}
-// SCAN_CKPT = 4: state pair p entering lane-block gb (= the forward's checkpoint after lane-block gb - 1; gb = 0 starts from zero, which
-// is what the range check returns for the dropped access): issue only, the pair is consumed a whole row later
-__device__ __forceinline__ Raw2 bwd_issue_ck(const float* __restrict__ hstate, size_t row, int nlb, int gb, int p) {
-  const __amdgpu_buffer_rsrc_t rs = row_rsrc(hstate + row * (size_t)nlb * NS, nlb * NS);
-  const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, (gb >= 1 && gb <= nlb) ? (unsigned)(gb - 1) * 8 : OOB, p * nlb * 8, 0);
-  static_assert(sizeof(v) == sizeof(Raw2), "64-bit buffer load");
-  Raw2 r;
-  __builtin_memcpy(r.v, &v, sizeof(r.v));
-  return r;
 }
 // v[lane - k] inside each 16-lane row (k is a constant after unrolling: the switch folds); lanes without a source get `old`
 template <int K>
@@ -708,17 +680,12 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
     int t = c * CHUNK + tl * ITEMS;
     // first row's streams: requested before the staging, consumed after it (row index clamped: always issued, never under a branch)
     Raw4 n_uu, n_g, n_dl;
-    float n_par, n_ck = 0.f;
-    Raw2 hck[NS / 2];  // SCAN_CKPT = 4: the 16 states entering this lane's four steps, for the row about to be worked on (see below)
+    float n_par, n_ck;
     {
       const int dd = min(d0, dlast);
       bwd_fetch_row<VEC>(u, gy, b, K, k, Dk, dd, L, t, rev, xmode, n_uu, n_g);
       n_par = bwd_fetch_param(Am, Dv, dbias, k * Dk + dd, lane);
-      if (!CKL) n_ck = bwd_fetch_ck(hstate, ((size_t)b * K + k) * Dk + dd, nblk, c, lane);
-      if (CKL) {
-#pragma unroll
-        for (int p = 0; p < NS / 2; ++p) hck[p] = bwd_issue_ck(hstate, ((size_t)b * K + k) * Dk + dd, nblk, c * WAVE + tl, p);
-      }
+      n_ck = bwd_fetch_ck(hstate, ((size_t)b * K + k) * Dk + dd, nblk, c, lane);
       n_dl = n_uu;
       if (!DTR) n_dl = load4_issue<VEC>(delta + (((size_t)b * K + k) * Dk + dd) * L, t, L, rev);
     }
@@ -742,10 +709,9 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
       float uu[ITEMS], g[ITEMS], dt[ITEMS], dtu[ITEMS], S[ITEMS], ddtA[ITEMS];
       const float par = n_par;
       // states entering this lane's 64-step block, lane (r, j): state j (zero for the first block of the sequence)
-      const float ck = (c > 0 || lane < 48) ? n_ck : 0.f;   // (SCAN_CKPT = 64 only)
+      // states entering this lane's 64-step block, lane (r, j): state j (zero for the first block of the sequence)
+      const float ck = (c > 0 || lane < 48) ? n_ck : 0.f;
       const float m15 = (lane & 15) == 15 ? 1.f : 0.f;  // the lane of each row that comes first in time
-      const size_t nrow_ck = ((size_t)b * K + k) * Dk + min(d + 1, dlast);  // SCAN_CKPT = 4: the row whose checkpoints are requested during this one
-      Raw2 hnx[2] = {{{0.f, 0.f}}, {{0.f, 0.f}}};
       const float m0 = lane == 0 ? 1.f : 0.f;           // the lane that comes last in time: where the next chunk's carry enters
       {
         float dl[ITEMS];
@@ -758,7 +724,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
           const int dn = min(d + 1, dlast);
           bwd_fetch_row<VEC>(u, gy, b, K, k, Dk, dn, L, t, rev, xmode, n_uu, n_g);
           n_par = bwd_fetch_param(Am, Dv, dbias, k * Dk + dn, lane);
-          if (!CKL) n_ck = bwd_fetch_ck(hstate, ((size_t)b * K + k) * Dk + dn, nblk, c, lane);
+          n_ck = bwd_fetch_ck(hstate, ((size_t)b * K + k) * Dk + dn, nblk, c, lane);
           if (!DTR) n_dl = load4_issue<VEC>(delta + (((size_t)b * K + k) * Dk + dn) * L, t, L, rev);
         }
         if (DTR) dtproj_row(s_W + wr * RMAX, s_dtr, R, tl, dl);
@@ -804,30 +770,15 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
         float SA = alast * P, SB = cg[ITEMS - 1];  // the lane's map gh -> SA gh + SB
 #pragma unroll
         for (int i = ITEMS - 2; i >= 0; --i) SB = fmaf(a[i + 1], SB, cg[i]);
-        float hin_;
-        if (CKL) {
-          // h_{t-1} of this lane's first step: read, not recomputed.  dL/dh: inclusive prefix scan over the whole wave (lanes 0 .. l =
-          // everything later in time)
-          hin_ = hck[n / 2].v[n & 1];
-          prefix_scan_b(SA, SB);
-          // this pair's registers are free: the NEXT row's pair goes into them and has the rest of this row to arrive.  The last two
-          // pairs would be requested at the very end of the row (and the row's first instructions wait for every load issued before
-          // them): theirs are requested early, into two spare pairs, and moved over when the row is done
-          if ((n & 1) && n / 2 < NS / 2 - 2) hck[n / 2] = bwd_issue_ck(hstate, nrow_ck, nblk, c * WAVE + tl, n / 2);
-          if (n == 1) hnx[0] = bwd_issue_ck(hstate, nrow_ck, nblk, c * WAVE + tl, NS / 2 - 2);
-          if (n == 3) hnx[1] = bwd_issue_ck(hstate, nrow_ck, nblk, c * WAVE + tl, NS / 2 - 1);
-        } else {
-          // h: the lane's map h -> A h + Bv (A = a0 P); the block's entry state joins at the lane that comes first in time (lane 15 of
-          // the row): from there on Bv is the state itself; four in-row levels, fused with the six of dL/dh
-          float A = a[0] * P, Bv = bu[0];
+        // h: the lane's map h -> A h + Bv (A = a0 P); the block's entry state joins at the lane that comes first in time (lane 15 of the
+        // row): from there on Bv is the state itself; four in-row suffix levels, fused with the six prefix levels of dL/dh
+        float A = a[0] * P, Bv = bu[0];
 #pragma unroll
-          for (int i = 1; i < ITEMS; ++i) Bv = fmaf(a[i], Bv, bu[i]);
-          const float h0 = row_shr(0.f, ck, 15 - n);  // lane 15 of each row: state n of the row's checkpoint (elsewhere: finite, times 0)
-          Bv = fmaf(A * m15, h0, Bv);
-          prefix_and_row_suffix_scan_b(SA, SB, A, Bv);
-          hin_ = dpp<0x101, 0xf>(h0, Bv);  // the state after lane + 1 (row_shl:1), the checkpoint at lane 15
-        }
-        const float hin = hin_;
+        for (int i = 1; i < ITEMS; ++i) Bv = fmaf(a[i], Bv, bu[i]);
+        const float h0 = row_shr(0.f, ck, 15 - n);  // lane 15 of each row: state n of the row's checkpoint (elsewhere: finite, times 0)
+        Bv = fmaf(A * m15, h0, Bv);
+        prefix_and_row_suffix_scan_b(SA, SB, A, Bv);
+        const float hin = dpp<0x101, 0xf>(h0, Bv);  // h_{t-1} of this lane's first step: the state after lane + 1 (row_shl:1), the checkpoint at lane 15
         hh[0] = fmaf(a[0], hin, bu[0]);
 #pragma unroll
         for (int i = 1; i < ITEMS; ++i) hh[i] = fmaf(a[i], hh[i - 1], bu[i]);
@@ -853,7 +804,6 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
                           "+v"(dAv[n & 7]), "+v"(ncry));
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (CKL) { hck[NS / 2 - 2] = hnx[0]; hck[NS / 2 - 1] = hnx[1]; }
       STAMP(3)  // 3: the 16 states
       if (lane < NS) s_carry[wr * NS + lane] = ncry;
       // ---- after the states: du = D gy + dt S;  d(dt) = sum_n da_n A_n + u S;  d(delta) = d(dt) * sigmoid(delta + bias)
@@ -1094,12 +1044,12 @@ static int scan_fwd_launch(const float* u, const float* delta, const float* dtr,
   if (N != NS || (long long)B * K > 65535 || (xmode && K != 4) || (dtr && (R < 1 || R > RMAX))) return TAMTR_EUNSUP;
   hipStream_t s = (hipStream_t)stream;
   if (!dtr) R = 0;
-  // 8 steps per lane (512-step chunks, 16 waves) on the vector path; 4 steps / 8 waves for L % 4 != 0, the SCAN_CKPT = 4 build and TAMTR_SCAN_FWD4=1
+  // 8 steps per lane (512-step chunks, 16 waves) on the vector path; 4 steps / 8 waves for L % 4 != 0 and TAMTR_SCAN_FWD4=1
   static const bool fwd4 = [] { const char* e = getenv("TAMTR_SCAN_FWD4"); return e && e[0] == '1'; }();  // read once (A/B switch)
   // ... and only where 512-step chunks do not pad the sequence much more than 256-step ones (L = 1600: 2048 against 1792 steps, measured
   // 0.87 against 0.78 ms; L = 25600 / 6400: 2.46 against 2.80 ms, 1.26 against 1.34 ms - profiles/r03_scan_forward_it8.txt)
   const long long pad8 = (L + 2 * CHUNK - 1) / (2 * CHUNK) * (2LL * CHUNK), pad4 = (L + CHUNK - 1) / CHUNK * (long long)CHUNK;
-  const bool it8 = L % 4 == 0 && !CKL && !fwd4 && pad8 * 16 <= pad4 * 17;
+  const bool it8 = L % 4 == 0 && !fwd4 && pad8 * 16 <= pad4 * 17;
   const int ch = it8 ? 2 * CHUNK : CHUNK, nw = it8 ? 2 * FWD_ROWS : FWD_ROWS;
   const int nchunk = (L + ch - 1) / ch;
   dim3 grid((Dk + nw * FWD_RPW - 1) / (nw * FWD_RPW), B * K);
@@ -1111,9 +1061,7 @@ static int scan_fwd_launch(const float* u, const float* delta, const float* dtr,
       return TAMTR_ELAUNCH; /* (per call: the attribute belongs to the current device) */                                              \
     hipLaunchKernelGGL(kern, grid, dim3(NW * WAVE), dyn, s, u, delta, A, Bm, Cm, D, dbias, y, hstate, K, Dk, L, nchunk, xmode, dtr, Wdt, R); \
   }
-  if constexpr (!CKL) {
-    if (it8) { if (dtr) LAUNCH_FWD(true, true, 2 * ITEMS, 2 * FWD_ROWS) else LAUNCH_FWD(true, false, 2 * ITEMS, 2 * FWD_ROWS) }
-  }
+  if (it8) { if (dtr) LAUNCH_FWD(true, true, 2 * ITEMS, 2 * FWD_ROWS) else LAUNCH_FWD(true, false, 2 * ITEMS, 2 * FWD_ROWS) }
   if (!it8) {
     if (L % 4 == 0) { if (dtr) LAUNCH_FWD(true, true, ITEMS, FWD_ROWS) else LAUNCH_FWD(true, false, ITEMS, FWD_ROWS) }
     else { if (dtr) LAUNCH_FWD(false, true, ITEMS, FWD_ROWS) else LAUNCH_FWD(false, false, ITEMS, FWD_ROWS) }
