@@ -37,6 +37,17 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert h.tamtr_maxsigmoid_gate_fwd(z, z, z, z, z, z, z, 1, 1, 32, 16, 10, 1.0, 0, z) == -1
     assert h.tamtr_msdeform_attn_fwd(z, z, z, z, z, 1, 1, 1, 64, 1, 1, 4, 0, z) == -1
     assert h.tamtr_contrastive_logits_fwd(z, z, z, z, z, z, z, 1, 1, 1, 64, 0, z) == -1
+    # next-3: the gate's 3x3 value convolution and the BatchNorm combine (null operands; channel counts the kernel is not built for)
+    one = ctypes.c_void_p(16)   # a non-null, 16-byte aligned address that is never dereferenced: the checks come first
+    assert h.tamtr_conv3x3_cl_stats_fwd(z, 64, z, z, z, z, z, z, 1, 8, 16, 64, 64, 1e-3, 0.03, z) == -1
+    assert h.tamtr_conv3x3_cl_stats_fwd(one, 48, one, one, z, z, z, one, 1, 8, 16, 48, 64, 1e-3, 0.03, z) == -2     # C1 % 32
+    assert h.tamtr_conv3x3_cl_stats_fwd(one, 64, one, one, z, z, z, one, 1, 8, 16, 64, 96, 1e-3, 0.03, z) == -2     # C2 % 64
+    assert h.tamtr_conv3x3_cl_stats_fwd(one, 32, one, one, z, z, z, one, 1, 8, 16, 64, 64, 1e-3, 0.03, z) == -1     # pitch < C1
+    assert h.tamtr_conv3x3_pack_weight(z, z, 64, 64, 0, z) == -1
+    assert h.tamtr_conv3x3_pack_weight(one, one, 40, 64, 0, z) == -2
+    assert h.tamtr_bn_finalize(z, z, z, z, 64, 10, 1e-3, 0.03, z) == -1
+    assert h.tamtr_conv3x3_tiles(2, 40, 40) == 2 * 5 * 3 and h.tamtr_conv3x3_tiles(1, 8, 16) == 1
+    assert h.tamtr_selective_scan_chunk() == 64                                     # checkpoint interval of hstate (ABI 23)
 
 
 def test_cpu_tensors_are_refused_not_emulated():
