@@ -1050,7 +1050,10 @@ static int scan_fwd_launch(const float* u, const float* delta, const float* dtr,
   // 0.87 against 0.78 ms; L = 25600 / 6400: 2.46 against 2.80 ms, 1.26 against 1.34 ms - profiles/r03_scan_forward_it8.txt)
   const long long pad8 = (L + 2 * CHUNK - 1) / (2 * CHUNK) * (2LL * CHUNK), pad4 = (L + CHUNK - 1) / CHUNK * (long long)CHUNK;
   const bool it8 = L % 4 == 0 && !fwd4 && pad8 * 16 <= pad4 * 17;
-  const int ch = it8 ? 2 * CHUNK : CHUNK, nw = it8 ? 2 * FWD_ROWS : FWD_ROWS;
+  // 16 waves per workgroup keep four waves on every SIMD beside the 64 KB of tiles - if the grid still covers the chip (256 CUs on MI355X:
+  // the only target); a small grid (1280 px / 8 images, level 0: 128 such workgroups) keeps 8-wave workgroups, one per CU
+  const bool wide = it8 && (long long)((Dk + 2 * FWD_ROWS * FWD_RPW - 1) / (2 * FWD_ROWS * FWD_RPW)) * B * K >= 256;
+  const int ch = it8 ? 2 * CHUNK : CHUNK, nw = wide ? 2 * FWD_ROWS : FWD_ROWS;
   const int nchunk = (L + ch - 1) / ch;
   dim3 grid((Dk + nw * FWD_RPW - 1) / (nw * FWD_RPW), B * K);
   const size_t dyn = ((size_t)2 * NS * ch + (size_t)R * ch + (size_t)nw * FWD_RPW * (RMAX + 32 + NS)) * sizeof(float);
@@ -1061,7 +1064,8 @@ static int scan_fwd_launch(const float* u, const float* delta, const float* dtr,
       return TAMTR_ELAUNCH; /* (per call: the attribute belongs to the current device) */                                              \
     hipLaunchKernelGGL(kern, grid, dim3(NW * WAVE), dyn, s, u, delta, A, Bm, Cm, D, dbias, y, hstate, K, Dk, L, nchunk, xmode, dtr, Wdt, R); \
   }
-  if (it8) { if (dtr) LAUNCH_FWD(true, true, 2 * ITEMS, 2 * FWD_ROWS) else LAUNCH_FWD(true, false, 2 * ITEMS, 2 * FWD_ROWS) }
+  if (it8 && wide) { if (dtr) LAUNCH_FWD(true, true, 2 * ITEMS, 2 * FWD_ROWS) else LAUNCH_FWD(true, false, 2 * ITEMS, 2 * FWD_ROWS) }
+  if (it8 && !wide) { if (dtr) LAUNCH_FWD(true, true, 2 * ITEMS, FWD_ROWS) else LAUNCH_FWD(true, false, 2 * ITEMS, FWD_ROWS) }
   if (!it8) {
     if (L % 4 == 0) { if (dtr) LAUNCH_FWD(true, true, ITEMS, FWD_ROWS) else LAUNCH_FWD(true, false, ITEMS, FWD_ROWS) }
     else { if (dtr) LAUNCH_FWD(false, true, ITEMS, FWD_ROWS) else LAUNCH_FWD(false, false, ITEMS, FWD_ROWS) }

@@ -25,8 +25,9 @@ def timeit(fn, n=5, warm=2):
 
 
 def bench_scan():
-    for lvl, (d_inner, L, R) in enumerate([(256, 25600, 8), (512, 6400, 16), (1024, 1600, 32)]):
-        B, K, N = 16, 4, 16
+    big = os.environ.get('TAMTR_BENCH_PX') == '1280'   # configs[4]: 1280 px, 8 images
+    for lvl, (d_inner, L, R) in enumerate([(256, 102400, 8), (512, 25600, 16), (1024, 6400, 32)] if big else [(256, 25600, 8), (512, 6400, 16), (1024, 1600, 32)]):
+        B, K, N = (8 if big else 16), 4, 16
         g = torch.Generator(device='cuda').manual_seed(0)
         side = int(L ** 0.5)
         u2 = torch.randn(B, 2, d_inner, L, device='cuda', generator=g)
