@@ -1052,7 +1052,11 @@ static int scan_fwd_launch(const float* u, const float* delta, const float* dtr,
   const bool it8 = L % 4 == 0 && !fwd4 && pad8 * 16 <= pad4 * 17;
   // 16 waves per workgroup keep four waves on every SIMD beside the 64 KB of tiles - if the grid still covers the chip (256 CUs on MI355X:
   // the only target); a small grid (1280 px / 8 images, level 0: 128 such workgroups) keeps 8-wave workgroups, one per CU
+#ifdef SCAN_FWD_NARROW   // (A/B build: 8-wave workgroups always)
+  const bool wide = false;
+#else
   const bool wide = it8 && (long long)((Dk + 2 * FWD_ROWS * FWD_RPW - 1) / (2 * FWD_ROWS * FWD_RPW)) * B * K >= 256;
+#endif
   const int ch = it8 ? 2 * CHUNK : CHUNK, nw = wide ? 2 * FWD_ROWS : FWD_ROWS;
   const int nchunk = (L + ch - 1) / ch;
   dim3 grid((Dk + nw * FWD_RPW - 1) / (nw * FWD_RPW), B * K);
