@@ -1001,20 +1001,35 @@ __global__ __launch_bounds__(256) void dtproj_gdtr_kernel(const float* __restric
     }
     __syncthreads();
     if (live) {
+      // ranks 16 / 32: eight rows' loads are issued together (row index clamped, the surplus rows' values replaced by zero).  Written as
+      // load - use per row the loop keeps ONE 8-byte load in flight per thread and waits out a memory round trip per row; with R x 4
+      // accumulators per thread there are too few waves per SIMD to hide that (level 1: 241 -> 175 us, level 2: 212 -> 130 us); at rank 8 the
+      // plain loop already runs at the rate of its bytes and the extra registers cost waves (302 -> 332 us): it stays
+      constexpr int UB = RT >= 16 ? 8 : 1;
       const int dn = min(64, dend - d0);
-      for (int dd = 0; dd < dn; ++dd) {
-        float4 g;
-        if (G16) {
-          const uint2 h = *reinterpret_cast<const uint2*>(gp16 + (size_t)(d0 + dd) * L + l0);
-          g = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xffff0000u));
-        } else {
-          g = *reinterpret_cast<const float4*>(gp + (size_t)(d0 + dd) * L + l0);
+      for (int dd = 0; dd < dn; dd += UB) {
+        float4 g[UB];
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+          const size_t ro = (size_t)(d0 + min(dd + j, dn - 1)) * L + l0;
+          if (G16) {
+            const uint2 h = *reinterpret_cast<const uint2*>(gp16 + ro);
+            g[j] = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xffff0000u));
+          } else {
+            g[j] = *reinterpret_cast<const float4*>(gp + ro);
+          }
         }
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-          const float w = sW[dd][r];
-          acc[r][0] = fmaf(w, g.x, acc[r][0]); acc[r][1] = fmaf(w, g.y, acc[r][1]);
-          acc[r][2] = fmaf(w, g.z, acc[r][2]); acc[r][3] = fmaf(w, g.w, acc[r][3]);
+        for (int j = 0; j < UB; ++j) {
+          const bool ok = dd + j < dn;
+          const float4 gj = ok ? g[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+          const int row = min(dd + j, 63);
+#pragma unroll
+          for (int r = 0; r < RT; ++r) {
+            const float w = sW[row][r];
+            acc[r][0] = fmaf(w, gj.x, acc[r][0]); acc[r][1] = fmaf(w, gj.y, acc[r][1]);
+            acc[r][2] = fmaf(w, gj.z, acc[r][2]); acc[r][3] = fmaf(w, gj.w, acc[r][3]);
+          }
         }
       }
     }
