@@ -268,7 +268,11 @@ __device__ __forceinline__ void stage_rows_vec(const float* __restrict__ P, int 
       v[j] = *reinterpret_cast<const float4*>(P + (ok ? (size_t)r * L + (rev ? L - 4 - t0 - tt : t0 + tt) : 0));
       if (!ok) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (rev) v[j] = make_float4(v[j].w, v[j].z, v[j].y, v[j].x);
-      dst[j] = i < total ? r * CHUNK + tt : -1;
+      // (512-step tiles, 8 steps per lane: the lane's two 16-byte pieces are kept 1 KB apart - piece h of lane l at (h * 64 + l) * 4 -
+      // so that a wave's fragment read is one contiguous kilobyte; side by side the lanes' 32-byte stride made every ds_read_b128 2-way
+      // conflicted)
+      const int tp = CH == 2 * CHUNK_DEFAULT ? ((tt >> 2) & 1) * (CH / 2) + (tt >> 3) * 4 : tt;
+      dst[j] = i < total ? r * CHUNK + tp : -1;
     }
 #pragma unroll
     for (int j = 0; j < PER; ++j)
@@ -316,8 +320,8 @@ __device__ __forceinline__ void dtproj_row8(const float* __restrict__ Wrow, cons
     float4 f[4][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      f[j][0] = *reinterpret_cast<const float4*>(&s_dtr[q + j][lane * 8]);
-      f[j][1] = *reinterpret_cast<const float4*>(&s_dtr[q + j][lane * 8 + 4]);
+      f[j][0] = *reinterpret_cast<const float4*>(&s_dtr[q + j][lane * 4]);          // (tile layout: stage_rows_vec)
+      f[j][1] = *reinterpret_cast<const float4*>(&s_dtr[q + j][CHUNK + lane * 4]);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -329,7 +333,7 @@ __device__ __forceinline__ void dtproj_row8(const float* __restrict__ Wrow, cons
   }
   for (; q < R; ++q) {
     const float w = Wrow[q];
-    const float4 f0 = *reinterpret_cast<const float4*>(&s_dtr[q][lane * 8]), f1 = *reinterpret_cast<const float4*>(&s_dtr[q][lane * 8 + 4]);
+    const float4 f0 = *reinterpret_cast<const float4*>(&s_dtr[q][lane * 4]), f1 = *reinterpret_cast<const float4*>(&s_dtr[q][CHUNK + lane * 4]);
     acc[0] = fmaf(w, f0.x, acc[0]); acc[1] = fmaf(w, f0.y, acc[1]); acc[2] = fmaf(w, f0.z, acc[2]); acc[3] = fmaf(w, f0.w, acc[3]);
     acc[4] = fmaf(w, f1.x, acc[4]); acc[5] = fmaf(w, f1.y, acc[5]); acc[6] = fmaf(w, f1.z, acc[6]); acc[7] = fmaf(w, f1.w, acc[7]);
   }
@@ -471,8 +475,8 @@ __global__ __launch_bounds__(NW* WAVE) void selscan_fwd_kernel(const float* __re
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
           for (int h = 0; h < H; ++h) {
-            const float4 b4 = *reinterpret_cast<const float4*>(&sB[n + j][lane * IT + 4 * h]);
-            const float4 c4 = *reinterpret_cast<const float4*>(&sC[n + j][lane * IT + 4 * h]);
+            const float4 b4 = *reinterpret_cast<const float4*>(&sB[n + j][h * (CH / H) + lane * 4]);  // (IT = 8: piece h of a lane lies 1 KB
+            const float4 c4 = *reinterpret_cast<const float4*>(&sC[n + j][h * (CH / H) + lane * 4]);  //  after piece 0, see stage_rows_vec)
             bb[j][4 * h] = b4.x; bb[j][4 * h + 1] = b4.y; bb[j][4 * h + 2] = b4.z; bb[j][4 * h + 3] = b4.w;
             cc[j][4 * h] = c4.x; cc[j][4 * h + 1] = c4.y; cc[j][4 * h + 2] = c4.z; cc[j][4 * h + 3] = c4.w;
           }
