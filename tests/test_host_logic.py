@@ -344,3 +344,20 @@ def test_bottleneck_shortcut_and_repconvn_on_cpu_match_their_definition():
     assert int(blk.cv2.bn.num_batches_tracked) == 1 and int(r.conv1.bn.num_batches_tracked) == 1
     plain = RepNBottleneck(16, 8).train()   # no shortcut when the widths differ
     assert plain(x).shape == (2, 8, 9, 7) and not plain.add
+
+
+def test_proj_conv_kernel_gating_is_host_logic_only():
+    """ops.conv3x3_cl_ok (which operands csrc/conv3x3.hip takes; next-3) decides on the host and touches no GPU: CPU tensors, fp32 maps,
+    strided / grouped / biased / 1x1 convolutions and channel counts outside the kernel's tiling go to the library path."""
+    import torch
+    import torch.nn as nn
+    import tamtr_amd.ops as ops
+    conv = nn.Conv2d(64, 64, 3, 1, 1, bias=False)
+    x = torch.zeros(1, 64, 8, 16, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert not ops.conv3x3_cl_ok(x, conv)                                   # a CPU tensor: never
+    assert ops._cl_pitch(x) == 64 and ops._cl_pitch(torch.zeros(1, 128, 8, 16).contiguous(memory_format=torch.channels_last).chunk(2, 1)[1]) == 128
+    assert ops._cl_pitch(torch.zeros(1, 64, 8, 16)) == 0                    # NCHW: no pixel pitch
+    meta = torch.empty(1, 64, 8, 16, dtype=torch.bfloat16, device='meta')   # the remaining checks are on the module, not on memory
+    for bad in (nn.Conv2d(64, 64, 3, 2, 1, bias=False), nn.Conv2d(64, 64, 3, 1, 1, bias=True), nn.Conv2d(64, 64, 1, 1, 0, bias=False),
+                nn.Conv2d(64, 64, 3, 1, 1, groups=2, bias=False), nn.Conv2d(64, 96, 3, 1, 1, bias=False), nn.Conv2d(48, 64, 3, 1, 1, bias=False)):
+        assert not ops.conv3x3_cl_ok(meta, bad)
