@@ -10,7 +10,7 @@
 Workload = BASELINE.json configs[1]/[2] ("TAM-TR-s" := the reference's only graph, TAMTR.yaml, 42.1 M params - SURVEY D3):
 synthetic images rand(B,3,640,640), unit-norm 10x512 text features, 8 GT boxes per image (=> 192 denoising + 100 queries).
 The step is the reference's training step (engine/trainer.py:328-357,471-479): forward through BaseModel.forward(dict),
-loss, backward, gradient clip 0.1, AdamW(lr 1e-4, wd 1e-4).  Every rank runs bs 16 (weak scaling); gradients are summed
+loss, backward, gradient clip 0.1, AdamW(lr 1e-4, wd 1e-4), EMA update of the weights (utils/torch_utils.py:392-419).  Every rank runs bs 16 (weak scaling); gradients are summed
 over ranks with bucketed RCCL all-reduces overlapped with the backward (tam-tr_amd/dist.py).
 
 One JSON line on rank 0.  `roofline`: the MEH value-projection GEMM (tamtr_linear_bf16, the dominant dense contraction of
@@ -169,7 +169,8 @@ def cpu_baseline(n_img=8, S=640, repeats=1):
     mean = sum(times) / len(times)
     return {'value': n_img / mean, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
             'sample': f'{n_img} image(s) {S}x{S} (BASELINE configs[0]), fp32 CPU oracle (torch CPU ops + C scan twin): warm-up step on 2 images, '
-                      f'then {repeats} timed fwd+bwd step(s) on {n_img}, mean {mean:.1f} s (min {min(times):.1f}, max {max(times):.1f})'}
+                      f'then {repeats} timed fwd+bwd step(s) on {n_img}, mean {mean:.1f} s (min {min(times):.1f}, max {max(times):.1f}); a single-step figure on a '
+                      'shared host: 43 - 93 s across boxes of this pool (+-2x) - context, not a target'}
 
 
 def graph_vs_eager(model, batch, seed=4321):
@@ -228,6 +229,11 @@ def main():
 
     import tamtr_amd  # noqa: F401  (raises if the HIP library is missing; loading it does not touch the GPU)
     from tamtr_amd import dist as tdist
+    n_dev = torch.cuda.device_count()    # (counting devices does not initialise the GPU)
+    if args.gpus > max(n_dev, 1) and os.environ.get('TAMTR_BENCH_ALLOW_GLOO') != '1':
+        # one rank per GPU: with fewer devices than ranks two ranks would share a card and the line would not be an N-GPU measurement
+        raise SystemExit(f'bench.py --gpus {args.gpus}: this node shows {n_dev} GPU(s) (torch.cuda.device_count()); one rank per GPU is needed. '
+                         'Nothing was launched.  (TAMTR_BENCH_ALLOW_GLOO=1 rehearses the code path with ranks sharing a device over gloo.)')
     plan = tdist.launch_plan(args.gpus, os.environ, sys.argv[1:], __file__)
     if plan is not None:     # `python bench.py --gpus N`: become the launcher of N ranks; nothing below runs in this process
         raise SystemExit(tdist.self_launch(plan))
@@ -243,13 +249,16 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
-    from tamtr_amd.tuning import use_tuned_convolutions
-    conv_tuning = use_tuned_convolutions(args.conv_tuning, args.conv_db)   # before the first convolution
+    from tamtr_amd.tuning import use_tuned_convolutions_ranked
+    # before the first convolution; rank 0 seeds the shared per-user table directory while the others wait (tuning.py)
+    conv_tuning = use_tuned_convolutions_ranked(args.conv_tuning, args.conv_db, rank=rank, world=world)
     torch.set_num_threads(min(8, host_cores()))  # host side = launch issue + a few tiny CPU ops (dn RNG, scipy LSA): no 128-thread pools
     torch.manual_seed(0)
     model = RTDETRDetectionWorldModel(nc=10).to(dev).train()
     model.autocast_dtype = torch.bfloat16 if args.dtype == 'bf16' else None
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999), fused=True)
+    from tamtr_amd.engine import ModelEMA
+    ema = ModelEMA(model)   # the reference's optimizer_step ends with ema.update(model) on every rank (trainer.py:259,478-479)
     reducer = None
     if world > 1:
         reducer = tdist.GradReducer(model.named_parameters(), skip=lambda n: '.attn.' in n, late=lambda n: 'denoising_class_embed' in n,
@@ -269,6 +278,7 @@ def main():
             reducer.finish()
         torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], max_norm=0.1)
         opt.step()
+        ema.update(model)
         return loss
 
     def fence():
@@ -353,7 +363,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'host_cpu_ms_per_step': {'max': max(host_all), 'per_rank': [round(v, 2) for v in host_all], 'host_cores': host_cores()},
-            'config': {'workload': f'TAM-TR (TAMTR.yaml graph, 42.1M params) train step fwd+loss+bwd+AdamW, {args.imgsz}x{args.imgsz}, '
+            'config': {'workload': f'TAM-TR (TAMTR.yaml graph, 42.1M params) train step fwd+loss+bwd+clip+AdamW+EMA, {args.imgsz}x{args.imgsz}, '
                                    f'bs {args.batch}/GPU, 10 text prompts, 8 GT/img, full BTA-PAN+MEH HIP path',
                        'global_batch': world * args.batch, 'parallelism': f'dp{world}', 'final_loss': float(loss.detach()),
                        'bf16_vs_fp32': mode_err, 'dist_backend': backend, 'dist_world_size': world,

@@ -339,6 +339,9 @@ def fit(model, train_loader, prepare, epochs, val_loader=None, lr0=1e-4, lrf=1.0
     its last `close_mosaic` epochs starts with mosaic already closed.  static_graph: record trunk + VSS blocks + input projection as HIP graphs on the first batch
     (model.capture_static_part; batches of another shape, and evaluation, run eagerly).  Returns the per-epoch records."""
     nb = len(train_loader)
+    if nb == 0:   # e.g. drop_last with fewer samples per rank than the batch size: the loop below would 'train' for zero steps without a word
+        raise ValueError(f'fit(): the training loader yields no batches ({len(train_loader.dataset)} samples, batch size {train_loader.batch_size}, '
+                         f'drop_last={getattr(train_loader, "drop_last", None)})')
     opt = build_optimizer(model, name=optimizer, lr=lr0, momentum=momentum, decay=weight_decay,
                           iterations=math.ceil(len(train_loader.dataset) / max(train_loader.batch_size or 1, 1)) * epochs)
     lf = linear_lr(epochs, lrf)
@@ -362,14 +365,14 @@ def fit(model, train_loader, prepare, epochs, val_loader=None, lr0=1e-4, lrf=1.0
         from .data import reset_workers
         reset_workers(train_loader)     # persistent workers keep their own copy of the dataset
 
-    if mosaic_open and start > epochs - close_mosaic:   # resumed past the switch-over epoch (trainer.py:611-615)
+    if mosaic_open and resume is not None and start > epochs - close_mosaic:   # RESUMED past the switch-over epoch (trainer.py:593-594,617: not a fresh run)
         shut_mosaic()
         mosaic_open = False
     for epoch in range(start, epochs):
         model.train()
         if hasattr(train_loader.sampler, 'set_epoch'):
             train_loader.sampler.set_epoch(epoch)
-        if mosaic_open and epoch >= epochs - close_mosaic:
+        if mosaic_open and epoch == epochs - close_mosaic:   # trainer.py:315 tests equality: a run shorter than close_mosaic never closes it
             shut_mosaic()
             mosaic_open = False
         t0, mean_items, waited, i = time.time(), None, 0.0, -1

@@ -219,8 +219,9 @@ class RTDETRDetectionWorldModel(nn.Module):
         The model is left exactly as it was found: BatchNorm running statistics / counters moved by the warm-up passes are put back and
         no random numbers are drawn (the DropPath factors are an INPUT of the recorded function; the step draws them eagerly).
         verify=True: the recorded graphs are replayed once and held to an eager forward + backward on the same inputs
-        (GraphedPart.verify: token memory and every parameter gradient); on a mismatch the graphs are dropped, the reason is logged and
-        RuntimeError is raised - callers (engine.fit, bench.py, tools/train.py) then run eagerly.  The result is kept in
+        (GraphedPart.verify: token memory and every parameter gradient); on a mismatch - or when eager execution itself is too noisy for the
+        comparison to decide anything (`conclusive: False`; verify='loose' accepts that case) - the graphs are dropped, the reason is logged
+        and RuntimeError is raised - callers (engine.fit, bench.py, tools/train.py) then run eagerly.  The result is kept in
         `self.static_part_check`."""
         import torch.version
         from .graphs import GraphedPart, VALIDATED_HIP
@@ -254,11 +255,19 @@ class RTDETRDetectionWorldModel(nn.Module):
                    f"HIP {torch.version.hip}): running eagerly")
             (log or print)(msg)
             raise RuntimeError(msg)
-        if log is not None and verify and not self.static_part_check['conclusive']:
+        if verify and not self.static_part_check['conclusive']:
+            # eager execution itself is not reproducible here (MIOpen's heuristic solvers, tables of another build): the comparison can only
+            # tell "finite and within an order of magnitude", which a replay that is wrong by a few hundred per cent passes.  That is not
+            # accepted silently: the graphs are dropped unless the caller asked for the loose check (verify='loose').
             chk = self.static_part_check
-            log(f"HIP-graph replay check inconclusive: eager execution itself is not reproducible here (whole-gradient difference between two eager "
-                f"runs {chk['eager_noise_grad_l2']:.2e}, replay against eager {chk['grad_l2_rel_max']:.2e}); only finiteness and order of magnitude were "
-                'checked - TAMTR_DETERMINISTIC=1 gives an exact comparison')
+            msg = (f"HIP-graph replay check inconclusive: eager execution itself is not reproducible here (whole-gradient difference between two "
+                   f"eager runs {chk['eager_noise_grad_l2']:.2e}, replay against eager {chk['grad_l2_rel_max']:.2e}); only finiteness and order of "
+                   "magnitude could be checked - TAMTR_DETERMINISTIC=1 or the shipped convolution tables give a conclusive comparison")
+            if verify != 'loose':
+                (log or print)(msg + ": running eagerly (capture_static_part(verify='loose') accepts such a capture)")
+                raise RuntimeError(msg)
+            if log is not None:
+                log(msg + " - accepted (verify='loose')")
         if log is not None and not any(str(torch.version.hip).startswith(v) for v in VALIDATED_HIP):
             log(f'HIP-graph replay: runtime {torch.version.hip} is not one this package was validated on {VALIDATED_HIP}; the replay check passed')
         self._static = (graphed, tuple(img.shape), img.dtype, self.autocast_dtype, self.training, shapes, tuple(txt.shape))

@@ -361,9 +361,27 @@ _MSDA_ATOMICS = _os.environ.get('TAMTR_MSDA_ATOMICS') == '1'   # A/B switch: the
 
 def deterministic():
     """TAMTR_DETERMINISTIC=1 or torch.use_deterministic_algorithms(True): the reference's `deterministic: True`
-    (cfg/default.yaml:26, utils/torch_utils.py:371-389).  Kernels of this package are order-fixed by construction; the switch makes
-    the few paths that would fall back to an atomic kernel raise instead, and tuning.py keeps MIOpen off its split-K solvers."""
+    (cfg/default.yaml:26, utils/torch_utils.py:371-389).  Kernels of this package are order-fixed by construction; the few shapes that
+    only an atomic kernel serves go through _atomic_fallback(), which follows torch's own convention for nondeterministic ops."""
     return _os.environ.get('TAMTR_DETERMINISTIC') == '1' or torch.are_deterministic_algorithms_enabled()
+
+
+_WARNED = set()
+
+
+def _atomic_fallback(what):
+    """Called before a float-atomic kernel runs in deterministic mode.  Strict mode (use_deterministic_algorithms(True)) raises, like
+    torch's own nondeterministic ops; warn-only mode - what the reference sets (utils/torch_utils.py:376: warn_only=True) and what
+    tuning.use_deterministic_convolutions() therefore sets - warns once per shape class and lets the atomic kernel run."""
+    if not deterministic():
+        return
+    if torch.are_deterministic_algorithms_enabled() and not torch.is_deterministic_algorithms_warn_only_enabled():
+        raise _lib.TamtrHipError(f'deterministic mode: {what}')
+    if what not in _WARNED:
+        _WARNED.add(what)
+        import warnings
+        warnings.warn(f'{what}; running the float-atomic kernel, this step is not bitwise reproducible '
+                      '(torch.use_deterministic_algorithms(True) without warn_only raises here instead)', UserWarning, stacklevel=3)
 
 
 def msda_sorted_ok(Q, P, D):
@@ -402,9 +420,8 @@ class _MSDeformCore(torch.autograd.Function):
             call('tamtr_msdeform_attn_bwd_sorted', ptr(gout), ptr(value), ctypes.cast(sh, ctypes.c_void_p), ptr(loc32), ptr(aw32),
                  ptr(gvalue), ptr(gloc), ptr(gaw), B, L, M, D, Q, nl, P, M * D, dtype_code(value), stream_ptr())
             return gvalue, None, gloc.to(loc_dt), gaw.to(aw_dt)
-        if deterministic():
-            raise _lib.TamtrHipError(f'deterministic mode: the deformable-attention backward has no atomics-free kernel for Q*P*4 = {Q * P * 4} > 8192 '
-                                     f'corners per level or D = {D} (csrc/msdeform.hip)')
+        _atomic_fallback(f'the deformable-attention backward has no atomics-free kernel for Q*P*4 = {Q * P * 4} > 8192 corners per level '
+                         f'or D = {D} (csrc/msdeform.hip)')
         gvalue = torch.zeros(B, L, M, D, device=value.device, dtype=torch.float32)  # float-atomic accumulator
         call('tamtr_msdeform_attn_bwd', ptr(gout), ptr(value), ctypes.cast(sh, ctypes.c_void_p), ptr(loc32), ptr(aw32),
              ptr(gvalue), ptr(gloc), ptr(gaw), B, L, M, D, Q, nl, P, dtype_code(value), stream_ptr())
@@ -443,8 +460,8 @@ class _ContrastiveLogits(torch.autograd.Function):
         K = w32.shape[1]
         g = _c(g.float())
         dx = torch.empty_like(x)
-        if K > 16 and deterministic():
-            raise _lib.TamtrHipError(f'deterministic mode: the contrastive head backward sums d(what) with LDS atomics for K = {K} > 16 prompts')
+        if K > 16:
+            _atomic_fallback(f'the contrastive head backward sums d(what) with LDS atomics for K = {K} > 16 prompts (csrc/contrastive.hip)')
         slabs = _lib.lib().tamtr_contrastive_bwd_slabs(Q)   # per-workgroup partials of d(what), added below in a fixed order
         dwhat = torch.empty(B, slabs, K, C, device=x.device, dtype=torch.float32)
         call('tamtr_contrastive_logits_bwd', ptr(g), ptr(x), ptr(w32), ptr(ls), ptr(xinv), ptr(winv), ptr(dx), ptr(dwhat), B, Q, K,

@@ -5,8 +5,8 @@ Out of the box PyTorch asks MIOpen for its *heuristic* solver per convolution.  
 step) and costs 10 ms per step against what MIOpen's own timed search picks (105.8 -> 95.6 ms per step).  The search takes ~4
 minutes on a fresh machine, so its result - MIOpen's text find-db / perf-db, 130 KB - is shipped under tuned/miopen/ and handed to
 MIOpen through MIOPEN_USER_DB_PATH (a writable copy in a persistent per-user, per-MIOpen-build directory: MIOpen locks and appends
-to it).  Shapes that are not in the table are searched once per machine and kept there.  The training loader drops the tail batch
-(data.build_dataloader(drop_last=...)) so that the one uncovered training shape does not occur.
+to it).  Shapes that are not in the table (an epoch's tail batch, which the loader keeps like the reference's does; the validation batch)
+are searched once per machine and kept there.
 """
 import glob
 import json
@@ -113,3 +113,15 @@ def use_tuned_convolutions(mode='shipped', db_dir=None, log=None):
             f'{"" if persistent else " (temporary)"}; a shape outside them - a tail batch, the validation batch - is searched once (minutes) '
             'and kept there')
     return 'shipped tables'
+
+
+def use_tuned_convolutions_ranked(mode='shipped', db_dir=None, log=None, rank=0, world=1):
+    """use_tuned_convolutions() for one rank of a data-parallel job on one host: the ranks share the per-user table directory, so rank 0
+    seeds it (the copy of the shipped tables) while the others wait at a barrier, and no rank opens a table another one is still
+    writing.  Needs the process group (and, for RCCL, the rank's device) to be set up; world == 1 is the plain call."""
+    if world > 1 and rank != 0:
+        torch.distributed.barrier()
+    out = use_tuned_convolutions(mode, db_dir, log)
+    if world > 1 and rank == 0:
+        torch.distributed.barrier()
+    return out

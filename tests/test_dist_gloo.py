@@ -284,3 +284,104 @@ raise SystemExit(3 if '--fail' in sys.argv else 0)
     assert out.read_text() == '2 3.0'
     r = subprocess.run([sys.executable, str(script), '--gpus', '2', '--out', str(out), '--fail'], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
+
+
+def test_eight_ranks_self_launched_bf16_buckets_one_rank_without_boxes(tmp_path):
+    """The 8-GPU configuration (BASELINE configs[3]) rehearsed on the CPU: a script started as `python script --gpus 8` becomes the
+    launcher of 8 gloo ranks (launch_plan / self_launch, as bench.py does); the ranks shard 64 samples, reduce their gradients through
+    GradReducer with bf16 buckets on the wire, one rank's step has no contribution for the `late` parameter (a batch without boxes:
+    no gradient for `denoising_class_embed`), the table directory is seeded by rank 0 first (tuning.use_tuned_convolutions_ranked's
+    barrier protocol).  Checked: every rank issues the collectives in bucket order on every step, every rank ends with the same fp32
+    gradients, and they are the bf16-wire sums of the single-process gradient of the whole batch."""
+    script = tmp_path / 'dp8.py'
+    script.write_text(f'''
+import os, sys
+sys.path.insert(0, {ROOT!r})
+from tamtr_amd import dist as tdist
+plan = tdist.launch_plan(int(sys.argv[sys.argv.index('--gpus') + 1]), os.environ, sys.argv[1:], __file__)
+if plan is not None:
+    raise SystemExit(tdist.self_launch(plan))
+import torch, torch.nn as nn, torch.distributed as dist
+rank, local, world = tdist.init_from_env('gloo')
+torch.set_num_threads(1)
+out = sys.argv[sys.argv.index('--out') + 1]
+# rank 0 first, the others behind its barrier (the order tuning.use_tuned_convolutions_ranked keeps for the shared table directory)
+mark = os.path.join(out, 'seeded')
+if rank != 0:
+    dist.barrier()
+    assert os.path.exists(mark), 'a rank passed the barrier before rank 0 had seeded'
+else:
+    open(mark, 'w').close()
+    dist.barrier()
+
+
+class Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.embed = nn.Embedding(11, 8)          # the `late` parameter: no gradient on a rank whose batch has no boxes
+        self.a, self.b = nn.Linear(8, 32), nn.Linear(32, 4)
+        self.dead = nn.Linear(8, 8)                # never differentiated: the discarded gates' parameters (skip)
+
+    def forward(self, x, labels):
+        y = self.b(torch.relu(self.a(x)))
+        with torch.no_grad():
+            self.dead(x)
+        return y if labels is None else y + self.embed(labels)[:, :4]
+
+
+torch.manual_seed(0)
+model = Net()
+g = torch.Generator().manual_seed(1)
+x, lab = torch.randn(64, 8, generator=g), torch.randint(0, 11, (64,), generator=g)
+lo, hi = tdist.shard_batch(64, rank, world)
+red = tdist.GradReducer(model.named_parameters(), bucket_bytes=600, grad_dtype=torch.bfloat16, skip=lambda n: n.startswith('dead'),
+                        late=lambda n: n.startswith('embed'))
+assert len(red.buckets) >= 2 and red.buckets[-1]['params'][-1][0] == 'embed.weight'
+order, real = [], dist.all_reduce
+def spy(t, *a, **k):
+    order.append(t.numel())
+    return real(t, *a, **k)
+dist.all_reduce = spy
+grads = []
+for step in range(3):
+    red.prepare()
+    boxes = not (rank == 5 and step == 1)          # step 1: rank 5's images have no boxes
+    model(x[lo:hi], lab[lo:hi] if boxes else None).pow(2).sum().backward()
+    red.finish()
+    grads.append({{k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}})
+dist.all_reduce = real
+assert order == [b['flat'].numel() for b in red.buckets] * 3, order
+torch.save(grads, os.path.join(out, f'rank{{rank}}.pt'))
+dist.barrier()
+dist.destroy_process_group()
+''')
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
+    r = subprocess.run([sys.executable, str(script), '--gpus', '8', '--out', str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = [torch.load(tmp_path / f'rank{k}.pt') for k in range(8)]
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.embed = nn.Embedding(11, 8)
+            self.a, self.b = nn.Linear(8, 32), nn.Linear(32, 4)
+            self.dead = nn.Linear(8, 8)
+
+        def forward(self, x, labels):
+            y = self.b(torch.relu(self.a(x)))
+            return y if labels is None else y + self.embed(labels)[:, :4]
+    torch.manual_seed(0)
+    model = Net()
+    g = torch.Generator().manual_seed(1)
+    x, lab = torch.randn(64, 8, generator=g), torch.randint(0, 11, (64,), generator=g)
+    for step in range(3):
+        model.zero_grad()
+        sum(model(x[8 * k:8 * k + 8], None if (k == 5 and step == 1) else lab[8 * k:8 * k + 8]).pow(2).sum() for k in range(8)).backward()
+        for k in range(1, 8):       # all ranks hold the same reduced gradients, in fp32, for exactly the reduced parameters
+            assert set(got[k][step]) == set(got[0][step]) == {'embed.weight', 'a.weight', 'a.bias', 'b.weight', 'b.bias'}
+            assert all(torch.equal(got[k][step][n], got[0][step][n]) and got[k][step][n].dtype == torch.float32 for n in got[0][step])
+        for n, p in model.named_parameters():
+            if n in got[0][step]:   # 8 bf16 addends per element: 8 significant bits each
+                assert torch.allclose(got[0][step][n], p.grad, rtol=3e-2, atol=3e-2 * float(p.grad.abs().max())), (step, n)

@@ -1,6 +1,8 @@
 """CPU: host-side logic of the product (no HIP kernels involved): checkpoint surface (state_dict keys/shapes of every
 module vs the reference layout pinned in oracle/specs.py), the RT-DETR loss / RIOU / Hungarian matcher / denoising
 groups vs the reference fixtures, graph wiring."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -361,3 +363,51 @@ def test_proj_conv_kernel_gating_is_host_logic_only():
     for bad in (nn.Conv2d(64, 64, 3, 2, 1, bias=False), nn.Conv2d(64, 64, 3, 1, 1, bias=True), nn.Conv2d(64, 64, 1, 1, 0, bias=False),
                 nn.Conv2d(64, 64, 3, 1, 1, groups=2, bias=False), nn.Conv2d(64, 96, 3, 1, 1, bias=False), nn.Conv2d(48, 64, 3, 1, 1, bias=False)):
         assert not ops.conv3x3_cl_ok(meta, bad)
+
+
+def test_atomic_kernels_in_deterministic_mode_follow_torchs_warn_only_convention(monkeypatch):
+    """the reference's deterministic mode is warn-only (utils/torch_utils.py:376), and so is tuning.use_deterministic_convolutions().
+    A shape only an atomic kernel serves (contrastive head with more than 16 prompts, deformable backward beyond 8 192 corners) must warn
+    once and run there, and raise only under strict torch.use_deterministic_algorithms(True)."""
+    import warnings
+    import tamtr_amd.ops as ops
+    from tamtr_amd import TamtrHipError
+    monkeypatch.delenv('TAMTR_DETERMINISTIC', raising=False)
+    was, was_warn = torch.are_deterministic_algorithms_enabled(), torch.is_deterministic_algorithms_warn_only_enabled()
+    try:
+        torch.use_deterministic_algorithms(False)
+        ops._WARNED.clear()
+        with warnings.catch_warnings():
+            warnings.simplefilter('error')
+            ops._atomic_fallback('shape X')                      # not deterministic: silent
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        with pytest.warns(UserWarning, match='shape X'):
+            ops._atomic_fallback('shape X')
+        with warnings.catch_warnings():
+            warnings.simplefilter('error')
+            ops._atomic_fallback('shape X')                      # once per shape class
+        torch.use_deterministic_algorithms(True)
+        with pytest.raises(TamtrHipError, match='shape X'):
+            ops._atomic_fallback('shape X')
+        torch.use_deterministic_algorithms(False)
+        monkeypatch.setenv('TAMTR_DETERMINISTIC', '1')           # the package's own switch alone is warn-only as well
+        ops._WARNED.clear()
+        with pytest.warns(UserWarning, match='shape Y'):
+            ops._atomic_fallback('shape Y')
+    finally:
+        torch.use_deterministic_algorithms(was, warn_only=was_warn)
+        ops._WARNED.clear()
+
+
+def test_bench_refuses_more_ranks_than_gpus_before_launching_anything():
+    """bench.py --gpus N on a node that shows fewer than N GPUs stops with a clear message before it starts any rank.
+    Here: no GPU at all (or one) against --gpus 8; counting devices does not initialise the GPU."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    if torch.cuda.device_count() >= 8:
+        pytest.skip('this node has 8 GPUs')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'TAMTR_BENCH_ALLOW_GLOO')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0'], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and 'one rank per GPU' in r.stderr and '[launch]' not in r.stderr, r.stderr[-1500:]

@@ -60,8 +60,9 @@ def main():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--grad-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire (N > 1)')
     ap.add_argument('--static-part', default='graph', choices=['graph', 'eager'], help='replay trunk + VSS + input projection as HIP graphs (model.capture_static_part)')
-    ap.add_argument('--keep-tail', action='store_true', help="train on each epoch's incomplete last batch too (the reference does; here it is a "
-                                                             'shape outside the tuned tables and the recorded graphs, so it is dropped by default)')
+    ap.add_argument('--drop-tail', action='store_true', help="leave out each epoch's incomplete last batch (NOT the reference's behaviour - its "
+                                                             'build_dataloader has no drop_last and trains on the tail; the tail is a shape outside the tuned '
+                                                             'tables and the recorded graphs: it runs kernel by kernel and its convolutions are searched once per machine)')
     ap.add_argument('--conv-tuning', default='shipped', choices=['shipped', 'search', 'off'], help='MIOpen solver choice (tam-tr_amd/tuning.py)')
     args = ap.parse_args()
 
@@ -74,10 +75,6 @@ def main():
     rank, local, world = tdist.init_from_env()
     if args.gpus is not None and args.gpus != world:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    from tamtr_amd.tuning import use_tuned_convolutions
-    conv_tuning = use_tuned_convolutions(args.conv_tuning, log=(print if rank == 0 else None))   # before the first convolution (tables cover 640 px / 16 images; other shapes are searched once)
-    if rank == 0:
-        print(f'convolution tuning: {conv_tuning}', flush=True)
     try:       # host side = kernel launches + a few tiny CPU ops: a thread pool sized for the whole host only adds wake-up latency
         torch.set_num_threads(min(8, len(os.sched_getaffinity(0))))
     except AttributeError:
@@ -85,6 +82,11 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)      # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    from tamtr_amd.tuning import use_tuned_convolutions_ranked
+    # before the first convolution (tables cover 640 px / 16 images; other shapes are searched once); rank 0 seeds the shared directory first
+    conv_tuning = use_tuned_convolutions_ranked(args.conv_tuning, log=(print if rank == 0 else None), rank=rank, world=world)
+    if rank == 0:
+        print(f'convolution tuning: {conv_tuning}', flush=True)
     tmp = None
     if args.synthetic:
         tmp = tempfile.TemporaryDirectory()
@@ -102,7 +104,7 @@ def main():
 
     train = D.PromptDetDataset(spec['train'], names, args.imgsz, augment=True, hyp={'mosaic': args.mosaic}, batch_size=args.batch,
                                device_augment=args.device_augment)
-    tl = D.build_dataloader(train, args.batch, args.workers, shuffle=True, rank=rank if world > 1 else -1, drop_last=not args.keep_tail)
+    tl = D.build_dataloader(train, args.batch, args.workers, shuffle=True, rank=rank if world > 1 else -1, drop_last=args.drop_tail)
     vl = None
     if rank == 0 and 'val' in spec:
         vl = D.build_dataloader(D.PromptDetDataset(spec['val'], names, args.imgsz, augment=False), args.batch * 2, args.workers, shuffle=False)
