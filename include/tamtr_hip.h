@@ -66,7 +66,8 @@ int tamtr_maxsigmoid_gate_bwd(const void* dout, const void* x, const float* gk, 
  *      NHWC map is fine), v (T) [B*HW, C] packed = the RAW convolution output of the value branch; mean_rstd_* f32 [C][2] (batch mean,
  *      1/sqrt(var + eps), as tamtr_bncl_stats writes them), gamma_* / beta_* f32 [C]; a NULL mean_rstd_* means "already normalised /
  *      no BatchNorm" for that operand.  out (T) [B*HW, C] packed; aw / arg as above or NULL when no backward will follow.
- *      C = nh*hc <= 512, C/8 and hc/8 powers of two.
+ *      C = nh*hc <= 512, C/8 and hc/8 powers of two; e, v, out, gk 16-byte aligned, ld_e % 8 == 0 (bf16) / % 4 == 0 (f32): a lane
+ *      moves the 8 channels it owns as 16-byte pieces, four pixel rows of them in flight (round 4).
  */
 int tamtr_maxsigmoid_gate_cl_fwd(const void* e, long long ld_e, const float* mean_rstd_e, const float* gamma_e, const float* beta_e,
                                  const void* v, const float* mean_rstd_v, const float* gamma_v, const float* beta_v, const float* gk,
@@ -313,6 +314,13 @@ int tamtr_sum_n(const void* const* src, int n, void* out, long long n_elems, int
  *      workgroup, added by the caller (fixed order).  N % 8 == 0, N <= 2048, 256 % (N / 8) == 0. */
 int tamtr_colsum_blocks(long long M);
 int tamtr_colsum_bf16(const void* X, float* partial, long long M, int N, void* stream);
+/*      out f32 [C] = sum over the R rows of in (T) [R, C], added in a fixed order in ONE launch: the last stage of the package's two-stage
+ *      reductions - the d(gamma) / d(beta) partial rows of LayerNorm (vmamba.py:1190,1222 backward), the depthwise convolution's
+ *      d(weight) tile sums (vmamba.py:949-952), the scan's per-image d(A) / d(D) rows (csms6s.py:267), the row-slice products of the
+ *      tall linears' weight gradients (vmamba.py:935,1010 in_proj / out_proj).  Stands where `partials.sum(0)` stood: torch's
+ *      multi-workgroup reduction zeroes a semaphore buffer with a memset node per launch, which a HIP-graph replay under AQL packet
+ *      capture does not keep in order with the kernels around it.  C % 4 == 0; in 16-byte (f32) / 8-byte (bf16) aligned. */
+int tamtr_slab_sum_rows(const void* in, float* out, int R, long long C, int dtype, void* stream);
 int tamtr_fold_add(const float* g4, const void* m0, const void* m1, float* out, int B, long long n, int dtype, void* stream);
 
 /*      tamtr_layernorm_* : LayerNorm over the channel axis of a token-major map, VSSBlock.norm / norm2

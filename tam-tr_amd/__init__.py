@@ -12,16 +12,6 @@ import os
 if os.environ.get('TAMTR_CHANNELS_LAST', '1') != '0':
     os.environ.setdefault('PYTORCH_MIOPEN_SUGGEST_NHWC', '1')
 
-# MIOpen's "naive" reference convolutions (ConvDirectNaiveConv{Fwd,Bwd,Wrw}: one thread per output element, double accumulation) are
-# applicable to every problem, so every timed search (torch.backends.cudnn.benchmark, tuning.py) TIMES them - 0.3 ... 690 ms per call,
-# 66 s of GPU time before the first step of a 640 px / 16 image run (profiles/r03_bench_kernel_stats.csv rows 1-4), a find-db hit or not -
-# and the heuristic falls back to them for fp32 NHWC maps (32 ms per convolution in the fp32 parity mode).  Taken out of the
-# candidate list here (MIOpen reads the switches per call); kept in the deterministic mode, where they are the only NHWC bf16 solvers
-# that qualify.  Override by exporting the variables.
-if os.environ.get('TAMTR_DETERMINISTIC') != '1':
-    for _d in ('FWD', 'BWD', 'WRW'):
-        os.environ.setdefault(f'MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_{_d}', '0')
-
 # HIP graphs (graphs.py): with the runtime's AQL-packet capture of graph nodes, replays of the recorded backward intermittently
 # produced garbage gradients on ROCm 7.2 (tools/try_graph.py bisect; clean with the switch off).  Read when the HIP runtime starts.
 import sys

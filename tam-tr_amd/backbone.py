@@ -9,6 +9,14 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+def _conv(conv, x):
+    """conv(x); on the GPU through ops.conv2d_module (1x1 convolutions: weight gradient off MIOpen's memset + atomic solvers)."""
+    if x.is_cuda:
+        from . import ops
+        return ops.conv2d_module(conv, x)
+    return conv(x)
+
+
 BN_EPS, BN_MOMENTUM = 1e-3, 0.03  # the reference rewrites every BatchNorm2d after construction (torch_utils.py:303-313)
 
 
@@ -54,7 +62,7 @@ class Conv(nn.Module):
     def forward(self, x, residual=None):
         """residual: added to the block's output (the shortcut of a bottleneck); on the channels-last kernel path it joins inside the
         BatchNorm apply pass."""
-        return self.post(self.conv(x), residual)
+        return self.post(_conv(self.conv, x), residual)
 
     def post(self, y, residual=None):
         """Everything after the convolution: BatchNorm, activation, optional shortcut."""
@@ -94,7 +102,7 @@ class RepConvN(nn.Module):
         c1, c2 = self.conv1, self.conv2
         if x.is_cuda and type(self.act) in (nn.SiLU, nn.Identity) and 'bn' in c1._modules and 'bn' in c2._modules:
             from . import ops
-            y1, y2 = c1.conv(x), c2.conv(x)
+            y1, y2 = c1.conv(x), _conv(c2.conv, x)
             if (c1.fusable(y1) and c2.fusable(y2) and ops.is_cl(y1) and ops.is_cl(y2) and ops.bn_cl_ok(y1.shape[1], y1.dtype)
                     and c1.bn.track_running_stats and c2.bn.track_running_stats and c1.bn.eps == c2.bn.eps and c1.bn.momentum == c2.bn.momentum):
                 B, C, H, W = y1.shape   # both BatchNorms, the sum and the activation in one pass each way (csrc/bn.hip bncl2_*)

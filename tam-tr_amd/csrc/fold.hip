@@ -96,6 +96,54 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
   }
 }
 
+
+// out[c] = sum over r of in[r][c], r = 0 .. R-1: the LAST stage of every two-stage reduction of this package (per-workgroup partial
+// rows of d(gamma) / d(beta) / d(weight), per-image rows of the scan's d(A) / d(D), per-slice products of a split-K weight gradient),
+// in one launch and in a FIXED order (a thread adds its rows r = rg, rg + RG, ... in sequence, then the RG row groups are added in
+// index order through LDS): bitwise reproducible, no atomics, no semaphore.  Replaces torch's `partials.sum(0)`, whose multi-workgroup
+// form counts arrivals in a semaphore buffer that it zeroes with a memset node before every launch - the one node kind that does not
+// survive a HIP-graph replay under the runtime's AQL packet capture (profiles/r04_packet_capture_bisect.txt).
+// Two shapes of one kernel: R <= 32 (many columns, few rows: split-K slabs, per-image rows): RG = 1, a thread streams R rows of its
+// 4 columns; larger R (few columns, up to a few thousand partial rows): 1024 threads = CG column groups x RG row groups.
+template <typename T>
+__global__ __launch_bounds__(1024) void slab_sum_rows_kernel(const T* __restrict__ in, float* __restrict__ out, int R, long long C, int CG, int RG) {
+  __shared__ float4 red[1024];
+  const int cg = threadIdx.x % CG, rg = threadIdx.x / CG;
+  const long long c4 = (long long)blockIdx.x * CG + cg;      // group of 4 columns
+  const bool live = c4 * 4 < C;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    const T* p = in + c4 * 4;
+    int r = rg;
+    for (; r + 3 * RG < R; r += 4 * RG) {   // four rows in flight
+      float v[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Elt<T>::ld4(p + (long long)(r + j * RG) * C, v[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc.x += v[j][0]; acc.y += v[j][1]; acc.z += v[j][2]; acc.w += v[j][3]; }
+    }
+    for (; r < R; r += RG) {
+      float v[4];
+      Elt<T>::ld4(p + (long long)r * C, v);
+      acc.x += v[0]; acc.y += v[1]; acc.z += v[2]; acc.w += v[3];
+    }
+  }
+  if (RG == 1) {
+    if (live) *reinterpret_cast<float4*>(out + c4 * 4) = acc;
+    return;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (rg == 0 && live) {
+    float4 t = red[cg];
+    for (int g = 1; g < RG; ++g) {
+      const float4 u = red[g * CG + cg];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    *reinterpret_cast<float4*>(out + c4 * 4) = t;
+  }
+}
+
 }  // namespace
 
 extern "C" int tamtr_colsum_blocks(long long M) {
@@ -112,6 +160,29 @@ extern "C" int tamtr_colsum_bf16(const void* X, float* partial, long long M, int
   const int nblk = tamtr_colsum_blocks(M);
   const int rpb = (int)((M + nblk - 1) / nblk);
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, partial, M, N, rpb);
+  return tamtr_launch_status();
+}
+
+// in (T) [R, C] row-major -> out f32 [C] = the sum of the R rows, added in a fixed order (see slab_sum_rows_kernel); C % 4 == 0
+extern "C" int tamtr_slab_sum_rows(const void* in, float* out, int R, long long C, int dtype, void* stream) {
+  if (!in || !out || R <= 0 || C <= 0) return TAMTR_EINVAL;
+  if (dtype != TAMTR_F32 && dtype != TAMTR_BF16) return TAMTR_EINVAL;
+  if (C % 4 || (uintptr_t)in % (dtype == TAMTR_F32 ? 16 : 8) || (uintptr_t)out % 16) return TAMTR_EUNSUP;
+  const long long c4 = C / 4;
+  int CG, RG;
+  if (R <= 32) { CG = 256; RG = 1; }
+  else {
+    CG = 64;
+    while (CG > 1 && CG / 2 >= c4) CG /= 2;     // fewer column groups than 64: more row groups per workgroup
+    RG = 1024 / CG;
+  }
+  const long long blocks = (c4 + CG - 1) / CG;
+  if (blocks > 0x7fffffffLL) return TAMTR_EUNSUP;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == TAMTR_F32)
+    hipLaunchKernelGGL(slab_sum_rows_kernel<float>, dim3((unsigned)blocks), dim3(CG * RG), 0, s, (const float*)in, out, R, C, CG, RG);
+  else
+    hipLaunchKernelGGL(slab_sum_rows_kernel<bf16_t>, dim3((unsigned)blocks), dim3(CG * RG), 0, s, (const bf16_t*)in, out, R, C, CG, RG);
   return tamtr_launch_status();
 }
 

@@ -169,58 +169,148 @@ inline bool gate_args_ok(int B, int nh, int hc, int HW, int T) {
 // map through its row pitch), each lane owns 8 channels and applies its per-channel affine (a = rstd * gamma, b = beta - mean * a,
 // built from the batch statistics) in registers; a head's hc channels sit in hc / 8 adjacent lanes, so the T text dot products are
 // 8 FMAs per lane plus a butterfly over those lanes; max / sigmoid / scale and one 16-byte store.  Text tile [T, C] in LDS.
+//
+// Round 4: the round-3 form walked its 128 rows one at a time - one 16-byte load in flight per lane, every row a
+// full memory round trip behind the previous one's stores: 54 - 68 us per site = 0.7 - 2.3 TB/s, slower than the NCHW kernel it
+// replaced, with 208 workgroups at the 40 x 40 sites.  Now a lane takes U = 4 rows: their 8 loads (e and v) are issued together
+// before anything is computed, the text row is read from LDS once per t for all four, the butterfly is two DPP quad permutes
+// (hc = 32: four lanes per head) instead of ds_bpermute round trips, and a workgroup covers exactly 4 waves x (64 / lanes-per-row)
+// x U rows - 32 / 64 / 128 rows at C = 256 / 128 / 64, i.e. 800 / 1 600 / 3 200 workgroups at the three site shapes (16 images).
 template <typename ET>
+__device__ __forceinline__ void ld8(const ET* p, float (&o)[8]);
+template <>
+__device__ __forceinline__ void ld8<float>(const float* p, float (&o)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+template <>
+__device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&o)[8]) {
+  const uint4 t = *reinterpret_cast<const uint4*>(p);
+  const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+template <typename ET>
+__device__ __forceinline__ void st8(ET* p, const float (&v)[8]);
+template <>
+__device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <>
+__device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+  uint4 t;
+  t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  t.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+  t.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = t;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {   // quad permute of v (DPP: no LDS round trip)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+constexpr int GATE_CL_U = 4;   // rows per lane, all loads issued up front
+
+template <typename ET, bool VBN>
 __global__ __launch_bounds__(GATE_THREADS) void gate_cl_fwd_kernel(const ET* __restrict__ e, size_t ld_e, const float* __restrict__ mr_e,
                                                                     const float* __restrict__ ga_e, const float* __restrict__ be_e,
                                                                     const ET* __restrict__ v, const float* __restrict__ mr_v,
                                                                     const float* __restrict__ ga_v, const float* __restrict__ be_v,
                                                                     const float* __restrict__ gk, const float* __restrict__ bias,
                                                                     ET* __restrict__ out, float* __restrict__ aw_out,
-                                                                    int32_t* __restrict__ arg_out, int C, int hc, int HW, int T, float scale,
-                                                                    int rows_per_wg) {
-  extern __shared__ float s_gk[];  // [T][C]
+                                                                    int32_t* __restrict__ arg_out, int C, int hc, int HW, int T, float scale) {
+  constexpr int U = GATE_CL_U;
+  extern __shared__ __attribute__((aligned(16))) float s_gk[];  // [T][C]
   const int b = blockIdx.y, nh = C / hc;
-  for (int i = threadIdx.x; i < T * C; i += GATE_THREADS) s_gk[i] = gk[(size_t)b * T * C + i];
-  __syncthreads();
   const int lpr = C / 8, rpw = WAVE / lpr;           // lanes per pixel row, rows per wave
   const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
   const int c0 = (lane % lpr) * 8, rl = lane / lpr, head = c0 / hc, lph = hc / 8;
-  float ae[8], be[8], av[8], bv[8];
+  const int stride = (GATE_THREADS / WAVE) * rpw;    // rows between a lane's consecutive rows
+  const int r0 = blockIdx.x * (stride * U) + wave * rpw + rl;
+  // Everything this thread reads from global memory is requested here, unconditionally and in the order it is needed (a load inside a
+  // conditional block costs a drain of the whole queue at the block's end): text tile pieces, the value branch's BatchNorm constants,
+  // then the U rows of e and v.
+  const int n4 = T * C / 4;                           // float4 pieces of the text tile; <= 3 per thread at T * C <= 3072
+  const float4* gk4 = reinterpret_cast<const float4*>(gk + (size_t)b * T * C);
+  float4 tile[3];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    ae[j] = 1.f; be[j] = 0.f; av[j] = 1.f; bv[j] = 0.f;
-    if (mr_e) { ae[j] = mr_e[2 * (c0 + j) + 1] * ga_e[c0 + j]; be[j] = be_e[c0 + j] - mr_e[2 * (c0 + j)] * ae[j]; }
-    if (mr_v) { av[j] = mr_v[2 * (c0 + j) + 1] * ga_v[c0 + j]; bv[j] = be_v[c0 + j] - mr_v[2 * (c0 + j)] * av[j]; }
+  for (int k = 0; k < 3; ++k) tile[k] = gk4[min((int)threadIdx.x + k * GATE_THREADS, n4 - 1)];
+  float4 mrv[4], gav[2], bev[2];
+  if constexpr (VBN) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mrv[k] = reinterpret_cast<const float4*>(mr_v + 2 * c0)[k];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { gav[k] = reinterpret_cast<const float4*>(ga_v + c0)[k]; bev[k] = reinterpret_cast<const float4*>(be_v + c0)[k]; }
   }
-  const float rs = rsqrtf((float)hc), bm = bias[head];
-  const int row0 = blockIdx.x * rows_per_wg, row1 = min(row0 + rows_per_wg, HW);
-  for (int r = row0 + wave * rpw + rl; r < row1; r += (GATE_THREADS / WAVE) * rpw) {
-    const size_t row = (size_t)b * HW + r;
-    float ev[8], vv[8];
-    Elt<ET>::ld4(e + row * ld_e + c0, *reinterpret_cast<float(*)[4]>(ev));
-    Elt<ET>::ld4(e + row * ld_e + c0 + 4, *reinterpret_cast<float(*)[4]>(ev + 4));
+  const float bm = bias[head];
+  float ev[U][8], vv[U][8];
+  size_t rowi[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ev[j] = fmaf(ev[j], ae[j], be[j]);
-    float best = -INFINITY;
-    int besti = 0;
-    for (int t = 0; t < T; ++t) {
-      const float4 g0 = *reinterpret_cast<const float4*>(s_gk + (size_t)t * C + c0), g1 = *reinterpret_cast<const float4*>(s_gk + (size_t)t * C + c0 + 4);
-      float d = ev[0] * g0.x;
-      d = fmaf(ev[1], g0.y, d); d = fmaf(ev[2], g0.z, d); d = fmaf(ev[3], g0.w, d);
-      d = fmaf(ev[4], g1.x, d); d = fmaf(ev[5], g1.y, d); d = fmaf(ev[6], g1.z, d); d = fmaf(ev[7], g1.w, d);
-      for (int o = 1; o < lph; o <<= 1) d += __shfl_xor(d, o, WAVE);
-      if (d > best) { best = d; besti = t; }
+  for (int u = 0; u < U; ++u) {
+    rowi[u] = (size_t)b * HW + min(r0 + u * stride, HW - 1);
+    ld8<ET>(e + rowi[u] * ld_e + c0, ev[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) ld8<ET>(v + rowi[u] * C + c0, vv[u]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k)   // (clamped like the loads: a conditional store would pull its load into the branch, behind a queue drain)
+    reinterpret_cast<float4*>(s_gk)[min((int)threadIdx.x + k * GATE_THREADS, n4 - 1)] = tile[k];
+  for (int i = threadIdx.x + 3 * GATE_THREADS; i < n4; i += GATE_THREADS) reinterpret_cast<float4*>(s_gk)[i] = gk4[i];   // (T * C > 3072 only)
+  float av[8], bv[8];
+  if constexpr (VBN) {
+    const float mr[16] = {mrv[0].x, mrv[0].y, mrv[0].z, mrv[0].w, mrv[1].x, mrv[1].y, mrv[1].z, mrv[1].w,
+                          mrv[2].x, mrv[2].y, mrv[2].z, mrv[2].w, mrv[3].x, mrv[3].y, mrv[3].z, mrv[3].w};
+    const float ga[8] = {gav[0].x, gav[0].y, gav[0].z, gav[0].w, gav[1].x, gav[1].y, gav[1].z, gav[1].w};
+    const float be[8] = {bev[0].x, bev[0].y, bev[0].z, bev[0].w, bev[1].x, bev[1].y, bev[1].z, bev[1].w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { av[j] = mr[2 * j + 1] * ga[j]; bv[j] = be[j] - mr[2 * j] * av[j]; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { av[j] = 1.f; bv[j] = 0.f; }
+  }
+  if (mr_e) {   // (never in TAM-TR: ec is None, the embed operand has no BatchNorm)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a = mr_e[2 * (c0 + j) + 1] * ga_e[c0 + j], bb = be_e[c0 + j] - mr_e[2 * (c0 + j)] * a;
+#pragma unroll
+      for (int u = 0; u < U; ++u) ev[u][j] = fmaf(ev[u][j], a, bb);
     }
-    const float a = 1.f / (1.f + __expf(-(best * rs + bm)));
-    Elt<ET>::ld4(v + row * C + c0, *reinterpret_cast<float(*)[4]>(vv));
-    Elt<ET>::ld4(v + row * C + c0 + 4, *reinterpret_cast<float(*)[4]>(vv + 4));
+  }
+  const float rs = rsqrtf((float)hc);
+  __syncthreads();
+  float best[U];
+  int besti[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) vv[j] = fmaf(vv[j], av[j], bv[j]) * (a * scale);
-    Elt<ET>::st4(out + row * C + c0, *reinterpret_cast<float(*)[4]>(vv));
-    Elt<ET>::st4(out + row * C + c0 + 4, *reinterpret_cast<float(*)[4]>(vv + 4));
-    if (aw_out && c0 % hc == 0) {
-      aw_out[((size_t)b * nh + head) * HW + r] = a;
-      if (arg_out) arg_out[((size_t)b * nh + head) * HW + r] = besti;
+  for (int u = 0; u < U; ++u) { best[u] = -INFINITY; besti[u] = 0; }
+  for (int t = 0; t < T; ++t) {
+    const float4* gt = reinterpret_cast<const float4*>(s_gk) + ((t * C + c0) >> 2);   // (float4 indexing: provably 16-byte aligned -> ds_read_b128)
+    const float4 g0 = gt[0], g1 = gt[1];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float d = ev[u][0] * g0.x;
+      d = fmaf(ev[u][1], g0.y, d); d = fmaf(ev[u][2], g0.z, d); d = fmaf(ev[u][3], g0.w, d);
+      d = fmaf(ev[u][4], g1.x, d); d = fmaf(ev[u][5], g1.y, d); d = fmaf(ev[u][6], g1.z, d); d = fmaf(ev[u][7], g1.w, d);
+      if (lph >= 2) d += dpp_f<0xB1>(d);             // lane ^ 1
+      if (lph >= 4) d += dpp_f<0x4E>(d);             // lane ^ 2
+      for (int o = 4; o < lph; o <<= 1) d += __shfl_xor(d, o, WAVE);
+      if (d > best[u]) { best[u] = d; besti[u] = t; }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int r = r0 + u * stride;
+    const float a = 1.f / (1.f + __expf(-(best[u] * rs + bm)));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vv[u][j] = fmaf(vv[u][j], av[j], bv[j]) * (a * scale);
+    if (r < HW) {
+      st8<ET>(out + rowi[u] * C + c0, vv[u]);
+      if (aw_out && c0 % hc == 0) {
+        aw_out[((size_t)b * nh + head) * HW + r] = a;
+        if (arg_out) arg_out[((size_t)b * nh + head) * HW + r] = besti[u];
+      }
     }
   }
 }
@@ -276,19 +366,19 @@ extern "C" int tamtr_maxsigmoid_gate_cl_fwd(const void* e, long long ld_e, const
   if (!e || !v || !gk || !bias || !out || !gate_args_ok(B, nh, hc, HW, T)) return TAMTR_EINVAL;
   if ((mean_rstd_e && (!gamma_e || !beta_e)) || (mean_rstd_v && (!gamma_v || !beta_v)) || (arg && !aw)) return TAMTR_EINVAL;
   if (dtype != TAMTR_F32 && dtype != TAMTR_BF16) return TAMTR_EINVAL;
-  const int C = nh * hc, lpr = C / 8, al = dtype == TAMTR_F32 ? 16 : 8;
-  if (C % 8 || hc % 8 || lpr > WAVE || (lpr & (lpr - 1)) || ((hc / 8) & (hc / 8 - 1)) || ld_e < C || ld_e % 4 ||
-      ((uintptr_t)e | (uintptr_t)v | (uintptr_t)out) % al || (size_t)T * C * sizeof(float) > 60 * 1024 || B > 65535)
+  const int C = nh * hc, lpr = C / 8, al = 16;          // a lane moves 8 channels: 16-byte (bf16) / 2 x 16-byte (f32) accesses
+  if (C % 8 || hc % 8 || lpr > WAVE || (lpr & (lpr - 1)) || ((hc / 8) & (hc / 8 - 1)) || ld_e < C || ld_e % (dtype == TAMTR_F32 ? 4 : 8) ||
+      ((uintptr_t)e | (uintptr_t)v | (uintptr_t)out | (uintptr_t)gk | (uintptr_t)mean_rstd_v | (uintptr_t)gamma_v | (uintptr_t)beta_v) % al || (size_t)T * C * sizeof(float) > 60 * 1024 || B > 65535)
     return TAMTR_EUNSUP;
-  const int rows_per_wg = 128;
+  const int rows_per_wg = (GATE_THREADS / WAVE) * (WAVE / lpr) * GATE_CL_U;   // 32 / 64 / 128 rows at C = 256 / 128 / 64
   const dim3 grid((HW + rows_per_wg - 1) / rows_per_wg, B);
   const size_t lds = (size_t)T * C * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == TAMTR_F32)
-    hipLaunchKernelGGL(gate_cl_fwd_kernel<float>, grid, dim3(GATE_THREADS), lds, s, (const float*)e, (size_t)ld_e, mean_rstd_e, gamma_e, beta_e,
-                       (const float*)v, mean_rstd_v, gamma_v, beta_v, gk, bias, (float*)out, aw, arg, C, hc, HW, T, scale, rows_per_wg);
-  else
-    hipLaunchKernelGGL(gate_cl_fwd_kernel<bf16_t>, grid, dim3(GATE_THREADS), lds, s, (const bf16_t*)e, (size_t)ld_e, mean_rstd_e, gamma_e, beta_e,
-                       (const bf16_t*)v, mean_rstd_v, gamma_v, beta_v, gk, bias, (bf16_t*)out, aw, arg, C, hc, HW, T, scale, rows_per_wg);
+#define GO(ET, VBN)                                                                                                                       \
+  hipLaunchKernelGGL((gate_cl_fwd_kernel<ET, VBN>), grid, dim3(GATE_THREADS), lds, s, (const ET*)e, (size_t)ld_e, mean_rstd_e, gamma_e, beta_e, \
+                     (const ET*)v, mean_rstd_v, gamma_v, beta_v, gk, bias, (ET*)out, aw, arg, C, hc, HW, T, scale)
+  if (dtype == TAMTR_F32) { if (mean_rstd_v) GO(float, true); else GO(float, false); }
+  else { if (mean_rstd_v) GO(bf16_t, true); else GO(bf16_t, false); }
+#undef GO
   return tamtr_launch_status();
 }

@@ -282,7 +282,8 @@ def gate_cl_ok(x, C, nh):
     hc = C // nh if nh else 0
     lpr, lph = C // 8, hc // 8
     return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and _cl_pitch(x) and nh * hc == C and C % 8 == 0 and hc % 8 == 0
-            and 0 < lpr <= 64 and lpr & (lpr - 1) == 0 and lph & (lph - 1) == 0 and _cl_pitch(x) % 4 == 0)
+            and 0 < lpr <= 64 and lpr & (lpr - 1) == 0 and lph & (lph - 1) == 0 and _cl_pitch(x) % (16 // x.element_size()) == 0
+            and x.data_ptr() % 16 == 0)
 
 
 @torch.no_grad()
@@ -506,12 +507,12 @@ def dw_splitk(g2, x2):
         try:
             out = torch.bmm(a, b, out_dtype=torch.float32)
             _BMM_F32_OUT = True
-            return out.sum(0)
+            return slab_sum(out)
         except (NotImplementedError, RuntimeError, TypeError):
             if _BMM_F32_OUT:
                 raise
             _BMM_F32_OUT = False
-    return torch.bmm(a, b).float().sum(0)
+    return slab_sum(torch.bmm(a, b))
 
 
 class _LinearSplitK(torch.autograd.Function):
@@ -595,8 +596,24 @@ def colsum(g2):
         nblk = _lib.lib().tamtr_colsum_blocks(M)
         part = torch.empty(nblk, N, device=g2.device, dtype=torch.float32)
         call('tamtr_colsum_bf16', ptr(g2), ptr(part), M, N, stream_ptr())
-        return part.sum(0)
+        return slab_sum(part)
     return g2.sum(0, dtype=torch.float32)
+
+
+def slab_sum(t):
+    """t [R, ...] (f32 | bf16, contiguous) -> f32 [...] = t.sum(0) in a fixed order in ONE kernel (csrc/fold.hip tamtr_slab_sum_rows): the
+    last stage of the two-stage reductions (partial rows written by a kernel's workgroups, per-image rows, split-K slices).  torch's
+    `t.sum(0)` of such a shape is a multi-workgroup reduction behind a memset node (its arrival semaphores), the node kind that breaks
+    HIP-graph replays under AQL packet capture; it also needs `.float()` first for bf16 slices."""
+    R = t.shape[0]
+    C = t.numel() // max(R, 1)
+    if not (t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and t.is_contiguous() and R > 0 and C % 4 == 0 and t.data_ptr() % 16 == 0):
+        return t.float().sum(0)
+    if R == 1:
+        return t[0].float()
+    out = torch.empty(t.shape[1:], device=t.device, dtype=torch.float32)
+    call('tamtr_slab_sum_rows', ptr(t), ptr(out), R, C, dtype_code(t), stream_ptr())
+    return out
 
 
 class _LinearBF16ZeroRows(torch.autograd.Function):
@@ -693,6 +710,67 @@ def linear_bf16(x, weight, bias=None):
     return _LinearBF16.apply(x, weight, bias)
 
 
+# ------------------------------------------------------------------------------------------------ trunk: 1x1 convolutions' weight gradient
+class _Conv1x1CL(torch.autograd.Function):
+    """y = conv2d(x, w) for a 1x1 / stride 1 / ungrouped convolution on a channels-last map, with the WEIGHT gradient taken off MIOpen.
+    Forward and d/d(input) stay on the library (tuned tables).  MIOpen's weight-gradient solvers for these shapes split the reduction over
+    the B*H*W pixels across workgroups and add with atomics into a buffer they zero with hipMemsetAsync - a memset NODE in a recorded
+    graph, the one node kind that does not replay in order under the HIP runtime's AQL packet capture (profiles/r04_packet_capture_bisect.txt:
+    inf / NaN weight gradients on exactly the trunk's 1x1 convolutions).  A 1x1 convolution IS a per-pixel linear map, so its weight
+    gradient is dW [C2, C1] = dY^T X over the pixels: the row-sliced batched product + ordered slab sum of the tall linears
+    (dw_splitk, slab_sum) - fp32 result, bitwise reproducible, no memset, no atomics."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        xp = x if _is_cl(x) else _pack_cl(x)            # a channel slice of a wider map: packed once, kept for the backward
+        ctx.save_for_backward(xp, w)
+        return torch.nn.functional.conv2d(xp, w)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xp, w = ctx.saved_tensors
+        B, C1, H, W = xp.shape
+        C2 = w.shape[0]
+        gy = gy.to(xp.dtype)
+        gp = gy if _is_cl(gy) else (_pack_cl(gy) if _cl_pitch(gy) else gy.contiguous(memory_format=torch.channels_last))
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(gp, xp, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            g2, x2 = gp.permute(0, 2, 3, 1).reshape(B * H * W, C2), xp.permute(0, 2, 3, 1).reshape(B * H * W, C1)   # views of packed NHWC maps
+            gw = dw_splitk(g2, x2).view(C2, C1, 1, 1).to(w.dtype)
+        return gx, gw
+
+
+def _pack_cl(x):
+    """Packed channels-last copy of a channel slice of a channels-last map (no autograd: for use inside Functions)."""
+    B, C, H, W = x.shape
+    out = torch.empty((B, C, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    call('tamtr_copy_rows', ptr(x), _cl_pitch(x), ptr(out), C, B * H * W, C, dtype_code(x), stream_ptr())
+    return out
+
+
+def conv1x1_cl_ok(x, conv):
+    """A plain 1x1 / stride 1 / unpadded / ungrouped / unbiased nn.Conv2d on a channels-last (or channel-slice) fp32 / bf16 CUDA map whose
+    weight needs a gradient: the case _Conv1x1CL serves."""
+    return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and torch.is_grad_enabled()
+            and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and conv.weight.requires_grad
+            and bool(_cl_pitch(x)) and not x.is_contiguous() and x.shape[1] % 8 == 0 and x.data_ptr() % 16 == 0 and _cl_pitch(x) % 8 == 0)
+
+
+def conv2d_module(conv, x):
+    """conv(x) for an nn.Conv2d of the trunk; 1x1 convolutions on channels-last maps take _Conv1x1CL (library forward / input gradient,
+    own weight gradient), everything else the module itself."""
+    if conv1x1_cl_ok(x, conv):
+        w = conv.weight
+        if torch.is_autocast_enabled('cuda') and w.dtype != x.dtype and x.dtype == torch.get_autocast_dtype('cuda'):
+            w = w.to(x.dtype)    # (what autocast does inside conv2d; the trunk normally hands in the layer's bf16 copies already)
+        if w.dtype == x.dtype:
+            return _Conv1x1CL.apply(x, w)
+    return conv(x)
+
+
 # ------------------------------------------------------------------------------------------------ a-7 self-attention
 _mask_cache = []   # [(mask tensor, its _version, packed words)]: the entry keeps the mask alive, so its address cannot be reused
 
@@ -760,7 +838,7 @@ def _scan_row_sums(Bn, KD, device):
 def _split_row_sums(grow, R):
     """Add the images (a fixed-order reduction: no float atomics, bitwise reproducible) and cut the row into d(Wdt) [KD, R], dA [KD, 16],
     dD [KD], d(bias) [KD]."""
-    rs = grow.sum(0)
+    rs = slab_sum(grow)
     return rs[:, 16:16 + R], rs[:, :16], rs[:, 48], rs[:, 49]
 
 
@@ -907,7 +985,7 @@ class _DWConvSiluCross(torch.autograd.Function):
         ws = torch.empty(B, tiles, D, 10, device=xz.device, dtype=torch.float32)
         call('tamtr_dwconv_silu_cross_bwd', ptr(_c(g2.float())), ptr(xz), C2, ptr(w), ptr(bvec if b_dt is not None else None), ptr(gxz), C2,
              ptr(ws), B, D, H, W, dtype_code(xz), stream_ptr())
-        gwb = ws.sum((0, 1))
+        gwb = slab_sum(ws.view(-1, D, 10))
         gw = gwb[:, :9].reshape(w_shape).to(w_dt)
         gb = gwb[:, 9].to(b_dt) if b_dt is not None else None
         return gxz, gw, gb, None
@@ -961,7 +1039,7 @@ class _XProjCross(torch.autograd.Function):
                 gu2[:, i].copy_(torch.matmul(w.t(), gx))
                 ga = gx.view(Bn, 2 * C, S, L // S).transpose(1, 2).reshape(Bn * S, 2 * C, L // S)
                 ua = ub[:, i].reshape(Bn, D, S, L // S).transpose(1, 2).reshape(Bn * S, D, L // S)
-                gws.append(torch.bmm(ga, ua.transpose(1, 2)).float().sum(0))  # [2C, D]
+                gws.append(slab_sum(torch.bmm(ga, ua.transpose(1, 2))))  # [2C, D]
         gwx = torch.stack([gws[0][:C], gws[1][:C], gws[0][C:], gws[1][C:]], 0).to(w_dt)
         return gwx, gu2, None, None
 
@@ -1062,7 +1140,7 @@ class _LNGate(torch.autograd.Function):
         part = torch.empty(nblk, 2, D, device=x.device, dtype=torch.float32)
         call('tamtr_ln_gate_bwd', ptr(gout), ptr(x), ptr(xz), xz.shape[-1], ptr(g32), ptr(b32), ptr(stats), ptr(gx), ptr(gxz), ptr(part),
              ntok, D, dtype_code(xz), stream_ptr())
-        gsum = part.sum(0)
+        gsum = slab_sum(part)
         return gx, gxz, gsum[0].to(ctx.cfg[0]), gsum[1].to(ctx.cfg[1]), None
 
 
@@ -1137,7 +1215,7 @@ class _SS2DCore(torch.autograd.Function):
         part = torch.empty(nblk, 2, D, device=dev, dtype=torch.float32)
         call('tamtr_ln_gate_bwd', ptr(gout), ptr(ymT), ptr(xz), C2, ptr(g32), ptr(b32), ptr(stats), ptr(gy), ptr(gxz), ptr(part), B * L, D,
              dtype_code(xz), stream_ptr())
-        gsum = part.sum(0)
+        gsum = slab_sum(part)
         # cross-merge and scan
         g2 = torch.empty(B, 2, D, L, device=dev, dtype=torch.float32)
         call('tamtr_cross_merge_bwd', ptr(gy), ptr(g2), B, D, H, W, stream_ptr())
@@ -1166,7 +1244,7 @@ class _SS2DCore(torch.autograd.Function):
                 ms.append(torch.matmul(w.t(), gx))                                                                         # [B, D, L]
                 ga = gx.view(B, 2 * C, S, L // S).transpose(1, 2).reshape(B * S, 2 * C, L // S)
                 ua = ub[:, i].reshape(B, D, S, L // S).transpose(1, 2).reshape(B * S, D, L // S)
-                gws.append(torch.bmm(ga, ua.transpose(1, 2)).float().sum(0))  # [2C, D]
+                gws.append(slab_sum(torch.bmm(ga, ua.transpose(1, 2))))  # [2C, D]
         gwx = torch.stack([gws[0][:C], gws[1][:C], gws[0][C:], gws[1][C:]], 0).to(wx_dt)
         gu2 = torch.empty(B, 2, D, L, device=dev, dtype=torch.float32)
         call('tamtr_fold_add', ptr(gu), ptr(_c(ms[0])), ptr(_c(ms[1])), ptr(gu2), B, D * L, dtype_code(ms[0]), stream_ptr())
@@ -1176,7 +1254,7 @@ class _SS2DCore(torch.autograd.Function):
         wsd = torch.empty(B, tiles, D, 10, device=dev, dtype=torch.float32)
         call('tamtr_dwconv_silu_cross_bwd', ptr(gu2), ptr(xz), C2, ptr(cw), ptr(cb if cb_dt is not None else None), ptr(gxz), C2, ptr(wsd), B,
              D, H, W, dtype_code(xz), stream_ptr())
-        gwb = wsd.sum((0, 1))
+        gwb = slab_sum(wsd.view(-1, D, 10))
         gcw = gwb[:, :9].reshape(cw_shape).to(cw_dt)
         gcb = gwb[:, 9].to(cb_dt) if cb_dt is not None else None
         return (gxz, gcw, gcb, gwx, gW.to(wdt_dt), gA.to(a_dt), gD.to(d_dt), gdb.to(db_dt), gsum[0].to(ga_dt), gsum[1].to(be_dt), None, None,
@@ -1298,7 +1376,7 @@ class _LayerNorm(torch.autograd.Function):
         gx = torch.empty_like(x)
         part = torch.empty(_lib.lib().tamtr_ln_gate_blocks(ntok), 2, D, device=x.device, dtype=torch.float32)
         call('tamtr_layernorm_bwd', ptr(gout), ptr(x), ptr(g32), ptr(stats), ptr(gx), ptr(part), ntok, D, dtype_code(x), stream_ptr())
-        gsum = part.sum(0)
+        gsum = slab_sum(part)
         return gx, gsum[0].to(ctx.cfg[0]), gsum[1].to(ctx.cfg[1]), None
 
 

@@ -82,6 +82,21 @@ def use_deterministic_convolutions(search=False):
     return 'deterministic (MIOpen heuristic restricted to deterministic solvers)'
 
 
+def _no_naive_solvers():
+    """MIOpen's "naive" reference convolutions (ConvDirectNaiveConv{Fwd,Bwd,Wrw}: one thread per output element, double accumulation) are
+    applicable to every problem, so a timed search TIMES them for every convolution it looks at - 0.3 ... 690 ms per call, 66 s of GPU
+    time before the first step of a 640 px / 16 image run (profiles/r03_bench_kernel_stats.csv rows 1-4: 368 calls each of the fwd /
+    bwd / wrw kernels), find-db hit or not.  They never win, so the search modes take them out of the candidate list (MIOpen reads the
+    switches on its first use of them: call before the first convolution; exported values win).  Measured (profiles/r04_startup.txt):
+    fp32 probe forward 29.9 -> 2.2 s, capture warm-up 47.4 -> 0.9 s, step time unchanged.  NOT done outside the search modes: MIOpen's
+    heuristic picks the naive kernels for fp32 NHWC maps, and the fp32 parity tests are pinned on their double-accumulated sums (with
+    the next-best fp32 solvers one class logit of 17 520 moves by 1.4e-3 relative, past the 1e-3 bound of
+    test_full_model_640_fp32_elementwise_with_the_oracles_choices); and the deterministic mode needs them (the only NHWC bf16 solvers
+    that qualify)."""
+    for d in ('FWD', 'BWD', 'WRW'):
+        os.environ.setdefault(f'MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_{d}', '0')
+
+
 def use_tuned_convolutions(mode='shipped', db_dir=None, log=None):
     """Call before the first convolution.  mode: 'shipped' - timed-search mode backed by the shipped tables if they match this
     MIOpen build, else MIOpen's default heuristic; 'search' - timed search into db_dir (slow first run; how the tables are made);
@@ -99,6 +114,7 @@ def use_tuned_convolutions(mode='shipped', db_dir=None, log=None):
         os.makedirs(db_dir, exist_ok=True)
         os.environ['MIOPEN_USER_DB_PATH'] = db_dir
         torch.backends.cudnn.benchmark = True
+        _no_naive_solvers()
         return f'search ({db_dir})'
     if mode != 'shipped':
         raise ValueError(mode)
@@ -108,6 +124,7 @@ def use_tuned_convolutions(mode='shipped', db_dir=None, log=None):
     _seed(work)
     os.environ['MIOPEN_USER_DB_PATH'] = work
     torch.backends.cudnn.benchmark = True
+    _no_naive_solvers()
     if log:
         log(f'convolutions: MIOpen timed search backed by the shipped tables (640 px / 16 images, 1280 px / 8 images) in {work}'
             f'{"" if persistent else " (temporary)"}; a shape outside them - a tail batch, the validation batch - is searched once (minutes) '

@@ -108,7 +108,7 @@ def _run(case, dtype, graph=False, forced=False):
     b = {k: dev(v) for k, v in case['batch'].items()}
     try:
         if graph:
-            model.capture_static_part(b['img'], b['txt_feats'])   # checks one replay against eager execution and leaves the model as it was
+            model.capture_static_part(b['img'], b['txt_feats'], verify='loose')   # (MIOpen's heuristic solvers here: eager itself is not reproducible - loose check) checks one replay against eager execution and leaves the model as it was
             assert model.static_part_check['ok'] and model.static_part_check['grads'] == 552, model.static_part_check
             used = model._static[0]
         torch.manual_seed(5)

@@ -148,7 +148,13 @@ def test_replay_key_includes_the_prompt_shape(pkg):
     model.autocast_dtype = torch.bfloat16
     B, S = 2, 256
     batch = {k: (dev(v) if k in ('img', 'txt_feats') else v) for k, v in _bench_batch(B, S, 3).items()}
-    model.capture_static_part(batch['img'], batch['txt_feats'])
+    try:     # the strict check first: with MIOpen's heuristic solvers eager execution is not reproducible at this size, and a capture whose
+        model.capture_static_part(batch['img'], batch['txt_feats'])   # check cannot decide anything must NOT be accepted silently
+    except RuntimeError as e:
+        assert 'inconclusive' in str(e) and model._static is None and not model.static_part_check['conclusive']
+    else:
+        assert model.static_part_check['conclusive']
+    model.capture_static_part(batch['img'], batch['txt_feats'], verify='loose')   # heuristic MIOpen solvers: eager is not reproducible here
     assert model.static_part_check['ok']
     gp = model._static[0]
     loss, _ = model(batch)
@@ -184,7 +190,7 @@ def test_capture_after_eager_steps_then_train(pkg):
         return out
     held = []
     first = run(model, 2, held)                      # eager steps on the default stream, graphs kept alive
-    model.capture_static_part(batch['img'], batch['txt_feats'])
+    model.capture_static_part(batch['img'], batch['txt_feats'], verify='loose')
     gp = model._static[0]
     assert gp.n_live == 552 and len(gp.params) == 582, (gp.n_live, len(gp.params))   # 30 parameters of the discarded gates get no gradient
     graphed = first + run(model, 6, held)

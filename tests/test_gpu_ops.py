@@ -715,6 +715,67 @@ def test_colsum_bias_gradient_kernel(M, N):
     assert err <= 1e-5 * float(x.double().abs().sum(0).max()), err       # fp32 accumulation over <= 264 rows per partial, then <= 2048 partials
 
 
+@pytest.mark.parametrize('shape,dt', [((1600, 256, 10), torch.float32), ((3200, 2, 512), torch.float32), ((16, 1024, 64), torch.float32),
+                                      ((64, 512, 2048), torch.float32), ((256, 80, 256), torch.bfloat16), ((33, 8), torch.float32),
+                                      ((2048, 512), torch.float32), ((1, 4, 4), torch.float32), ((400, 12), torch.bfloat16)])
+def test_slab_sum_is_the_ordered_row_sum(shape, dt):
+    """ops.slab_sum (tamtr_slab_sum_rows: the last stage of the package's two-stage reductions - LayerNorm / depthwise-conv partial rows,
+    the scan's per-image rows, split-K slices) against a float64 sum of the same values, at the shapes the step produces; the same bits
+    on a second call (fixed order, no atomics) and on operands at another address."""
+    import tamtr_amd.ops as ops
+    g = torch.Generator(device='cuda').manual_seed(sum(shape))
+    x = (torch.randn(*shape, device='cuda', generator=g) + 0.05).to(dt)
+    a, b = ops.slab_sum(x), ops.slab_sum(x.clone())
+    assert a.dtype == torch.float32 and a.shape == x.shape[1:] and torch.equal(a, b)
+    ref = x.double().sum(0)
+    err = float((a.double() - ref).abs().max())
+    assert err <= 2e-6 * float(x.double().abs().sum(0).max()) + 1e-30, err
+
+
+@pytest.mark.parametrize('B,C1,C2,H,W,dt,sliced', [(16, 256, 128, 40, 40, torch.bfloat16, False), (4, 64, 64, 80, 80, torch.bfloat16, True),
+                                                   (2, 32, 32, 13, 21, torch.float32, False), (2, 1536, 512, 20, 20, torch.bfloat16, False),
+                                                   (3, 128, 256, 20, 20, torch.float32, True)])
+def test_conv1x1_weight_gradient_off_the_library(ops, B, C1, C2, H, W, dt, sliced):
+    """ops.conv2d_module on the trunk's 1x1 convolutions (nn/modules/conv.py:23-40 with k = 1): forward and d/d(input) are the library's,
+    the weight gradient is the row-sliced product + ordered slab sum (no memset node, no atomics).  Against plain nn.Conv2d autograd on
+    the same operands (fp32 reference of the same bf16 values for the weight gradient); packed input and a channel slice of a wider map;
+    the same bits on a second backward."""
+    import torch.nn as nn
+    torch.manual_seed(C1 + H)
+    conv = nn.Conv2d(C1, C2, 1, bias=False).cuda()
+    wide = (rnd((B, (2 if sliced else 1) * C1, H, W), 1)).to(dt).cuda().contiguous(memory_format=torch.channels_last)
+    x0 = wide.chunk(2, 1)[1] if sliced else wide
+    cot = rnd((B, C2, H, W), 2).to(dt).cuda().contiguous(memory_format=torch.channels_last)
+    w = conv.weight.detach().to(dt)
+
+    def run(fn):
+        x, wl = x0.detach().clone(memory_format=torch.preserve_format).requires_grad_(), w.clone().requires_grad_()
+        if sliced:   # keep the slice geometry: a view of a leaf
+            leaf = wide.detach().clone(memory_format=torch.preserve_format).requires_grad_()
+            x = leaf.chunk(2, 1)[1]
+        y = fn(x, wl)
+        gx, gw = torch.autograd.grad(y, [leaf if sliced else x, wl], cot)
+        return y.detach(), gx, gw
+
+    class _M:   # conv2d_module reads the module's attributes and weight
+        pass
+    def own(x, wl):
+        m = nn.Conv2d(C1, C2, 1, bias=False).cuda()
+        m.weight = nn.Parameter(wl.detach())
+        assert ops.conv1x1_cl_ok(x, m)
+        return ops._Conv1x1CL.apply(x, wl)
+    y, gx, gw = run(own)
+    y2, gx2, gw2 = run(own)
+    yr, gxr, gwr = run(lambda x, wl: torch.nn.functional.conv2d(x, wl))
+    assert torch.equal(y, yr) and torch.equal(gw, gw2) and torch.equal(gx, gx2)
+    assert_close(gx.float(), gxr.float(), 2e-2 if dt == torch.bfloat16 else 1e-4, (2e-2 if dt == torch.bfloat16 else 1e-4) * float(gxr.float().abs().max()), 'dX')
+    ref = torch.einsum('bohw,bihw->oi', cot.double(), x0.double()).view(C2, C1, 1, 1)      # exact dW of the same (rounded) operands
+    tol = 1e-2 if dt == torch.bfloat16 else 2e-4                                            # own: fp32 sums rounded once to the weight's dtype
+    assert_close(gw.double(), ref, tol, tol * float(ref.abs().max()), 'dW')
+    err_own, err_lib = float((gw.double() - ref).norm() / ref.norm()), float((gwr.double() - ref).norm() / ref.norm())
+    assert err_own <= 1.5 * err_lib + 1e-6, (err_own, err_lib)                              # no worse than the library's own weight gradient
+
+
 # ------------------------------------------------------------------------------------------------ next-3: proj_conv on MFMA
 @pytest.mark.parametrize('B,C,H,W,sliced', [(2, 64, 160, 160, True), (2, 128, 80, 80, True), (2, 256, 40, 40, True),
                                             (1, 64, 13, 21, False), (3, 128, 8, 16, False), (1, 64, 320, 320, True)])

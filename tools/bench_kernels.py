@@ -88,6 +88,29 @@ def bench_gate():
             print(f'gate C={C} {H}x{H} {str(dt)[6:]}: {a * 1e3:.0f} us, {byt / a / 1e6:.0f} GB/s (x + v + out)')
 
 
+def bench_gatecl():
+    """The form bench.py runs at the five TIAGELAN sites (three shapes): channels-last forward-only gate, e = a channel slice of the cv1
+    output, v = the RAW proj_conv output with its BatchNorm applied in the load (ops.maxsigmoid_gate_cl); next to it the NCHW kernel on
+    packed planes of the same sizes.  Algorithmic bytes: e + v + out."""
+    import torch.nn as nn
+    big = os.environ.get('TAMTR_BENCH_PX') == '1280'
+    for (C, nh, H) in ([(256, 8, 80), (128, 4, 160), (64, 2, 320)] if big else [(256, 8, 40), (128, 4, 80), (64, 2, 160)]):
+        B = 8 if big else 16
+        wide = torch.randn(B, 2 * C, H, H, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last)
+        e = wide.chunk(2, 1)[1]
+        v = torch.randn(B, C, H, H, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last)
+        gk = torch.randn(B, 10, C, device='cuda')
+        bias = torch.zeros(nh, device='cuda')
+        bn = nn.BatchNorm2d(C, eps=1e-3, momentum=0.03).cuda().train()
+        st = torch.stack([torch.randn(C, device='cuda') * 0.1, torch.rand(C, device='cuda') + 0.5], 1).contiguous()
+        a, mn = timeit(lambda: ops.maxsigmoid_gate_cl(e, gk, bias, v, st, bn, nh), n=20, warm=3)
+        xn, vn = e.contiguous(), v.contiguous()
+        a2, mn2 = timeit(lambda: ops.maxsigmoid_gate(xn, gk, bias, vn, nh), n=20, warm=3)
+        byt = 3 * v.numel() * 2
+        print(f'gate_cl C={C} {H}x{H} x{B} bf16: {a * 1e3:.1f} us avg / {mn * 1e3:.1f} min, {byt / mn / 1e6:.0f} GB/s (e + v + out = {byt / 1e6:.0f} MB); '
+              f'NCHW gate_fwd on packed planes {a2 * 1e3:.1f} us avg / {mn2 * 1e3:.1f} min')
+
+
 def bench_msda():
     B, Q, M, D = 16, 292, 8, 64
     shapes = [(160, 160), (80, 80), (40, 40)]
@@ -186,6 +209,6 @@ def bench_projconv():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['all']
-    for name in ('scan', 'gemm', 'gate', 'msda', 'attn', 'cpam', 'dwconv', 'lsap', 'projconv'):
+    for name in ('scan', 'gemm', 'gate', 'gatecl', 'msda', 'attn', 'cpam', 'dwconv', 'lsap', 'projconv'):
         if name in which or 'all' in which:
             globals()['bench_' + name]()

@@ -27,6 +27,9 @@ B, S = int(os.environ.get('BS', 16)), int(os.environ.get('IMG', 640))
 REPLAYS = int(os.environ.get('REPLAYS', 4))
 if blas != 'default':
     torch.backends.cuda.preferred_blas_library(blas)
+if os.environ.get('TUNED', '1') == '1':      # the shipped convolution tables: eager run-to-run noise 3e-3 instead of ~1 (MIOpen heuristic)
+    from tamtr_amd.tuning import use_tuned_convolutions
+    use_tuned_convolutions('shipped')
 torch.manual_seed(0)
 model = RTDETRDetectionWorldModel(nc=10).cuda().train()
 model.autocast_dtype = torch.bfloat16
@@ -127,7 +130,7 @@ for rep in range(REPLAYS):
         if r is None:
             continue
         d = float((gp.static_grads[i].float() - r).norm() / r.norm().clamp_min(1e-30))
-        if not d < 1e-2:
+        if not d < float(os.environ.get('OFF_TOL', '1e-2')):
             bad.setdefault(gp.names[i], []).append(d)
 gp._restore_buffers(saved)
 flags = {k: v for k, v in os.environ.items() if k.startswith(('DEBUG_', 'HIP_FORCE', 'AMD_SERIALIZE', 'GPU_', 'ROC_', 'TAMTR_'))}

@@ -74,3 +74,59 @@ for rep in range(4):
     errs.append(float((z - a).abs().max()))
 res['zeros_then_add_max_err'] = errs
 print(json.dumps(res), flush=True)
+
+# 4. memset nodes on REUSED pool memory (what a recorded training step is made of): is a memset node ordered against the kernels
+#    before and after it?  Chain per link: kernel writes ones into a block -> block freed -> same block re-allocated -> memset to zero
+#    -> kernel adds 1 in place -> result copied out.  Right answer: every element 1.  A memset executed before the ones-kernel of its
+#    own link (or not at all) leaves 2; one executed after the add leaves 0.
+N, LINKS = 1 << 18, 40
+outs = torch.empty(LINKS, N, device=dev)
+
+
+def chain():
+    ptrs = set()
+    for i in range(LINKS):
+        a = torch.empty(N, device=dev)
+        a.fill_(1.0)                 # kernel
+        ptrs.add(a.data_ptr())
+        del a
+        b = torch.empty(N, device=dev)
+        ptrs.add(b.data_ptr())
+        b.zero_()                    # memset node
+        b += 1.0                     # kernel
+        outs[i].copy_(b)             # kernel
+        del b
+    return len(ptrs)
+g, nptr = capture(chain)
+hist = []
+for rep in range(4):
+    outs.fill_(-7.0)
+    g.replay()
+    torch.cuda.synchronize()
+    vals, counts = torch.unique(outs, return_counts=True)
+    hist.append({str(float(v)): int(c) for v, c in zip(vals, counts)})
+res['reused_block_chain'] = {'distinct_blocks': nptr, 'links': LINKS, 'elements_per_link': N, 'value_histogram_per_replay': hist}
+
+# 5. the same with a torch global reduction in the chain (its semaphore memset lands on reused memory)
+x = torch.randn(8192, 512, device=dev)
+sums = torch.empty(LINKS, 512, device=dev)
+
+
+def chain2():
+    for i in range(LINKS):
+        a = torch.empty(1 << 16, device=dev)
+        a.fill_(3.0)                 # dirties the block the reduction's semaphores / staging buffer will get
+        del a
+        sums[i].copy_(x.sum(0))
+g, _ = capture(chain2)
+errs = []
+for rep in range(4):
+    x.copy_(torch.randn(8192, 512, device=dev))
+    sums.fill_(float('nan'))
+    g.replay()
+    torch.cuda.synchronize()
+    ref = x.double().sum(0)
+    e = (sums.double() - ref).norm(dim=1) / ref.norm()
+    errs.append({'links_off': int((~(e < 1e-5)).sum()), 'worst_rel': float(torch.nan_to_num(e, nan=1e30).max())})
+res['reduction_on_reused_blocks'] = errs
+print(json.dumps({k: res[k] for k in ('packet_capture', 'reused_block_chain', 'reduction_on_reused_blocks')}), flush=True)
