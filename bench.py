@@ -37,7 +37,6 @@ import os
 import sys
 import time
 
-os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')  # before the HIP runtime starts: see tam-tr_amd/graphs.py
 
 import torch
 
@@ -223,6 +222,8 @@ def main():
                          'tam-tr_amd/tuned/miopen (default), a fresh search (minutes), or its heuristic')
     ap.add_argument('--conv-db', default=None, help='directory the search writes its tables to (--conv-tuning search)')
     ap.add_argument('--grad-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire (N > 1)')
+    ap.add_argument('--optim-step', default='fused', choices=['fused', 'torch'],
+                    help='clip + AdamW + EMA as the table-driven kernels of csrc/optim.hip (engine.FusedOptimStep) or as the three torch calls')
     ap.add_argument('--no-graph-check', action='store_true', help='skip the graph-vs-eager step after the timed loop (profiling runs: keeps the trace to the timed steps)')
     ap.add_argument('--cpu-baseline-images', type=int, default=8, help='images of the CPU-oracle sample (BASELINE configs[0]: 8)')
     args = ap.parse_args()
@@ -257,8 +258,10 @@ def main():
     model = RTDETRDetectionWorldModel(nc=10).to(dev).train()
     model.autocast_dtype = torch.bfloat16 if args.dtype == 'bf16' else None
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, betas=(0.9, 0.999), fused=True)
-    from tamtr_amd.engine import ModelEMA
+    from tamtr_amd.engine import FusedOptimStep, ModelEMA
     ema = ModelEMA(model)   # the reference's optimizer_step ends with ema.update(model) on every rank (trainer.py:259,478-479)
+    # clip_grad_norm_(0.1) + AdamW.step() + ema.update() as four launches over a device table (csrc/optim.hip); --optim-step torch: the three torch calls
+    stepper = FusedOptimStep.create(model, opt, ema, max_norm=0.1) if args.optim_step == 'fused' else None
     reducer = None
     if world > 1:
         reducer = tdist.GradReducer(model.named_parameters(), skip=lambda n: '.attn.' in n, late=lambda n: 'denoising_class_embed' in n,
@@ -276,9 +279,12 @@ def main():
         loss.backward()
         if reducer is not None:
             reducer.finish()
-        torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], max_norm=0.1)
-        opt.step()
-        ema.update(model)
+        if stepper is not None:
+            stepper.step()
+        else:
+            torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], max_norm=0.1)
+            opt.step()
+            ema.update(model)
         return loss
 
     def fence():
@@ -368,7 +374,7 @@ def main():
                        'global_batch': world * args.batch, 'parallelism': f'dp{world}', 'final_loss': float(loss.detach()),
                        'bf16_vs_fp32': mode_err, 'dist_backend': backend, 'dist_world_size': world,
                        'grad_bucket_dtype': (args.grad_dtype if world > 1 else None), 'static_part': static_part,
-                       'static_part_check': _brief(getattr(model, 'static_part_check', None)), 'graph_vs_eager': gve, 'conv_tuning': conv_tuning,
+                       'optim_step': 'fused (csrc/optim.hip)' if stepper is not None else 'torch', 'static_part_check': _brief(getattr(model, 'static_part_check', None)), 'graph_vs_eager': gve, 'conv_tuning': conv_tuning,
                        'hbm_GiB_peak': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
             'roofline': None if ks is None else {
                 'bound': 'mfma', 'kernel': 'linear_bf16_wstat_kernel<512> (MEH value_proj x3 + enc_output and their dX, M=%d N=K=512)'

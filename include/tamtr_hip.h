@@ -421,6 +421,27 @@ int tamtr_maxpool_bwd(const void* gy, const uint8_t* code, const void* addend, v
 int tamtr_img_augment_u8(const uint8_t* src, const double* inv_affine, const uint8_t* luts, const int32_t* flags, float* out, int B,
                          int SH, int SW, int H, int W, int border, void* stream);
 
+/*      The reference's optimizer_step (ultralytics/engine/trainer.py:471-479): clip_grad_norm_(max_norm) -> AdamW.step() ->
+ *      ModelEMA.update (utils/torch_utils.py:392-419), over a device table of tensors built once by the caller; torch's FusedAdamKernel
+ *      arithmetic in fp32.  All table arrays are DEVICE arrays with one entry per tensor unless noted:
+ *        p, m, v, e   addresses of the values, exp_avg, exp_avg_sq and EMA copy (m[i] == 0: EMA-only entry, e.g. BatchNorm statistics;
+ *                     e[i] == 0: no EMA), all f32 with the element order of p;  step f32: Adam step counts (advanced for tensors that have a
+ *                     gradient);  numel i64;  group u8: parameter group;  chunk_tensor i32 / chunk_off i64 [nchunks]: the tensors cut into
+ *                     pieces of tamtr_optim_chunk() elements;  grads: THIS step's gradient addresses (0: none - Adam skipped, EMA still taken).
+ *        partial f32 [nchunks], normcoef f32 [2] workspaces; normcoef = {total gradient norm, clip coefficient} afterwards (device side:
+ *                     nothing is read back).  lr, wd: HOST arrays [ngroups <= 4].  max_norm <= 0: no clipping.  do_ema == 0: EMA untouched.
+ *      The clipped gradient is written back to the gradient buffers, as clip_grad_norm_ leaves it. */
+int tamtr_optim_chunk(void);
+int tamtr_optim_step(const void* const* p, const void* const* m, const void* const* v, const void* const* e, float* step, const long long* numel,
+                     const unsigned char* group, const int* chunk_tensor, const long long* chunk_off, const void* const* grads, int ntensors,
+                     int nchunks, float* partial, float* normcoef, const float* lr, const float* wd, int ngroups, float beta1, float beta2, float eps,
+                     float max_norm, float ema_decay, int do_ema, void* stream);
+
+/*      Node census of the graph that `stream` is capturing into (hipStreamGetCaptureInfo_v2 + hipGraphGetNodes): counts[t] = nodes of
+ *      hipGraphNodeType t, t < n_types <= 16 (0 kernel, 1 memcpy, 2 memset, ...).  Host-side helper of the HIP-graph replay
+ *      (tam-tr_amd/graphs.py: memset nodes do not survive AQL packet capture); TAMTR_EINVAL when the stream is not capturing. */
+int tamtr_graph_capture_census(void* stream, int* counts, int n_types);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,12 +12,6 @@ import os
 if os.environ.get('TAMTR_CHANNELS_LAST', '1') != '0':
     os.environ.setdefault('PYTORCH_MIOPEN_SUGGEST_NHWC', '1')
 
-# HIP graphs (graphs.py): with the runtime's AQL-packet capture of graph nodes, replays of the recorded backward intermittently
-# produced garbage gradients on ROCm 7.2 (tools/try_graph.py bisect; clean with the switch off).  Read when the HIP runtime starts.
-import sys
-
-_hip_may_be_up = 'torch' in sys.modules and sys.modules['torch'].cuda.is_initialized()
-GRAPH_REPLAY_SAFE = os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') == '0' or not _hip_may_be_up
-os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+# (HIP graphs, graphs.py: the runtime's AQL packet capture stays at its default - on - since round 4; the recorded part holds no memset node)
 
 from ._lib import LIB_PATH, TamtrHipError  # noqa: F401

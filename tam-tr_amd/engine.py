@@ -110,6 +110,131 @@ class ModelEMA:
         torch._foreach_add_(dst, src, alpha=1 - d)
 
 
+class FusedOptimStep:
+    """The reference's optimizer_step (ultralytics/engine/trainer.py:471-479): clip_grad_norm_(max_norm) -> optimizer.step() ->
+    ema.update(model), for torch.optim.AdamW on the GPU, as four kernel launches over a device table that is built once
+    (csrc/optim.hip tamtr_optim_step).  torch spends 9.4 ms of host time per step on the same work (grouping ~750 tensors into lists for
+    its multi-tensor kernels, three times over: profiles/r04_host_phases.txt), and the host is this step's critical path.
+
+    The optimizer object stays the owner of its state: `optimizer.state[p]` holds exp_avg / exp_avg_sq / step tensors as torch.optim.AdamW
+    would have created them (state_dict() / load_state_dict() work; the step counts are 0-d views of one flat tensor), `param_groups`
+    is read every step (warm-up and schedules change lr), the EMA object keeps its `updates` counter and decay ramp.
+    Same arithmetic as torch's fused AdamW kernel and as ModelEMA.update (fp32); the gradient norm stays on the device.
+
+        stepper = FusedOptimStep.create(model, optimizer, ema, max_norm=0.1)     # None when the combination is not served
+        ...backward...;  stepper.step()        # instead of clip_grad_norm_ + optimizer.step() + ema.update(model)
+    """
+
+    @staticmethod
+    def create(model, optimizer, ema=None, max_norm=0.1):
+        ps = [p for g in optimizer.param_groups for p in g['params']]
+        ok = (type(optimizer) is torch.optim.AdamW and len(optimizer.param_groups) <= 4 and ps
+              and all(p.is_cuda and p.dtype == torch.float32 and (p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)) for p in ps)
+              and not any(g.get('amsgrad') or g.get('maximize') or g.get('capturable') or g.get('differentiable') for g in optimizer.param_groups))
+        return FusedOptimStep(model, optimizer, ema, max_norm) if ok else None
+
+    def __init__(self, model, optimizer, ema=None, max_norm=0.1):
+        self.model, self.opt, self.ema, self.max_norm = model, optimizer, ema, float(max_norm)
+        self._key = None
+
+    def _state_key(self):
+        first = self.opt.param_groups[0]['params'][0]
+        st = self.opt.state.get(first, {})
+        e = None if self.ema is None else next(self.ema.ema.parameters()).data_ptr()
+        return (first.data_ptr(), st['exp_avg'].data_ptr() if 'exp_avg' in st else 0, e, sum(len(g['params']) for g in self.opt.param_groups))
+
+    @torch.no_grad()
+    def _build(self):
+        from . import _lib
+        dev = self.opt.param_groups[0]['params'][0].device
+        entries = []                                   # (tensor, group, has_adam)
+        for gi, g in enumerate(self.opt.param_groups):
+            entries += [(p, gi, True) for p in g['params']]
+        opt_ptrs = {p.data_ptr() for p, _, _ in entries}
+        ema_of = {}
+        if self.ema is not None:
+            msd, esd = self.model.state_dict(), self.ema.ema.state_dict()
+            by_ptr = {v.data_ptr(): k for k, v in msd.items() if v.dtype.is_floating_point}
+            for p, _, _ in entries:
+                k = by_ptr.get(p.data_ptr())
+                if k is not None:
+                    ema_of[id(p)] = esd[k]
+            for k, v in msd.items():   # floating-point buffers (BatchNorm statistics) and parameters outside the optimizer: EMA only
+                if v.dtype.is_floating_point and v.is_cuda and v.data_ptr() not in opt_ptrs:
+                    entries.append((v, 0, False))
+                    ema_of[id(v)] = esd[k]
+        n = len(entries)
+        steps = torch.zeros(n, device=dev, dtype=torch.float32)
+        P, M, V, E, numel, group = [], [], [], [], [], []
+        for i, (t, gi, adam) in enumerate(entries):
+            m = v = None
+            if adam:
+                st = self.opt.state[t]
+                if 'exp_avg' not in st:               # what torch.optim.AdamW._init_group creates on its first step
+                    st['exp_avg'] = torch.zeros_like(t, memory_format=torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(t, memory_format=torch.preserve_format)
+                elif 'step' in st:
+                    steps[i] = float(st['step'])
+                st['step'] = steps[i]                 # 0-d view: state_dict() / load_state_dict() see an ordinary step tensor
+                m, v = st['exp_avg'], st['exp_avg_sq']
+                if m.stride() != t.stride() or v.stride() != t.stride():
+                    raise ValueError('FusedOptimStep: optimizer state with other strides than its parameter')
+            e = ema_of.get(id(t))
+            if e is not None and (e.stride() != t.stride() or e.dtype != torch.float32):
+                raise ValueError('FusedOptimStep: EMA copy with another layout than the model tensor')
+            P.append(t.data_ptr()); M.append(m.data_ptr() if m is not None else 0); V.append(v.data_ptr() if v is not None else 0)
+            E.append(e.data_ptr() if e is not None else 0); numel.append(t.numel()); group.append(gi)
+        chunk = _lib.lib().tamtr_optim_chunk()
+        ct, co = [], []
+        for i, nel in enumerate(numel):
+            for off in range(0, nel, chunk):
+                ct.append(i); co.append(off)
+        I64 = lambda x: torch.tensor(x, dtype=torch.int64, device=dev)   # noqa: E731
+        self.tab = {'p': I64(P), 'm': I64(M), 'v': I64(V), 'e': I64(E), 'numel': I64(numel), 'group': torch.tensor(group, dtype=torch.uint8, device=dev),
+                    'ct': torch.tensor(ct, dtype=torch.int32, device=dev), 'co': I64(co), 'step': steps,
+                    'partial': torch.empty(len(ct), device=dev, dtype=torch.float32), 'norm': torch.zeros(2, device=dev, dtype=torch.float32)}
+        self.entries, self.n, self.nchunks, self.dev = entries, n, len(ct), dev
+        self.strides = [t.stride() for t, _, _ in entries]
+        self.adam = [a for _, _, a in entries]
+        self._key = self._state_key()
+
+    @torch.no_grad()
+    def step(self):
+        """clip + AdamW + EMA on the current stream; returns the device tensor [grad norm, clip coefficient] (no host read-back)."""
+        import ctypes
+        from . import _lib
+        from .hostio import stager
+        if self._key is None or self._key != self._state_key():   # first step, or state / EMA tensors were replaced (load_state_dict)
+            self._build()
+        ptrs = [0] * self.n
+        for i, (t, _, adam) in enumerate(self.entries):
+            if adam:
+                g = t.grad
+                if g is not None:
+                    if g.stride() != self.strides[i] or g.dtype != torch.float32:   # (never on this path: AccumulateGrad keeps the parameter's layout)
+                        g = torch.empty_like(t, memory_format=torch.preserve_format).copy_(g)
+                        t.grad = g
+                    ptrs[i] = g.data_ptr()
+        gptr = stager().h2d(torch.tensor(ptrs, dtype=torch.int64), self.dev)
+        groups = self.opt.param_groups
+        ng = len(groups)
+        lr = (ctypes.c_float * ng)(*[float(g['lr']) for g in groups])
+        wd = (ctypes.c_float * ng)(*[float(g['weight_decay']) for g in groups])
+        b1, b2 = groups[0]['betas']
+        if any(g['betas'] != groups[0]['betas'] or g['eps'] != groups[0]['eps'] for g in groups):
+            raise ValueError('FusedOptimStep: parameter groups must share betas and eps')
+        do_ema, d = 0, 0.0
+        if self.ema is not None and self.ema.enabled:
+            self.ema.updates += 1
+            do_ema, d = 1, self.ema.decay(self.ema.updates)
+        T = self.tab
+        P = _lib.ptr
+        _lib.call('tamtr_optim_step', P(T['p']), P(T['m']), P(T['v']), P(T['e']), P(T['step']), P(T['numel']), P(T['group']), P(T['ct']), P(T['co']),
+                  P(gptr), self.n, self.nchunks, P(T['partial']), P(T['norm']), ctypes.cast(lr, ctypes.c_void_p), ctypes.cast(wd, ctypes.c_void_p), ng,
+                  float(b1), float(b2), float(groups[0]['eps']), self.max_norm, float(d), do_ema, _lib.stream_ptr())
+        return T['norm']
+
+
 def train_step(model, batch, optimizer, ema=None, max_norm=0.1):
     """One optimisation step as the reference trainer runs it for RT-DETR models (bf16 autocast replaces the fp16 scaler)."""
     loss, items = model(batch)
@@ -119,7 +244,7 @@ def train_step(model, batch, optimizer, ema=None, max_norm=0.1):
     optimizer.zero_grad(set_to_none=True)
     if ema is not None:
         ema.update(model)
-    return loss.detach(), items
+    return loss.detach(), items   # (the three torch calls; engine.fit and bench.py run them as FusedOptimStep on the GPU)
 
 
 # ------------------------------------------------------------------------------------------------ validation side
@@ -347,6 +472,8 @@ def fit(model, train_loader, prepare, epochs, val_loader=None, lr0=1e-4, lrf=1.0
     lf = linear_lr(epochs, lrf)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lf)
     ema = ModelEMA(model) if rank == 0 else None
+    # clip + optimizer step + EMA as one table-driven launch group when the combination is served (AdamW, fp32 parameters on the GPU)
+    stepper = FusedOptimStep.create(model, opt, ema, max_norm=0.1)
     history, best, steps, start = [], None, 0, 0
     if resume is not None:
         start = int(resume.get('epoch', -1)) + 1
@@ -401,11 +528,14 @@ def fit(model, train_loader, prepare, epochs, val_loader=None, lr0=1e-4, lrf=1.0
             loss.backward()
             if reducer is not None:
                 reducer.finish()
-            torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], max_norm=0.1)
-            opt.step()
+            if stepper is not None:  # clip + AdamW + EMA in four launches (csrc/optim.hip)
+                stepper.step()
+            else:
+                torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], max_norm=0.1)
+                opt.step()
             if reducer is None:      # (the reducer's gradients are views of its flat buckets, zeroed by prepare())
                 opt.zero_grad(set_to_none=True)
-            if ema is not None:
+            if ema is not None and stepper is None:
                 ema.update(model)
             mean_items = items.detach() if mean_items is None else (mean_items * i + items.detach()) / (i + 1)   # no host sync
             steps += 1

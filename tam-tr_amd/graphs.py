@@ -8,19 +8,45 @@ Here the recorded function runs on detached aliases of the parameters (same stor
 stream), warm-up and both captures use ONE side stream, and the real parameters only appear as inputs of the replaying
 autograd node - nothing recorded ever touches an existing autograd graph or the default stream.
 
-Runtime switch: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (set by the package __init__ before HIP starts).  With ROCm 7.2's packet capture
-of graph nodes on, replays of the recorded backward intermittently returned garbage / NaN gradients (VSS blocks + projection,
-deterministic in eager mode: replay 4 of 5 wrong; 12 of 12 identical to eager with the switch off; a plain memset / reduce chain
-replays correctly either way).  Without it hipGraphLaunch enqueues node by node (the host is busy ~100 ms per step inside the two
-launches) but the GPU never waits: the step runs at its kernel time.
+AQL packet capture (ROCm 7.2's default way of launching a graph: every kernel node's dispatch packet is built once and the replay
+only rings the doorbell - hipGraphLaunch of the ~1 700-node forward graph costs the host 1 ms instead of 19, profiles/r04_host_phases.txt).
+Rounds 2 - 3 ran with it switched OFF (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0) because replays of the recorded backward returned garbage
+gradients.  Round 4 found what breaks (profiles/r04_packet_capture_bisect.txt): MEMSET NODES.  A hipMemsetAsync recorded into a
+graph is not kept in order with the kernel nodes around it once the packets are pre-built; every node that is a kernel replays exactly.
+Two things put memset nodes into this recording: torch's multi-workgroup reductions (`partials.sum(0)`: Reduce.cuh zeroes its arrival
+semaphores with cudaMemsetAsync before every launch and never resets them - the first replay finds fresh zeros, every later one a
+stale count, and the output is never written) and MIOpen's weight-gradient / input-gradient solvers for 1x1 convolutions (memset +
+atomic adds).  Neither the library GEMMs (rocBLAS and hipBLASLt replay correctly: the round-3 diagnosis was wrong) nor any kernel of
+this package was involved.  The recorded part therefore contains no memset node any more - ordered slab sums (ops.slab_sum) instead of
+torch reductions, the 1x1 convolutions' backward as GEMMs (ops._Conv1x1CL) - and packet capture stays ON.  GraphedPart checks this: it
+counts the memset nodes of both graphs (hipGraphGetNodes on the capturing stream's graph) and refuses to build with any of them while packet capture is on, and
+verify() replays three times (the corruption only shows from the second replay on).  DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, exported before
+the HIP runtime starts, restores node-by-node launches, under which memset nodes are harmless.
 """
 import os
 
 import torch
 
 
-# torch.version.hip prefixes the replay path (packet capture off + GraphedPart.verify) was exercised on
+# torch.version.hip prefixes the replay path (GraphedPart.verify, packet capture on and off) was exercised on
 VALIDATED_HIP = ('7.0', '7.2')
+
+
+def packet_capture_on():
+    """The HIP runtime launches graphs from pre-built AQL packets (its default) unless DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was in the
+    environment when it started."""
+    return os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '1') != '0'
+
+
+def capture_census(stream):
+    """Nodes by type of the graph `stream` is capturing into right now: {'kernel': n, 'memcpy': n, 'memset': n, 'other': n}
+    (csrc/capi.hip tamtr_graph_capture_census).  Call inside the capture, after the last recorded op."""
+    import ctypes
+    from . import _lib
+    counts = (ctypes.c_int * 16)()
+    _lib.call('tamtr_graph_capture_census', ctypes.c_void_p(stream.cuda_stream), ctypes.cast(counts, ctypes.c_void_p), 16)
+    c = list(counts)
+    return {'kernel': c[0], 'memcpy': c[1], 'memset': c[2], 'other': sum(c[3:])}
 
 
 class GraphedPart:
@@ -33,10 +59,6 @@ class GraphedPart:
     def __init__(self, module, sample_args, warmup=3, log=None):
         if not all(isinstance(a, torch.Tensor) and a.is_cuda for a in sample_args):
             raise ValueError('sample_args must be CUDA tensors')
-        from . import GRAPH_REPLAY_SAFE
-        if (os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') != '0' or not GRAPH_REPLAY_SAFE) and os.environ.get('TAMTR_GRAPH_TIMING_ONLY') != '1':
-            # (TAMTR_GRAPH_TIMING_ONLY=1: timing experiments with the runtime's packet capture on - gradients may be garbage)
-            raise RuntimeError('GraphedPart needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before the HIP runtime starts (see the module docstring)')
         self.module = module
         self.names, self.params = zip(*[(n, p) for n, p in module.named_parameters()])
         alias = {n: torch.nn.Parameter(p.detach(), requires_grad=p.requires_grad) for n, p in zip(self.names, self.params)}  # same storage
@@ -62,10 +84,20 @@ class GraphedPart:
         t1 = time.perf_counter()
         with torch.cuda.graph(self.fwd, pool=pool, stream=self.stream):
             self.static_out = run()
+            census_f = capture_census(self.stream)
         self.static_gout = torch.zeros_like(self.static_out)
         leaves = [alias[n] for n in self.names if alias[n].requires_grad]
         with torch.cuda.graph(self.bwd, pool=pool, stream=self.stream):
             grads = torch.autograd.grad(self.static_out, leaves, self.static_gout, allow_unused=True)
+            census_b = capture_census(self.stream)
+        self.census = {'forward': census_f, 'backward': census_b}
+        self.memset_nodes = (census_f['memset'], census_b['memset'])
+        self.packet_capture = packet_capture_on()
+        if self.packet_capture and any(self.memset_nodes):
+            raise RuntimeError(f'GraphedPart: the recorded graphs contain memset nodes (forward {self.memset_nodes[0]}, backward {self.memset_nodes[1]}), which '
+                               'do not replay in order under the HIP runtime\'s AQL packet capture (see the module docstring): something in the recorded '
+                               'function zero-fills with hipMemsetAsync - torch.zeros / zero_(), a multi-workgroup torch reduction, a library solver.  '
+                               'Remove it, or export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the HIP runtime starts')
         if log is not None:
             log(f'graph capture: {warmup} warm-up passes (kernel selection / compilation) {t1 - t0:.1f} s, recording forward + backward {time.perf_counter() - t1:.1f} s')
         it = iter(grads)
@@ -106,7 +138,7 @@ class GraphedPart:
         for b, v in zip(self.module.buffers(), saved):
             b.copy_(v)
 
-    def verify(self, replays=1, tol=2e-2, noise_factor=6.0, junk_between=True):
+    def verify(self, replays=3, tol=2e-2, noise_factor=6.0, junk_between=True):
         """Replay the two recorded graphs on the capture inputs and hold them to an EAGER forward + backward of the same module on the
         same inputs and the same cotangent: the output and every live parameter gradient.  The eager pass runs twice, so every figure
         comes with the eager run-to-run level of the same quantity next to it: with MIOpen's split-K / atomic solvers the trunk is not

@@ -49,6 +49,7 @@ class ManbaWorldDecoder(nn.Module):
         # teacher forcing of the one discrete choice of the head (parity measurements): a LongTensor [B, nq] of anchor positions used
         # INSTEAD of torch.topk's picks in _get_decoder_input; None (always, outside tests) = the reference's top-k (head.py:1237)
         self.fixed_topk = None
+        self.last_topk = None
         self._reset_parameters()
 
     def forward(self, x, text, batch=None):
@@ -147,6 +148,7 @@ class ManbaWorldDecoder(nn.Module):
         memory = VSSBlock._ln(norm, y)  # LayerNorm kernel in the activation dtype
         scores = self.enc_score_head(memory)
         top = torch.topk(scores.max(-1).values, self.num_queries, dim=1).indices if self.fixed_topk is None else self.fixed_topk.to(feats.device)
+        self.last_topk = top.detach()   # this forward's picks (parity measurements replay them through fixed_topk)
         bi = torch.arange(bs, device=feats.device).unsqueeze(-1)
         top_feat = memory[bi, top]
         refer = self.enc_bbox_head(top_feat).float() + anchors[0][top]

@@ -214,6 +214,7 @@ class DETRLoss(nn.Module):
         # teacher forcing of the Hungarian assignment (parity measurements): per stacked layer [enc, dec 0..n-1] a list of per-image
         # (query_idx, gt_idx) pairs used INSTEAD of the matcher's; None (always, outside tests) = the matcher (loss.py:282-326)
         self.fixed_matches = None
+        self.last_matches = None
 
     def _layers(self, pb, ps, gt_bboxes, gt_cls, gt_groups, match):
         """(class, bbox, giou) of ALL decoder layers at once: pb [layers, bs, nq, 4], ps [layers, bs, nq, nc] -> three [layers]
@@ -223,9 +224,10 @@ class DETRLoss(nn.Module):
         Lr, bs, nq = pb.shape[:3]
         if match is None and self.fixed_matches is not None:
             assert len(self.fixed_matches) == Lr, (len(self.fixed_matches), Lr)
-            flats = [flat_matches(Matches(m), dev) for m in self.fixed_matches]
+            flats = [flat_matches(m if isinstance(m, Matches) else Matches(m), dev) for m in self.fixed_matches]
         elif match is None:
-            flats = [flat_matches(m, dev) for m in self.matcher(pb, ps, gt_bboxes, gt_cls, gt_groups)]
+            self.last_matches = ms = self.matcher(pb, ps, gt_bboxes, gt_cls, gt_groups)   # (kept: parity measurements replay them through fixed_matches)
+            flats = [flat_matches(m, dev) for m in ms]
         else:
             flats = [flat_matches(match, dev)] * Lr
         n = int(flats[0][0].shape[0])  # matched pairs per layer (every layer matches all boxes: the same count)

@@ -597,6 +597,8 @@ def colsum(g2):
         part = torch.empty(nblk, N, device=g2.device, dtype=torch.float32)
         call('tamtr_colsum_bf16', ptr(g2), ptr(part), M, N, stream_ptr())
         return slab_sum(part)
+    if g2.is_cuda and g2.dtype in (torch.float32, torch.bfloat16) and N % 4 == 0:
+        return slab_sum(_c(g2))   # short or fp32 matrices: the ordered row sum directly (no torch reduction: see slab_sum)
     return g2.sum(0, dtype=torch.float32)
 
 
@@ -713,12 +715,12 @@ def linear_bf16(x, weight, bias=None):
 # ------------------------------------------------------------------------------------------------ trunk: 1x1 convolutions' weight gradient
 class _Conv1x1CL(torch.autograd.Function):
     """y = conv2d(x, w) for a 1x1 / stride 1 / ungrouped convolution on a channels-last map, with the WEIGHT gradient taken off MIOpen.
-    Forward and d/d(input) stay on the library (tuned tables).  MIOpen's weight-gradient solvers for these shapes split the reduction over
-    the B*H*W pixels across workgroups and add with atomics into a buffer they zero with hipMemsetAsync - a memset NODE in a recorded
+    The forward stays on the library (tuned tables).  MIOpen's weight-gradient solvers for these shapes (and, for some, its input-gradient
+    solvers) split the reduction across workgroups and add with atomics into a buffer they zero with hipMemsetAsync - a memset NODE in a recorded
     graph, the one node kind that does not replay in order under the HIP runtime's AQL packet capture (profiles/r04_packet_capture_bisect.txt:
-    inf / NaN weight gradients on exactly the trunk's 1x1 convolutions).  A 1x1 convolution IS a per-pixel linear map, so its weight
-    gradient is dW [C2, C1] = dY^T X over the pixels: the row-sliced batched product + ordered slab sum of the tall linears
-    (dw_splitk, slab_sum) - fp32 result, bitwise reproducible, no memset, no atomics."""
+    inf / NaN weight gradients on exactly the trunk's 1x1 convolutions).  A 1x1 convolution IS a per-pixel linear map, so its backward is
+    two GEMMs over the [B*H*W, C] views of the channels-last maps: dX = dY W (library GEMM) and dW [C2, C1] = dY^T X as the row-sliced
+    batched product + ordered slab sum of the tall linears (dw_splitk, slab_sum) - fp32 result, bitwise reproducible, no memset, no atomics."""
 
     @staticmethod
     def forward(ctx, x, w):
@@ -733,11 +735,11 @@ class _Conv1x1CL(torch.autograd.Function):
         C2 = w.shape[0]
         gy = gy.to(xp.dtype)
         gp = gy if _is_cl(gy) else (_pack_cl(gy) if _cl_pitch(gy) else gy.contiguous(memory_format=torch.channels_last))
+        g2, x2 = gp.permute(0, 2, 3, 1).reshape(B * H * W, C2), xp.permute(0, 2, 3, 1).reshape(B * H * W, C1)   # views of packed NHWC maps
         gx = gw = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.ops.aten.convolution_backward(gp, xp, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        if ctx.needs_input_grad[0]:   # dX [M, C1] = dY [M, C2] W [C2, C1]: a library GEMM (MIOpen's input-gradient solvers for some of these shapes memset too)
+            gx = torch.mm(g2, w.view(C2, C1)).view(B, H, W, C1).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            g2, x2 = gp.permute(0, 2, 3, 1).reshape(B * H * W, C2), xp.permute(0, 2, 3, 1).reshape(B * H * W, C1)   # views of packed NHWC maps
             gw = dw_splitk(g2, x2).view(C2, C1, 1, 1).to(w.dtype)
         return gx, gw
 

@@ -23,8 +23,12 @@ class TallLinear(nn.Linear):
     ops.dw_splitk: the plain dW GEMM of a [B*H*W, C] activation runs on a handful of workgroups."""
 
     def forward(self, x):
-        if x.is_cuda and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16)):
-            return ops.linear_splitk(x.to(torch.bfloat16), self.weight, self.bias)
+        if x.is_cuda:
+            if x.dtype == torch.bfloat16 or (torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16):
+                x = x.to(torch.bfloat16)
+            # (fp32 too: the Function's backward sums dW slices and the bias gradient with the ordered slab sum - autograd's own backward
+            # of F.linear reduces with torch's multi-workgroup kernel, whose memset node does not replay under AQL packet capture)
+            return ops.linear_splitk(x, self.weight, self.bias)
         return F.linear(x, self.weight, self.bias)
 
 

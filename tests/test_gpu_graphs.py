@@ -9,6 +9,8 @@
 """
 import copy
 
+import os
+
 import pytest
 import torch
 import torch.nn as nn
@@ -213,3 +215,59 @@ def test_capture_after_eager_steps_then_train(pkg):
     model.zero_grad(set_to_none=True)
     loss, _ = model(batch)                           # eager again
     assert torch.isfinite(loss)
+
+
+
+def test_packet_capture_mode_whole_static_part_in_its_own_process():
+    """The mode bench.py and tools/train.py run since round 4: the HIP runtime's AQL packet capture of graph nodes ON (its default), the
+    whole static part (trunk + VSS blocks + input projection, 640 x 640, 16 images, bf16, shipped convolution tables) recorded and
+    replayed SIX times against eager execution (tools/graph_bisect.py; the runtime reads the switch when it starts, hence a process of
+    its own).  Asserted: the recorded graphs hold no memset node (the node kind that does not replay in order under packet capture:
+    profiles/r04_packet_capture_bisect.txt), every replay is finite, the token memory is identical and every one of the 552 gradients
+    is at the eager run-to-run level."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, PACKET_CAPTURE='1', PART='all', REPLAYS='6', OFF_TOL='2e-2', TUNED='1')
+    env.pop('DEBUG_CLR_GRAPH_PACKET_CAPTURE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'graph_bisect.py'), 'pc1_all'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d['flags'].get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') == '1' and d['part'] == 'all' and d['grads'] == 552
+    assert d['census']['forward']['memset'] == 0 and d['census']['backward']['memset'] == 0, d['census']
+    assert d['census']['forward']['kernel'] > 1000 and d['census']['backward']['kernel'] > 1000, d['census']
+    assert d['ok'] and d['conclusive'] and d['nonfinite'] == [0] * 6 and not d['off_tensors'], d
+    assert d['out_rel_max'] <= 1e-6 and d['grad_l2_rel_max'] <= max(2e-2, 6 * d['eager_noise_grad_l2']), d
+
+
+def test_packet_capture_mode_refuses_a_recording_with_memset_nodes():
+    """GraphedPart counts the nodes of what it records (tamtr_graph_capture_census) and, with packet capture on, refuses a recording that
+    holds memset nodes - here a module whose backward is torch's multi-workgroup reduction (a memset of its arrival semaphores per launch).
+    In a process of its own (the runtime's switch)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = f"""
+import os, sys
+os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] = '1'
+sys.path.insert(0, {ROOT!r})
+import torch, torch.nn as nn
+from tamtr_amd.graphs import GraphedPart, packet_capture_on
+class M(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = nn.Parameter(torch.ones(512))
+    def forward(self, x):
+        return (x * self.w).sum(0)                # [8192, 512] -> [512]: a global reduction in the forward, a broadcast in the backward
+assert packet_capture_on()
+x = torch.randn(8192, 512, device='cuda')
+try:
+    GraphedPart(M().cuda(), (x,))
+    print('BUILT')
+except RuntimeError as e:
+    print('REFUSED' if 'memset nodes' in str(e) else 'OTHER ' + str(e)[:200])
+"""
+    env = {k: v for k, v in os.environ.items() if k != 'DEBUG_CLR_GRAPH_PACKET_CAPTURE'}
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == 'REFUSED', (r.stdout[-500:], r.stderr[-1500:])

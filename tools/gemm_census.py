@@ -2,7 +2,7 @@
 """One eager training step under torch.profiler: every library GEMM call (aten::mm / addmm / bmm / baddbmm) with its operand shapes, device
 time, algorithmic bytes and the time those bytes take at 5 TB/s - which library GEMMs are far from their byte time."""
 import os, sys, collections
-os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import synth_batch

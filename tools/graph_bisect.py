@@ -12,7 +12,6 @@ process.  Prints one JSON line: per-replay counts and the parameters whose gradi
 """
 import json, os, sys
 os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] = os.environ.get('PACKET_CAPTURE', '0')
-os.environ['TAMTR_GRAPH_TIMING_ONLY'] = '1'      # let GraphedPart build with packet capture on: this tool is the check
 import torch
 import torch.nn as nn
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -136,5 +135,5 @@ gp._restore_buffers(saved)
 flags = {k: v for k, v in os.environ.items() if k.startswith(('DEBUG_', 'HIP_FORCE', 'AMD_SERIALIZE', 'GPU_', 'ROC_', 'TAMTR_'))}
 print(json.dumps({'tag': tag, 'part': part, 'blas': blas, 'flags': flags, 'ok': chk['ok'], 'conclusive': chk['conclusive'],
                   'eager_noise_grad_l2': chk['eager_noise_grad_l2'], 'grad_l2_rel_max': chk['grad_l2_rel_max'], 'out_rel_max': chk['out_rel_max'],
-                  'grads': len(live), 'nonfinite': [r['nonfinite_grads'] for r in chk['replays']],
+                  'census': getattr(gp, 'census', None), 'grads': len(live), 'nonfinite': [r['nonfinite_grads'] for r in chk['replays']],
                   'off_tensors': {k: [f'{v:.2e}' for v in vs] for k, vs in sorted(bad.items())}}), flush=True)

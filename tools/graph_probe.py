@@ -9,7 +9,6 @@ Prints one JSON line: GraphedPart.verify over 6 replays (token memory + 552 grad
 graphed training step."""
 import json, os, sys, time
 os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] = os.environ.get('PACKET_CAPTURE', '0')
-os.environ['TAMTR_GRAPH_TIMING_ONLY'] = '1'      # let GraphedPart build with packet capture on: this tool is the check
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import synth_batch

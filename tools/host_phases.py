@@ -6,19 +6,19 @@ GPU runs behind it (no synchronisation inside the loop; one at the end).  With t
 
 Prints ms per step per phase (mean over the steps), the synchronised step time and the process CPU time per step."""
 import argparse, os, sys, time
-os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] = os.environ.get('PACKET_CAPTURE', '0')
-if os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] != '0':
-    os.environ['TAMTR_GRAPH_TIMING_ONLY'] = '1'
+if 'PACKET_CAPTURE' in os.environ:      # default: the runtime's default (on)
+    os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] = os.environ['PACKET_CAPTURE']
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import synth_batch
-from tamtr_amd.engine import ModelEMA
+from tamtr_amd.engine import FusedOptimStep, ModelEMA
 from tamtr_amd.model import RTDETRDetectionWorldModel
 from tamtr_amd.tuning import use_tuned_convolutions
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--steps', type=int, default=20)
 ap.add_argument('--static-part', default='graph')
+ap.add_argument('--optim-step', default='fused', choices=['fused', 'torch'])
 args = ap.parse_args()
 use_tuned_convolutions('shipped')
 torch.set_num_threads(8)
@@ -27,6 +27,7 @@ model = RTDETRDetectionWorldModel(nc=10).cuda().train()
 model.autocast_dtype = torch.bfloat16
 opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, fused=True)
 ema = ModelEMA(model)
+stepper = FusedOptimStep.create(model, opt, ema, 0.1) if args.optim_step == 'fused' else None
 batch = synth_batch(16, 640, 1, 'cuda')
 if args.static_part == 'graph':
     model.capture_static_part(batch['img'], batch['txt_feats'], verify=False)
@@ -65,6 +66,10 @@ def step():
     lap('fwd: tail')
     loss.backward()
     lap('backward (eager decoder + loss nodes, then the graph launch)')
+    if stepper is not None:
+        stepper.step()
+        lap('clip + AdamW + EMA (engine.FusedOptimStep)')
+        return
     torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], max_norm=0.1)
     lap('clip_grad_norm_')
     opt.step()
@@ -83,7 +88,7 @@ for _ in range(args.steps):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print(f'# host issue time per step by phase ({args.steps} steps, static part: {args.static_part}, DEBUG_CLR_GRAPH_PACKET_CAPTURE={os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"]}, '
+print(f'# host issue time per step by phase ({args.steps} steps, static part: {args.static_part}, DEBUG_CLR_GRAPH_PACKET_CAPTURE={os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "unset = on")}, '
       f'{torch.get_num_threads()} torch threads)')
 for k, v in T.items():
     print(f'  {v / args.steps * 1e3:8.2f} ms  {k}')

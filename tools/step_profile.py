@@ -2,7 +2,7 @@
 """One eager training step under torch.profiler: the heaviest ops by device time and by host time (what makes a mode slow).
 TAMTR_DETERMINISTIC=1 python3 tools/step_profile.py   ->  the deterministic mode"""
 import os, sys, time
-os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import synth_batch

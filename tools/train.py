@@ -16,7 +16,6 @@ import os
 import sys
 import tempfile
 
-os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')  # before the HIP runtime starts: see tam-tr_amd/graphs.py
 
 import numpy as np
 import torch
