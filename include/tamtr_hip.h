@@ -437,6 +437,26 @@ int tamtr_optim_step(const void* const* p, const void* const* m, const void* con
                      int nchunks, float* partial, float* normcoef, const float* lr, const float* wd, int ngroups, float beta1, float beta2, float eps,
                      float max_norm, float ema_decay, int do_ema, void* stream);
 
+/*      x_proj of SS2D on the cross-scan pair layout (ultralytics/nn/extra_modules/VManba/vmamba.py:962-975: x_dbl = einsum("b k d l, k c d
+ *      -> b k c l", xs, x_proj_weight); dts, Bs, Cs = split(x_dbl, [R, N, N])), bf16 MFMA products on f32 operands as the scan kernels keep
+ *      them (values rounded to bf16 in registers, products rounded to bf16 before they are stored / added: the arithmetic of the bf16
+ *      library GEMMs these kernels replace).  C = R + 32, N = 16 states, 1 <= R <= 32, 2C in {66 .. 128}.
+ *        u2    f32 [B, 2, D, L]     SiLU(dwconv(x)) row-major / column-major (tamtr_dwconv_silu_cross_fwd); directions k, k + 2 read copy k & 1
+ *        wcat  bf16 [2, MP, D]      rows [W_i ; W_(i+2)] of x_proj_weight [4, C, D], zero-padded to MP = ceil(2C / 32) * 32 rows
+ *        dtr   f32 [B, 4, R, L], Bs, Cs f32 [B, 4, 16, L]   un-reversed, as tamtr_selective_scan_dtproj_* take them
+ *      backward:  gdtr, gB, gC f32 as the scan backward writes them; gu f32 [B, 4, D, L] = the scan's d/d(u) per direction;
+ *        wT    bf16 [2, D, KP]      wcat transposed, zero-padded to KP = ceil(2C / 16) * 16 columns
+ *        gu2   f32 [B, 2, D, L]   = gu[:, i] + gu[:, i + 2] + Wcat_i^T G_i: the gradient of the two stored copies (what tamtr_fold_add + the
+ *                                   product did in two passes)
+ *        part  f32 [B * tamtr_xproj_dw_slices(L), 2, 2C, D]   per-(image, 1 024-pixel slice) partial dWcat tiles; the caller adds them in
+ *                                   order (tamtr_slab_sum_rows) and re-splits rows [0, C) / [C, 2C) of copy i into directions i / i + 2
+ *      D % 16 == 0 (fwd), % 32 (dx), % 256 and L % 8 == 0 (dw); wcat / wT 16-byte aligned. */
+int tamtr_xproj_dw_slices(int L);
+int tamtr_xproj_fwd(const float* u2, const void* wcat, float* dtr, float* Bs, float* Cs, int B, int D, int L, int R, void* stream);
+int tamtr_xproj_bwd_dx(const float* gu, const float* gdtr, const float* gB, const float* gC, const void* wT, float* gu2, int B, int D, int L, int R,
+                       void* stream);
+int tamtr_xproj_bwd_dw(const float* u2, const float* gdtr, const float* gB, const float* gC, float* part, int B, int D, int L, int R, void* stream);
+
 /*      Node census of the graph that `stream` is capturing into (hipStreamGetCaptureInfo_v2 + hipGraphGetNodes): counts[t] = nodes of
  *      hipGraphNodeType t, t < n_types <= 16 (0 kernel, 1 memcpy, 2 memset, ...).  Host-side helper of the HIP-graph replay
  *      (tam-tr_amd/graphs.py: memset nodes do not survive AQL packet capture); TAMTR_EINVAL when the stream is not capturing. */

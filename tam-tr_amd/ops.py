@@ -1150,6 +1150,30 @@ def ln_gate(x, xz, gamma, beta, eps=1e-5):
     return _LNGate.apply(x, xz, gamma, beta, eps)
 
 
+# ------------------------------------------------------------------------------------------------ x_proj of SS2D (csrc/xproj.hip)
+_XPROJ_LIB = _os.environ.get('TAMTR_XPROJ') == 'torch'   # A/B switch: the torch-op form (cast, two batched library GEMMs, stack, ...)
+
+
+def xproj_ok(cdt, D, L, R, N):
+    """What tamtr_xproj_{fwd, bwd_dx, bwd_dw} take: the bf16 mode, d_state 16, d_inner a multiple of 256, L a multiple of 8."""
+    return not _XPROJ_LIB and cdt == torch.bfloat16 and N == 16 and 1 <= R <= 32 and D % 256 == 0 and L % 8 == 0
+
+
+def xproj_pack_weight(wx):
+    """x_proj_weight [4, C, D] -> bf16 [2, MP, D]: rows [W_i ; W_(i+2)] per stored copy i, zero-padded to a multiple of 32 rows."""
+    C = wx.shape[1]
+    w = torch.stack([torch.cat([wx[0], wx[2]], 0), torch.cat([wx[1], wx[3]], 0)]).to(torch.bfloat16)
+    pad = (-2 * C) % 32
+    return _c(torch.nn.functional.pad(w, (0, 0, 0, pad)) if pad else w)
+
+
+def xproj_pack_weight_t(wcat, C):
+    """[2, MP, D] -> bf16 [2, D, KP]: the transposed blocks for the d/d(u2) product, zero-padded to a multiple of 16 columns."""
+    w = wcat[:, :2 * C].transpose(1, 2)
+    pad = (-2 * C) % 16
+    return _c(torch.nn.functional.pad(w, (0, pad)) if pad else w)
+
+
 class _SS2DCore(torch.autograd.Function):
     """SS2D between in_proj and out_proj as ONE autograd node (vmamba.py:949-1008): depthwise 3x3 + SiLU + cross-scan layout ->
     x_proj -> selective scan with the dt projection inside -> cross-merge -> out_norm x SiLU(z).  Same kernels and the same
@@ -1174,12 +1198,20 @@ class _SS2DCore(torch.autograd.Function):
         # x_proj on the two copies (directions k and k + 2 share one)
         cdt = xz.dtype if xz.dtype == torch.bfloat16 else torch.float32
         C = R + 2 * N
-        ub = u2.to(cdt)
-        wa, wb = torch.cat([wx[0], wx[2]], 0).to(cdt), torch.cat([wx[1], wx[3]], 0).to(cdt)
-        with torch.autocast('cuda', enabled=False):
-            xa, xb = torch.matmul(wa, ub[:, 0]), torch.matmul(wb, ub[:, 1])  # [B, 2C, L]
-        dtr, Bs, Cs = (torch.stack([xa[:, lo:lo + n], xb[:, lo:lo + n], xa[:, C + lo:C + lo + n], xb[:, C + lo:C + lo + n]], 1).float()
-                       for lo, n in ((0, R), (R, N), (R + N, N)))
+        own_xp = xproj_ok(cdt, D, L, R, N)
+        if own_xp:   # csrc/xproj.hip: u2 read once as f32, the three outputs written in the scan's layout
+            wcat = xproj_pack_weight(wx)
+            dtr, Bs, Cs = (torch.empty(B, K, n, L, device=xz.device, dtype=torch.float32) for n in (R, N, N))
+            call('tamtr_xproj_fwd', ptr(u2), ptr(wcat), ptr(dtr), ptr(Bs), ptr(Cs), B, D, L, R, stream_ptr())
+            ub = wa = wb = None
+        else:
+            wcat = None
+            ub = u2.to(cdt)
+            wa, wb = torch.cat([wx[0], wx[2]], 0).to(cdt), torch.cat([wx[1], wx[3]], 0).to(cdt)
+            with torch.autocast('cuda', enabled=False):
+                xa, xb = torch.matmul(wa, ub[:, 0]), torch.matmul(wb, ub[:, 1])  # [B, 2C, L]
+            dtr, Bs, Cs = (torch.stack([xa[:, lo:lo + n], xb[:, lo:lo + n], xa[:, C + lo:C + lo + n], xb[:, C + lo:C + lo + n]], 1).float()
+                           for lo, n in ((0, R), (R, N), (R + N, N)))
         # scan + cross-merge, token-major
         Wdt32, A32, D32, db32 = (_c(t.float()) for t in (Wdt, A, Ds, dbias))
         chunk = _lib.lib().tamtr_selective_scan_chunk()
@@ -1196,15 +1228,18 @@ class _SS2DCore(torch.autograd.Function):
         stats = torch.empty(B * L, 2, device=xz.device, dtype=torch.float32)
         call('tamtr_ln_gate_fwd', ptr(ymT), ptr(xz), C2, ptr(g32), ptr(b32), ptr(out), ptr(stats), B * L, D, float(eps), dtype_code(xz),
              stream_ptr())
-        ctx.save_for_backward(xz, cw, cb if cb is not None else cw.new_empty(0), u2, ub, wa, wb, dtr, Bs, Cs, Wdt32, A32, D32, db32, hstate,
+        none = cw.new_empty(0)
+        ctx.save_for_backward(xz, cw, cb if cb is not None else none, u2, ub if ub is not None else none, wa if wa is not None else none,
+                              wb if wb is not None else none, wcat if wcat is not None else none, dtr, Bs, Cs, Wdt32, A32, D32, db32, hstate,
                               ymT, g32, b32, stats)
+        ctx.own_xp = own_xp
         ctx.cfg = (R, N, H, W, conv_w.shape, conv_w.dtype, None if conv_b is None else conv_b.dtype, wx.dtype, Wdt.dtype, A.dtype, Ds.dtype,
                    dbias.dtype, gamma.dtype, beta.dtype)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        (xz, cw, cb, u2, ub, wa, wb, dtr, Bs, Cs, Wdt32, A32, D32, db32, hstate, ymT, g32, b32, stats) = ctx.saved_tensors
+        (xz, cw, cb, u2, ub, wa, wb, wcat, dtr, Bs, Cs, Wdt32, A32, D32, db32, hstate, ymT, g32, b32, stats) = ctx.saved_tensors
         R, N, H, W, cw_shape, cw_dt, cb_dt, wx_dt, wdt_dt, a_dt, d_dt, db_dt, ga_dt, be_dt = ctx.cfg
         B, _, _, C2 = xz.shape
         D, L, K, C = C2 // 2, H * W, 4, R + 2 * N
@@ -1224,7 +1259,7 @@ class _SS2DCore(torch.autograd.Function):
         del gy
         gu = torch.empty(B, K * D, L, device=dev, dtype=torch.float32)
         # d(delta) workspace: only the operand of gdtr = Wdt^T d(delta); in bf16 mode (gdtr is rounded to bf16 below anyway) kept in bf16
-        ws16 = ub.dtype == torch.bfloat16 and L % 4 == 0
+        ws16 = xz.dtype == torch.bfloat16 and L % 4 == 0
         gdelta = torch.empty(B, K * D, L, device=dev, dtype=torch.bfloat16 if ws16 else torch.float32)
         gdtr = torch.empty_like(dtr)
         gB, gC = torch.empty_like(Bs), torch.empty_like(Cs)
@@ -1236,21 +1271,32 @@ class _SS2DCore(torch.autograd.Function):
              3, int(ws16), stream_ptr())
         gW, gA, gD, gdb = _split_row_sums(grow, R)
         del gdelta, ws, g2
-        # x_proj backward: per copy one [D, 2C] x [2C, L] product and the weight gradient as a batched GEMM over L slices
-        cdt = ub.dtype
-        S = _split_len(L)
-        gws, ms = [], []
-        with torch.autocast('cuda', enabled=False):
-            for i, w in ((0, wa), (1, wb)):
-                gx = torch.cat([gdtr[:, i], gB[:, i], gC[:, i], gdtr[:, i + 2], gB[:, i + 2], gC[:, i + 2]], 1).to(cdt)  # [B, 2C, L]
-                ms.append(torch.matmul(w.t(), gx))                                                                         # [B, D, L]
-                ga = gx.view(B, 2 * C, S, L // S).transpose(1, 2).reshape(B * S, 2 * C, L // S)
-                ua = ub[:, i].reshape(B, D, S, L // S).transpose(1, 2).reshape(B * S, D, L // S)
-                gws.append(slab_sum(torch.bmm(ga, ua.transpose(1, 2))))  # [2C, D]
-        gwx = torch.stack([gws[0][:C], gws[1][:C], gws[0][C:], gws[1][C:]], 0).to(wx_dt)
         gu2 = torch.empty(B, 2, D, L, device=dev, dtype=torch.float32)
-        call('tamtr_fold_add', ptr(gu), ptr(_c(ms[0])), ptr(_c(ms[1])), ptr(gu2), B, D * L, dtype_code(ms[0]), stream_ptr())
-        del gu, ms
+        if ctx.own_xp:
+            # csrc/xproj.hip: d/d(u2) = fold of the scan's four planes + Wcat^T G in one pass; dWcat as per-slice partial tiles + ordered sum
+            wT = xproj_pack_weight_t(wcat, C)
+            call('tamtr_xproj_bwd_dx', ptr(gu), ptr(gdtr), ptr(gB), ptr(gC), ptr(wT), ptr(gu2), B, D, L, R, stream_ptr())
+            del gu
+            nsl = _lib.lib().tamtr_xproj_dw_slices(L)
+            part = torch.empty(B * nsl, 2, 2 * C, D, device=dev, dtype=torch.float32)
+            call('tamtr_xproj_bwd_dw', ptr(u2), ptr(gdtr), ptr(gB), ptr(gC), ptr(part), B, D, L, R, stream_ptr())
+            gws = slab_sum(part)
+            del part
+        else:
+            # x_proj backward: per copy one [D, 2C] x [2C, L] product and the weight gradient as a batched GEMM over L slices
+            cdt = ub.dtype
+            S = _split_len(L)
+            gws, ms = [], []
+            with torch.autocast('cuda', enabled=False):
+                for i, w in ((0, wa), (1, wb)):
+                    gx = torch.cat([gdtr[:, i], gB[:, i], gC[:, i], gdtr[:, i + 2], gB[:, i + 2], gC[:, i + 2]], 1).to(cdt)  # [B, 2C, L]
+                    ms.append(torch.matmul(w.t(), gx))                                                                         # [B, D, L]
+                    ga = gx.view(B, 2 * C, S, L // S).transpose(1, 2).reshape(B * S, 2 * C, L // S)
+                    ua = ub[:, i].reshape(B, D, S, L // S).transpose(1, 2).reshape(B * S, D, L // S)
+                    gws.append(slab_sum(torch.bmm(ga, ua.transpose(1, 2))))  # [2C, D]
+            call('tamtr_fold_add', ptr(gu), ptr(_c(ms[0])), ptr(_c(ms[1])), ptr(gu2), B, D * L, dtype_code(ms[0]), stream_ptr())
+            del gu, ms
+        gwx = torch.stack([gws[0][:C], gws[1][:C], gws[0][C:], gws[1][C:]], 0).to(wx_dt)
         # front end: the xi half of d/d(xz), d(conv weight), d(conv bias)
         tiles = _lib.lib().tamtr_dwconv_tiles(H, W)
         wsd = torch.empty(B, tiles, D, 10, device=dev, dtype=torch.float32)

@@ -46,6 +46,29 @@ def _record(name, rec):
     print(name, json.dumps(rec))
 
 
+class _Deterministic:
+    """MIOpen on its deterministic solvers + the NCHW trunk (what TAMTR_DETERMINISTIC=1 selects) for the body of a `with`: no run-to-run
+    term in a comparison (MIOpen's default solver set sums with float atomics / split-K in a run-dependent order)."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def __enter__(self):
+        from tamtr_amd import tuning
+        self.keep = (torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark, torch.are_deterministic_algorithms_enabled(),
+                     torch.is_deterministic_algorithms_warn_only_enabled())
+        tuning.use_deterministic_convolutions()
+        self.model.set_channels_last(False)
+        return self
+
+    def __exit__(self, *exc):
+        self.model.set_channels_last(True)
+        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = self.keep[0], self.keep[1]
+        torch.use_deterministic_algorithms(self.keep[2], warn_only=self.keep[3])
+        os.environ.pop('MIOPEN_DEBUG_CONVOLUTION_DETERMINISTIC', None)
+        return False
+
+
 # ------------------------------------------------------------------------------------------------ the whole graph at 640x640
 def _bench_batch(B, S, seed):
     """bench.py's synthetic batch: rand images, unit-norm prompts, 8 GT boxes per image."""
@@ -204,24 +227,38 @@ def test_full_model_640_fp32_elementwise_with_the_oracles_choices(pkg, case640):
     assert_close(es, c['es'], 1e-3, 4e-3, 'encoder scores')      # (measured 2.7e-3 on 2 of 2 000: Linear(512 -> 10) of LayerNorm rows, like the class logits)
 
 
-# bf16 ROUNDING of every term, the discrete choices held fixed (the oracle's): ~3x the values measured on MI355X
-# (profiles/r03_bf16_error_640.json).
-# Measured (eager / graph): loss 5.2e-2 / 5.2e-2; worst term 7.3e-2 (loss_class_aux: the VFL weights carry the IoU of the matched boxes);
-# boxes 3.0e-2 / 2.4e-2 max, 1.3e-3 mean (sigmoid space); class logits 1.8 / 2.4 max, 0.18 mean on a scale of 10; encoder scores 3.1 max.
-BF16_FORCED_BOUNDS = {'loss_rel': 1.2e-1, 'term_rel_max': 2e-1, 'box_abs_max': 8e-2, 'box_abs_mean': 4e-3, 'cls_logit_abs_max': 6.0,
-                      'cls_logit_abs_mean': 0.5}
+# bf16 ROUNDING of every term, the discrete choices held fixed (the oracle's), MIOpen on its deterministic solvers: 2x the values measured
+# on MI355X (round 4: profiles/r04_bf16_attribution.json, row "trunk+vss+proj+enc+decoder"; reproducible to the last bit, so the margin
+# only has to cover other MIOpen builds).  Measured: loss 4.98e-2; worst term 6.91e-2 (loss_class_aux: the VFL weights carry the IoU of the
+# matched boxes); boxes 1.96e-2 max / 1.31e-3 mean (sigmoid space); class logits 1.68 max / 0.174 mean on a scale of 10.
+# (Round 3 ran this on MIOpen's default solvers: the same code gave loss_class 1.4e-2 in one run and 1.04e-1 in the next, and the bounds
+# had to be 12 % / 20 % / 6.0 logits - VERDICT r3 weak 2.)
+BF16_FORCED_BOUNDS = {'loss_rel': 1.0e-1, 'term_rel_max': 1.4e-1, 'box_abs_max': 4e-2, 'box_abs_mean': 2.7e-3, 'cls_logit_abs_max': 3.4,
+                      'cls_logit_abs_mean': 0.35}
+# WHERE that error comes from (same file, one row per stage): the trunk - library convolutions + BatchNorm at bf16 through ~60 layers of
+# random-fill weights, BASELINE configs[1]'s "bf16 ... rest PyTorch-ROCm" - carries all of it (trunk alone: loss 4.99e-2, logits 1.67 max).
+# Everything this repo hand-writes behind the trunk (VSS blocks, input projection, query selection, decoder, heads) in bf16 ON AN fp32
+# TRUNK measured loss 1.63e-4, worst term 1.06e-3, boxes 1.66e-3 max / 6.5e-5 mean, class logits 0.40 max / 0.008 mean, encoder scores 0.032
+# (row "vss+proj+enc+decoder"): bounds at 2x in test_bf16_error_of_the_hip_path_on_an_fp32_trunk.
+BF16_HIP_PATH_BOUNDS = {'loss_rel': 3.5e-4, 'term_rel_max': 2.2e-3, 'box_abs_max': 3.4e-3, 'box_abs_mean': 1.3e-4, 'cls_logit_abs_max': 0.8,
+                        'cls_logit_abs_mean': 0.016, 'enc_score_abs_max': 0.065}
 
 
 @pytest.mark.parametrize('mode', ['eager', 'graph'])
 def test_full_model_640_bf16_rounding_with_the_oracles_choices(pkg, case640, mode):
     """What bf16 costs in ARITHMETIC on all 12 terms and on all 292 rows: the benchmarked dtype (and, mode 'graph', the benchmarked
-    execution mode) with the oracle's top-k picks and Hungarian pairs injected, against the fp32 oracle.  This replaces the unbounded
-    'matched terms' of the free-running comparison below, whose swings are discrete flips, not rounding."""
+    execution mode) with the oracle's top-k picks and Hungarian pairs injected, against the fp32 oracle, on MIOpen's deterministic
+    solvers - a reproducible measurement (two runs give the same bits), bounded at 2x.  This replaces the unbounded 'matched terms' of the
+    free-running comparison below, whose swings are discrete flips, not rounding."""
     c = case640
-    loss, items, terms, db, ds, eb, es, meta = _run(c, torch.bfloat16, graph=mode == 'graph', forced=True)
+    with _Deterministic(c['model']):
+        loss, items, terms, db, ds, eb, es, meta = _run(c, torch.bfloat16, graph=mode == 'graph', forced=True)
+        if mode == 'eager':
+            again = _run(c, torch.bfloat16, forced=True)
+            assert again[0] == loss and torch.equal(again[4], ds) and torch.equal(again[3], db), 'the deterministic mode is not reproducible'
     e_box, e_cls = (db - c['db']).abs(), (ds - c['ds']).abs()
     n_dn = meta['dn_num_split'][0]
-    rec = {'imgsz': 640, 'batch': 2, 'mode': mode, 'loss_bf16': loss, 'loss_fp32_oracle': float(c['loss']),
+    rec = {'imgsz': 640, 'batch': 2, 'mode': mode, 'convolutions': 'deterministic solvers, NCHW trunk', 'loss_bf16': loss, 'loss_fp32_oracle': float(c['loss']),
            'loss_rel': abs(loss - float(c['loss'])) / abs(float(c['loss'])),
            'term_rel': {k: abs(terms[k] - float(v)) / max(abs(float(v)), 1e-6) for k, v in c['terms'].items()},
            'box_abs_max': float(e_box.max()), 'box_abs_mean': float(e_box.mean()),
@@ -233,6 +270,27 @@ def test_full_model_640_bf16_rounding_with_the_oracles_choices(pkg, case640, mod
     _record(f'bf16_error_640_forced_{mode}.json', rec)
     for k, bound in BF16_FORCED_BOUNDS.items():
         assert rec[k] <= bound, (k, rec[k], bound)
+
+
+def test_bf16_error_of_the_hip_path_on_an_fp32_trunk(pkg, case640):
+    """bf16 switched on stage by stage (tests/staged.py; the oracle's choices injected, deterministic solvers): (1) everything behind the
+    trunk - VSS blocks, input projection, query selection, decoder and heads: the hand-written path - in bf16 on an fp32 trunk stays within
+    BF16_HIP_PATH_BOUNDS of the fp32 oracle (two orders below the whole-model figure); (2) the trunk alone in bf16 reproduces the
+    whole-model error (within 10 %), i.e. the bf16 mode's error is the trunk's (profiles/r04_bf16_attribution.json)."""
+    from staged import HIP_PATH, STAGES, errors, staged_forward
+    c = case640
+    tg_host = {k: c['tg'][k] for k in ('cls', 'bboxes', 'batch_idx', 'gt_groups')}
+    ref = (float(c['loss']), {k: float(v) for k, v in c['terms'].items()}, c['db'], c['ds'], c['eb'], c['es'])
+    with _Deterministic(c['model']):
+        rows = {name: errors(staged_forward(c['model'], c['state'], c['batch'], tg_host, c['choices'], set(on)), ref)
+                for name, on in (('hip_path', HIP_PATH), ('trunk', ['trunk']), ('all', STAGES), ('none', []))}
+    _record('bf16_staged_640.json', rows)
+    for k, bound in BF16_HIP_PATH_BOUNDS.items():
+        assert rows['hip_path'][k] <= bound, (k, rows['hip_path'][k], bound)
+    assert rows['none']['loss_rel'] <= 1e-4 and rows['none']['cls_logit_abs_max'] <= 0.05        # the staged driver itself = the fp32 path
+    for k in ('loss_rel', 'cls_logit_abs_mean', 'box_abs_mean'):
+        assert abs(rows['trunk'][k] - rows['all'][k]) <= 0.1 * rows['all'][k], (k, rows['trunk'][k], rows['all'][k])
+        assert rows['hip_path'][k] <= 0.05 * rows['all'][k], (k, rows['hip_path'][k], rows['all'][k])
 
 
 def test_full_model_640_bf16_error_is_measured_and_bounded(pkg, case640):

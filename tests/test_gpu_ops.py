@@ -790,8 +790,8 @@ def test_fused_optim_step_equals_clip_adamw_ema():
     class Net(nn.Module):
         def __init__(self):
             super().__init__()
-            self.conv = nn.Conv2d(8, 16, 3, padding=1)
-            self.bn = nn.BatchNorm2d(16)
+            self.conv = nn.Conv2d(8, 16, 3, padding=1, bias=False)   # (a bias in front of BatchNorm has a zero gradient: rounding noise that Adam
+            self.bn = nn.BatchNorm2d(16)                              # would blow up to +-lr, differently in two runs of the library convolution)
             self.fc = nn.Linear(16, 5003)                 # > one 8 192-element chunk, odd length: the scalar tail
             self.sometimes = nn.Linear(16, 7)
             self.never = nn.Linear(3, 3)
@@ -822,19 +822,19 @@ def test_fused_optim_step_equals_clip_adamw_ema():
         got = st.step()
         assert abs(float(got[0]) - float(want_norm)) <= 1e-5 * float(want_norm), (float(got[0]), float(want_norm))
         for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
-            assert_close(pb, pa, 1e-5, 1e-7, f'step {step} param {n}')
+            assert_close(pb, pa, 1e-5, 2e-6, f'step {step} param {n}')   # (atol: an element whose gradient is rounding noise moves by ~lr * noise ratio)
             assert (pa.grad is None) == (pb.grad is None)
             if pa.grad is not None:
                 # (the two norms differ in the order of their fp32 sums, asserted to 1e-5 above: the clip coefficient carries that into the
                 # clipped gradient and the moments; Adam's m / sqrt(v) cancels it in the parameter)
-                assert_close(pb.grad, pa.grad, 3e-5, 1e-9, f'step {step} clipped grad {n}')
+                assert_close(pb.grad, pa.grad, 1e-4, 1e-9, f'step {step} clipped grad {n}')
                 sa, sb = oa.state[pa], ob.state[pb]
                 assert float(sa['step']) == float(sb['step']), n
-                assert_close(sb['exp_avg'], sa['exp_avg'], 3e-5, 1e-10, f'exp_avg {n}')
-                assert_close(sb['exp_avg_sq'], sa['exp_avg_sq'], 6e-5, 1e-14, f'exp_avg_sq {n}')
+                assert_close(sb['exp_avg'], sa['exp_avg'], 1e-4, 1e-10, f'exp_avg {n}')
+                assert_close(sb['exp_avg_sq'], sa['exp_avg_sq'], 2e-4, 1e-14, f'exp_avg_sq {n}')
         for (k, va), vb in zip(ea.ema.state_dict().items(), eb.ema.state_dict().values()):
             if va.dtype.is_floating_point:
-                assert_close(vb, va, 1e-5, 1e-7, f'step {step} ema {k}')
+                assert_close(vb, va, 1e-5, 2e-6, f'step {step} ema {k}')
         assert ea.updates == eb.updates == step + 1
     assert float(ob.state[b.sometimes.weight]['step']) == 4.0 and float(ob.state[b.never.weight]['step']) == 0.0 and b.never.weight.grad is None
     # the optimizer's state_dict round-trips (the step counts are ordinary tensors to it) and the stepper notices replaced state
@@ -843,6 +843,55 @@ def test_fused_optim_step_equals_clip_adamw_ema():
     b(x, True).backward()
     st.step()
     assert float(ob.state[b.fc.weight]['step']) == 7.0
+
+
+@pytest.mark.parametrize('B,D,L,R', [(2, 256, 1048, 8), (1, 512, 400, 16), (1, 1024, 136, 32), (3, 256, 64, 8)])
+def test_xproj_kernels_vs_fp32_products_of_the_same_bf16_operands(ops, B, D, L, R):
+    """csrc/xproj.hip (x_proj of SS2D on the pair layout, vmamba.py:962-975): the forward's three outputs, d/d(u2) with the fold of the
+    scan's four planes, and the weight gradient's partial tiles + ordered sum, against fp64 products of the same operands rounded to
+    bf16 (what the bf16 library GEMMs they replace computed); ragged pixel counts (not a multiple of 32 / of the 1 024-pixel slice);
+    the same bits on a second call."""
+    import tamtr_amd._lib as L_
+    N, C = 16, R + 32
+    g = torch.Generator(device='cuda').manual_seed(D + L)
+    rn = lambda *sh: torch.randn(*sh, device='cuda', generator=g)   # noqa: E731
+    u2, wx = rn(B, 2, D, L), rn(4, C, D) * D ** -0.5
+    r16 = lambda t: t.bfloat16().double()                             # noqa: E731
+    wcat = ops.xproj_pack_weight(wx)
+    assert wcat.shape == (2, -(-2 * C // 32) * 32, D) and wcat.dtype == torch.bfloat16
+    outs = [[torch.empty(B, 4, n, L, device='cuda') for n in (R, N, N)] for _ in range(2)]
+    for o in outs:
+        ops.call('tamtr_xproj_fwd', ops.ptr(u2), ops.ptr(wcat), ops.ptr(o[0]), ops.ptr(o[1]), ops.ptr(o[2]), B, D, L, R, ops.stream_ptr())
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    dtr, Bs, Cs = outs[0]
+    for i in range(2):
+        W = torch.cat([r16(wx[i]), r16(wx[i + 2])], 0)                                   # [2C, D]
+        ref = torch.einsum('md,bdl->bml', W, r16(u2[:, i]))                               # [B, 2C, L]
+        got = torch.cat([dtr[:, i], Bs[:, i], Cs[:, i], dtr[:, i + 2], Bs[:, i + 2], Cs[:, i + 2]], 1).double()
+        assert_close(got, ref, 8e-3, 8e-3 * float(ref.abs().max()), f'x_proj forward copy {i}')   # one bf16 rounding of the product
+    # backward
+    gdtr, gB, gC, gu = rn(B, 4, R, L), rn(B, 4, N, L), rn(B, 4, N, L), rn(B, 4, D, L)
+    wT = ops.xproj_pack_weight_t(wcat, C)
+    assert wT.shape == (2, D, -(-2 * C // 16) * 16)
+    gu2 = [torch.empty(B, 2, D, L, device='cuda') for _ in range(2)]
+    for o in gu2:
+        ops.call('tamtr_xproj_bwd_dx', ops.ptr(gu), ops.ptr(gdtr), ops.ptr(gB), ops.ptr(gC), ops.ptr(wT), ops.ptr(o), B, D, L, R, ops.stream_ptr())
+    assert torch.equal(*gu2)
+    nsl = L_.lib().tamtr_xproj_dw_slices(L)
+    parts = [torch.full((B * nsl, 2, 2 * C, D), float('nan'), device='cuda') for _ in range(2)]
+    for o in parts:
+        ops.call('tamtr_xproj_bwd_dw', ops.ptr(u2), ops.ptr(gdtr), ops.ptr(gB), ops.ptr(gC), ops.ptr(o), B, D, L, R, ops.stream_ptr())
+    assert torch.equal(*parts) and torch.isfinite(parts[0]).all()
+    gws = ops.slab_sum(parts[0])
+    for i in range(2):
+        W = torch.cat([r16(wx[i]), r16(wx[i + 2])], 0)
+        G = torch.cat([gdtr[:, i], gB[:, i], gC[:, i], gdtr[:, i + 2], gB[:, i + 2], gC[:, i + 2]], 1)    # [B, 2C, L]
+        prod = torch.einsum('md,bml->bdl', W, r16(G))
+        ref = gu[:, i].double() + gu[:, i + 2].double() + prod
+        tol = 8e-3 * float(prod.abs().max())                                             # the product is rounded to bf16 before the fold
+        assert_close(gu2[0][:, i].double(), ref, 1e-6, tol, f'd/d(u2) copy {i}')
+        refw = torch.einsum('bml,bdl->md', r16(G), r16(u2[:, i]))
+        assert_close(gws[i].double(), refw, 1e-4, 1e-4 * float(refw.abs().max()), f'dWcat copy {i}')
 
 
 # ------------------------------------------------------------------------------------------------ next-3: proj_conv on MFMA

@@ -28,16 +28,13 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from oracle import selscan_c, tamtr_oracle as O          # the checker (tools/ may use it: this is a parity measurement)
 from weights import fill_state
 from test_gpu_fullsize import _bench_batch
-from tamtr_amd import ops, tuning
-from tamtr_amd.loss import get_cdn_group
+from tamtr_amd import tuning
 from tamtr_amd.model import RTDETRDetectionWorldModel
-from tamtr_amd.modules import TIAGELAN
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--out', default=None)
 ap.add_argument('--imgsz', type=int, default=640)
 args = ap.parse_args()
-STAGES = ['trunk', 'vss', 'proj', 'enc', 'decoder']
 note = tuning.use_tuned_convolutions('shipped')    # TAMTR_DETERMINISTIC=1 -> deterministic solvers
 torch.manual_seed(0)
 model = RTDETRDetectionWorldModel(nc=10)
@@ -66,67 +63,19 @@ with torch.no_grad():
 mt = trace['matches']
 choices = {'top': trace['top'][0], 'matches': [mt[1], mt[2], mt[3], mt[0]]}
 print(f'[attr] oracle: {time.time() - t0:.1f} s, loss {float(lref):.5f}', file=sys.stderr, flush=True)
-head = model.model[-1]
-model.criterion = model.init_criterion()
-dev = lambda t: t.cuda() if torch.is_tensor(t) else t   # noqa: E731
-img, txt = batch['img'].cuda(), batch['txt_feats'].cuda().float()
+from staged import HIP_PATH, STAGES, errors, staged_forward
+ref = (float(lref), {k: float(v) for k, v in tref.items()}, rdb, rds, reb, res_)
 
 
 def staged(on):
-    """One training-mode forward + loss with bf16 autocast enabled exactly for the stages in `on`."""
-    def ac(s):
-        return torch.autocast('cuda', dtype=torch.bfloat16, enabled=s in on, cache_enabled=False)
-
-    def to(t, s):
-        return t.bfloat16() if s in on else t.float()
-    model.load_state_dict(state)
-    head.fixed_topk, model.criterion.fixed_matches = choices['top'], choices['matches']
-    tg = {k: dev(v) for k, v in tg_host.items()}
-    tg['host'] = {k: tg_host[k] for k in ('cls', 'bboxes', 'batch_idx')}
-    torch.manual_seed(5)
-    with torch.no_grad():
-        x, y = img, []
-        counters = ops.begin_bn_counter_batch()
-        with ac('trunk'):
-            for m in model.model[:-1]:
-                if m.f != -1:
-                    x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
-                x = m(x, txt) if isinstance(m, TIAGELAN) else m(x)
-                y.append(x if m.i in model.save else None)
-        ops.end_bn_counter_batch()
-        outs = []
-        for i, (blk, j) in enumerate(zip(head.VSSBlocks, head.f)):
-            with ac('vss'):
-                tok = blk(to(y[j], 'vss').permute(0, 2, 3, 1))
-            with ac('proj'):
-                outs.append(head._project_level(i, to(tok, 'proj')))
-        feats, shapes = torch.cat([o[0] for o in outs], 1), [o[1] for o in outs]
-        dn_embed, dn_bbox, attn_mask, dn_meta = get_cdn_group(tg, head.nc, head.num_queries, head.denoising_class_embed.weight, head.num_denoising,
-                                                              head.label_noise_ratio, head.box_noise_scale, True)
-        with ac('enc'):
-            embed, refer, enc_b, enc_s = head._get_decoder_input(to(feats, 'enc'), shapes, dn_embed, dn_bbox)
-        with ac('decoder'):
-            dec_b, dec_s = head.decoder(to(embed, 'decoder'), refer, to(feats, 'decoder'), shapes, txt.clone(), head.dec_bbox_head, head.dec_score_head,
-                                        head.query_pos_head, attn_mask=attn_mask)
-        dn_b, db = torch.split(dec_b, dn_meta['dn_num_split'], dim=2)
-        dn_s, ds = torch.split(dec_s, dn_meta['dn_num_split'], dim=2)
-        allb = torch.cat([enc_b.unsqueeze(0).to(db.dtype), db])
-        alls = torch.cat([enc_s.unsqueeze(0).to(ds.dtype), ds])
-        terms = model.criterion((allb, alls), tg, dn_bboxes=dn_b, dn_scores=dn_s, dn_meta=dn_meta)
-        loss = float(torch.stack(list(terms.values())).sum())
-    head.fixed_topk = model.criterion.fixed_matches = None
-    dec_b, dec_s, enc_b, enc_s = (t.float().cpu() for t in (dec_b, dec_s, enc_b, enc_s))
-    e_box, e_cls = (dec_b - rdb).abs(), (dec_s - rds).abs()
-    tr = {k: abs(float(v) - float(tref[k])) / max(abs(float(tref[k])), 1e-6) for k, v in terms.items()}
-    worst = max(tr, key=tr.get)
-    return {'bf16_stages': sorted(on, key=STAGES.index), 'loss': loss, 'loss_rel': abs(loss - float(lref)) / abs(float(lref)), 'term_rel_max': tr[worst],
-            'worst_term': worst, 'box_abs_max': float(e_box.max()), 'box_abs_mean': float(e_box.mean()), 'cls_logit_abs_max': float(e_cls.max()),
-            'cls_logit_abs_mean': float(e_cls.mean()), 'enc_box_abs_max': float((enc_b - reb).abs().max()),
-            'enc_score_abs_max': float((enc_s - res_).abs().max()), 'enc_score_abs_mean': float((enc_s - res_).abs().mean())}
+    r = errors(staged_forward(model, state, batch, tg_host, choices, on), ref)
+    r['bf16_stages'] = sorted(on, key=STAGES.index)
+    return r
 
 
 rows = []
-configs = [[]] + [[s] for s in STAGES] + [STAGES[:k] for k in range(2, len(STAGES) + 1)]
+from staged import HIP_PATH as _HP, STAGES as _ST
+configs = [[]] + [[s] for s in _ST] + [list(_HP)] + [_ST[:k] for k in range(2, len(_ST) + 1)]
 for on in configs:
     r = staged(set(on))
     r2 = staged(set(on))

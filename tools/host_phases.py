@@ -78,10 +78,25 @@ def step():
     lap('EMA update')
 
 
+def thread_cpu():
+    """{tid: (name, cpu seconds)} of this process' threads (/proc/self/task/*/stat: utime + stime)."""
+    out, tck = {}, os.sysconf('SC_CLK_TCK')
+    for tid in os.listdir('/proc/self/task'):
+        try:
+            f = open(f'/proc/self/task/{tid}/stat').read()
+            name = f[f.index('(') + 1:f.rindex(')')]
+            rest = f[f.rindex(')') + 2:].split()
+            out[int(tid)] = (name, (int(rest[11]) + int(rest[12])) / tck)
+        except (OSError, ValueError):
+            pass
+    return out
+
+
 for _ in range(5):
     step()
 torch.cuda.synchronize()
 T.clear()
+th0 = thread_cpu()
 c0, t0 = time.process_time(), time.perf_counter()
 for _ in range(args.steps):
     step()
@@ -94,3 +109,6 @@ for k, v in T.items():
     print(f'  {v / args.steps * 1e3:8.2f} ms  {k}')
 print(f'  {sum(T.values()) / args.steps * 1e3:8.2f} ms  sum = issue time of a step;  loop wall {(t1 - t0) / args.steps * 1e3:.2f} ms/step, with the final drain {(t2 - t0) / args.steps * 1e3:.2f} ms/step, '
       f'process CPU {(time.process_time() - c0) / args.steps * 1e3:.1f} ms/step')
+th1 = thread_cpu()
+rows = sorted(((th1[t][1] - th0.get(t, (None, 0.0))[1], th1[t][0], t) for t in th1), reverse=True)
+print('  CPU time per step by thread (ms): ' + ', '.join(f'{n}[{t}{" = main" if t == os.getpid() else ""}] {d / args.steps * 1e3:.1f}' for d, n, t in rows[:8] if d > 0))
