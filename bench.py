@@ -199,6 +199,59 @@ def graph_vs_eager(model, batch, seed=4321):
             'finite': bool(torch.isfinite(gg).all())}
 
 
+def other_kernels(args, dev):
+    """The other kernels VERDICT r3 names, timed live (standalone, events on the launch stream, after the timed loop): the channels-last
+    text gate at the largest TIAGELAN site (HBM-bound: e + v + out) and the selective scan at MEH level 0 (the step's largest kernel:
+    VALU-issue-bound; priced against HBM on its algorithmic bytes, which is why its fraction is low - DESIGN 4)."""
+    import torch.nn as nn
+    import tamtr_amd.ops as ops
+    out = []
+
+    def t_ms(fn, n=10, warm=3):
+        for _ in range(warm):
+            fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in ev:
+            a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in ev)
+        return sum(ms) / len(ms)
+    B, H = args.batch, args.imgsz // 4
+    with torch.no_grad():
+        C, nh = 64, 2
+        wide = torch.randn(B, 2 * C, H, H, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+        e, v = wide.chunk(2, 1)[1], torch.randn(B, C, H, H, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+        gk, bias = torch.randn(B, 10, C, device=dev), torch.zeros(nh, device=dev)
+        bn = nn.BatchNorm2d(C, eps=1e-3, momentum=0.03).to(dev).train()
+        st = torch.stack([torch.randn(C, device=dev) * 0.1, torch.rand(C, device=dev) + 0.5], 1).contiguous()
+        ms = t_ms(lambda: ops.maxsigmoid_gate_cl(e, gk, bias, v, st, bn, nh), n=20)
+        byt = 3 * v.numel() * 2
+        out.append({'kernel': f'gate_cl_fwd_kernel<bf16> (BTA-PAN text gate, {C} ch x {H}^2 x {B}: TIAGELAN site 32)', 'bound': 'hbm', 'achieved': byt / ms / 1e6,
+                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': byt / ms / 1e6 / HBM_PEAK_GBS, 'avg_ms': ms, 'algorithmic_bytes': byt})
+        del wide, e, v
+    D, L, R, K, N = 256, H * H, 8, 4, 16
+    g = torch.Generator(device=dev).manual_seed(0)
+    rn = lambda *sh: torch.randn(*sh, device=dev, generator=g)   # noqa: E731
+    ins = [rn(B, 2, D, L), rn(B, K, R, L), rn(K * D, R) * R ** -0.5, -torch.exp(rn(K * D, N) * 0.3), rn(B, K, N, L), rn(B, K, N, L), rn(K * D), rn(K * D) - 3]
+    ins = [t.requires_grad_() for t in ins]
+    y = ops.selective_scan_cross(*ins)
+    gy = torch.randn_like(y)
+    f_ms = t_ms(lambda: ops.selective_scan_cross(*ins), n=5, warm=2)
+
+    def fb():
+        torch.autograd.grad(ops.selective_scan_cross(*ins), ins, gy)
+    b_ms = t_ms(fb, n=5, warm=2) - f_ms
+    state_steps = B * K * D * L * N
+    f_bytes = (2 + 4) * B * D * L * 4 + 3 * B * K * (R + 2 * N) * L * 4 // 3
+    b_bytes = (2 + 4 + 4) * B * D * L * 4 + 4 * B * D * L * 2
+    for name, ms, byt in (('selscan_fwd_kernel (MEH level 0: d_inner 256, L %d, 4 directions, 16 states)' % L, f_ms, f_bytes),
+                          ('selscan_bwd (kernel + dtproj_gdtr + slab_sum, same shape)', b_ms, b_bytes)):
+        out.append({'kernel': name, 'bound': 'hbm', 'limiter': 'VALU issue (fp32 recurrence: exp + 3 FMA per step and state, DPP scans)', 'achieved': byt / ms / 1e6,
+                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': byt / ms / 1e6 / HBM_PEAK_GBS, 'avg_ms': ms, 'algorithmic_bytes': byt,
+                    'state_steps_per_s': state_steps / (ms * 1e-3)})
+    return out
+
+
 def _brief(chk):
     if not chk:
         return None
@@ -224,7 +277,7 @@ def main():
     ap.add_argument('--grad-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire (N > 1)')
     ap.add_argument('--optim-step', default='fused', choices=['fused', 'torch'],
                     help='clip + AdamW + EMA as the table-driven kernels of csrc/optim.hip (engine.FusedOptimStep) or as the three torch calls')
-    ap.add_argument('--no-graph-check', action='store_true', help='skip the graph-vs-eager step after the timed loop (profiling runs: keeps the trace to the timed steps)')
+    ap.add_argument('--no-graph-check', action='store_true', help='skip the graph-vs-eager step and the standalone roofline_other launches after the timed loop (profiling runs: keeps the trace to the timed steps)')
     ap.add_argument('--cpu-baseline-images', type=int, default=8, help='images of the CPU-oracle sample (BASELINE configs[0]: 8)')
     args = ap.parse_args()
 
@@ -385,6 +438,11 @@ def main():
                 # algorithmic bytes (X read once + Y written once) per second over the 8 TB/s HBM peak
                 'hbm_view': _hbm_view(args, ks)},
         }
+        if args.dtype == 'bf16' and not args.no_graph_check:   # (profiling runs keep the trace to the timed steps)
+            try:
+                out['roofline_other'] = other_kernels(args, dev)
+            except Exception as e:  # noqa: BLE001 - an extra; the line stands without it
+                out['roofline_other'] = {'error': f'{type(e).__name__}: {e}'[:200]}
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.cpu_baseline_images, args.imgsz)
         else:

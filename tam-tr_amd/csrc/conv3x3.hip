@@ -148,9 +148,17 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_cl_kernel(const bf16_t* __
   }
 
   // ---- epilogue.  D[i][j]: i = channel (q & 3) + 8 (q >> 2) + 4 lh (+ 32 nb), j = pixel lr of the wave's 8 x 4 block.
-  // LDS tile [128 pixels][64 channels] bf16 (128-byte rows, 16-byte pieces XOR-ed with pixel & 7) over the weight stage.
+  // LDS tile [128 pixels][64 channels] bf16 (128-byte rows) over the weight stage, 16-byte pieces XOR-ed with cv_okey(pixel).
+  // Round 4 (`SQ_LDS_BANK_CONFLICT` 8.3e5 = 108 cycles per wave against a layout called conflict-free): enumerated
+  // per instruction with the guide's lane groups - the staging ds_write_b128 (8 lanes = two 64-byte rows r, r + 1 or r, r + 3: 4 r and
+  // 4 (r + 1) fall into different 64-byte halves of the 32-bank window, the XOR only permutes inside a half) and the fragment
+  // ds_read_b128 are conflict-free; the conflicts were HERE: a 16-lane group of these ds_write_b64 is 4 tile rows x 4 columns, and with
+  // the key `pixel & 7` = 4 (wave & 1) + column the four rows of a column shared one 16-byte piece: 4-way, 8 stores x 12 extra cycles = 96
+  // per wave.  The key now also takes the row's low bit, two rows per piece: 2-way, the minimum (the 8-byte half of a piece is fixed by
+  // the accumulator layout: 16 lanes of one half-wave can reach only 8 of the 16 8-byte slots of a 128-byte window).
   __syncthreads();
   unsigned char* s_o = s_w;
+  auto cv_okey = [](int p) { return (p & 3) | ((((p >> 2) ^ (p >> 4)) & 1) << 2); };
   {
     const int p = (lr >> 2) * CV_TW + 4 * wave + (lr & 3);  // tile pixel: row * 16 + column
 #pragma unroll
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_cl_kernel(const bf16_t* __
         uint2 v;
         v.x = (uint32_t)f2bf(acc[nb][4 * g]) | ((uint32_t)f2bf(acc[nb][4 * g + 1]) << 16);
         v.y = (uint32_t)f2bf(acc[nb][4 * g + 2]) | ((uint32_t)f2bf(acc[nb][4 * g + 3]) << 16);
-        *reinterpret_cast<uint2*>(s_o + p * 128 + (((co >> 3) ^ (p & 7)) << 4) + (co & 7) * 2) = v;
+        *reinterpret_cast<uint2*>(s_o + p * 128 + (((co >> 3) ^ cv_okey(p)) << 4) + (co & 7) * 2) = v;
       }
   }
   __syncthreads();
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_cl_kernel(const bf16_t* __
   for (int i = 0; i < 4; ++i) {
     const int p = (tid >> 3) + 32 * i;  // tile pixel: row p / 16, column p % 16
     const int gy = ty0 + (p >> 4), gx = tx0 + (p & 15);
-    const uint4 v = *reinterpret_cast<const uint4*>(s_o + p * 128 + ((j8 ^ (p & 7)) << 4));
+    const uint4 v = *reinterpret_cast<const uint4*>(s_o + p * 128 + ((j8 ^ cv_okey(p)) << 4));
     if (gy < H && gx < W) {
       *reinterpret_cast<uint4*>(y + (((size_t)b * H + gy) * W + gx) * C2 + n0 + 8 * j8) = v;
       const uint32_t u[4] = {v.x, v.y, v.z, v.w};
