@@ -424,7 +424,8 @@ def main():
             'host_cpu_ms_per_step': {'max': max(host_all), 'per_rank': [round(v, 2) for v in host_all], 'host_cores': host_cores()},
             'config': {'workload': f'TAM-TR (TAMTR.yaml graph, 42.1M params) train step fwd+loss+bwd+clip+AdamW+EMA, {args.imgsz}x{args.imgsz}, '
                                    f'bs {args.batch}/GPU, 10 text prompts, 8 GT/img, full BTA-PAN+MEH HIP path',
-                       'global_batch': world * args.batch, 'parallelism': f'dp{world}', 'final_loss': float(loss.detach()),
+                       'global_batch': world * args.batch, 'parallelism': f'dp{world}',
+                       'reduced_precision': 'bf16 (BASELINE configs[4] names fp16: this build serves every reduced-precision configuration as bf16 - same MFMA rate on gfx950, fp32 exponent range, no loss scaler; DESIGN 7)', 'final_loss': float(loss.detach()),
                        'bf16_vs_fp32': mode_err, 'dist_backend': backend, 'dist_world_size': world,
                        'grad_bucket_dtype': (args.grad_dtype if world > 1 else None), 'static_part': static_part,
                        'optim_step': 'fused (csrc/optim.hip)' if stepper is not None else 'torch', 'static_part_check': _brief(getattr(model, 'static_part_check', None)), 'graph_vs_eager': gve, 'conv_tuning': conv_tuning,

@@ -457,6 +457,38 @@ int tamtr_xproj_bwd_dx(const float* gu, const float* gdtr, const float* gB, cons
                        void* stream);
 int tamtr_xproj_bwd_dw(const float* u2, const float* gdtr, const float* gB, const float* gC, float* part, int B, int D, int L, int R, void* stream);
 
+/*      The per-layer terms of the RT-DETR loss and the matcher's cost matrix (a-10: ultralytics/models/utils/loss.py:85-166,282-326 - varifocal
+ *      class loss on the matched IoU, 5 x L1, 2 x (1 - RIOU); RIOU: ultralytics/utils/metrics.py:91-130; cost: models/utils/ops.py:84-112), all
+ *      decoder layers of a call stacked, fp32.  pb f32 [Lr, B, nq, 4] (xywh), ps f32 [Lr, B, nq, nc] (logits), gt_bboxes f32 [G, 4], gt_cls i64 [G];
+ *      matched pairs as flat i64 lists li, bi, si, gi [Lr * n] (layer-major, exactly n pairs per layer, a query matched at most once per layer).
+ *      fwd: workspaces tgt i64 [Lr, B, nq] PRESET to nc (no object), score f32 [Lr, B, nq] PRESET to 0, pair_l1 / pair_riou f32 [Lr * n],
+ *           partial f32 [Lr * tamtr_detr_blocks(B * nq)];  out f32 [3, Lr] = (class, bbox, giou) terms, gains and 1 / n applied.
+ *      bwd: up f32 [3, Lr] upstream gradients of `out`; gps f32 [Lr, B, nq, nc] (every element written), gpb f32 [Lr, B, nq, 4] (the matched rows
+ *           written: the caller zero-fills).  RIOU's alpha is a constant (torch.no_grad in the reference); ties of max / min split the gradient.
+ *      match_cost: C f32 [rows = Lr * B * nq, G] = g_class (focal pos - neg) + g_bbox L1 + g_giou (1 - RIOU), non-finite -> 0. */
+int tamtr_detr_blocks(int rows_per_layer);
+int tamtr_detr_layers_fwd(const float* pb, const float* ps, const float* gt_bboxes, const long long* gt_cls, const long long* li, const long long* bi,
+                          const long long* si, const long long* gi, int Lr, int B, int nq, int nc, int n, long long* tgt, float* score, float* pair_l1,
+                          float* pair_riou, float* partial, float g_class, float g_bbox, float g_giou, float* out, void* stream);
+int tamtr_detr_layers_bwd(const float* pb, const float* ps, const float* gt_bboxes, const long long* li, const long long* bi, const long long* si,
+                          const long long* gi, const long long* tgt, const float* score, const float* up, int Lr, int B, int nq, int nc, int n,
+                          float g_class, float g_bbox, float g_giou, float* gpb, float* gps, void* stream);
+int tamtr_detr_match_cost(const float* ps, const float* pb, const float* gt_bboxes, const long long* gt_cls, long long rows, int nc, int G, float g_class,
+                          float g_bbox, float g_giou, float alpha, float gamma, float* C, void* stream);
+
+/*      tamtr_bncl_act_fwd / _bwd with the OUTPUT (forward) / the incoming GRADIENT (backward) laid out as image segments of a wider buffer:
+ *      level i of the MEH token memory `feats` [B, L_0 + L_1 + L_2, hd] is the BatchNorm of its input projection written straight into
+ *      feats[:, off_i : off_i + L_i] (ultralytics/nn/modules/head.py:1087,1202-1219: `input_proj[i]` ... `torch.cat(feats, 1)`), and the
+ *      backward reads d(feats)[:, off_i : off_i + L_i] where it lies - no concatenation copy, no slice copies.
+ *      x (T) [N = B * seg_rows, C] packed; y / gy point at image 0's first row of the segment, image b's rows start b * seg_pitch elements
+ *      further (seg_pitch = (L_0 + L_1 + L_2) * C); C a power of two; everything else as tamtr_bncl_act_fwd / _bwd. */
+int tamtr_bncl_act_seg_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y, long long seg_rows,
+                           long long seg_pitch, float* mean_rstd, float* partials, long long N, int C, float eps, float momentum, int act, int dtype,
+                           void* stream);
+int tamtr_bncl_act_seg_bwd(const void* gy, long long seg_rows, long long seg_pitch, const void* x, const float* gamma, const float* beta,
+                           const float* mean_rstd, void* gx, float* ggamma, float* gbeta, float* partials, long long N, int C, int act, int dtype,
+                           void* stream);
+
 /*      Node census of the graph that `stream` is capturing into (hipStreamGetCaptureInfo_v2 + hipGraphGetNodes): counts[t] = nodes of
  *      hipGraphNodeType t, t < n_types <= 16 (0 kernel, 1 memcpy, 2 memset, ...).  Host-side helper of the HIP-graph replay
  *      (tam-tr_amd/graphs.py: memset nodes do not survive AQL packet capture); TAMTR_EINVAL when the stream is not capturing. */

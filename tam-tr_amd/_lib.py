@@ -10,7 +10,7 @@ from ctypes import c_float, c_int, c_longlong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TAMTR_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libtamtr_hip.so')  # env override: kernel A/B experiments
-ABI_VERSION = 27
+ABI_VERSION = 29
 
 F32, BF16 = 0, 1
 _ERR = {-1: 'TAMTR_EINVAL (bad argument)', -2: 'TAMTR_EUNSUP (shape/dtype outside what the kernels are built for)',
@@ -61,6 +61,12 @@ _SIGS = {
     'tamtr_fold_add': [_P, _P, _P, _P, _I, _LL, _I, _P],
     'tamtr_slab_sum_rows': [_P, _P, _I, _LL, _I, _P],
     'tamtr_graph_capture_census': [_P, _P, _I],
+    'tamtr_bncl_act_seg_fwd': [_P, _P, _P, _P, _P, _P, _LL, _LL, _P, _P, _LL, _I, _F, _F, _I, _I, _P],
+    'tamtr_bncl_act_seg_bwd': [_P, _LL, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _P],
+    'tamtr_detr_blocks': [_I],
+    'tamtr_detr_layers_fwd': [_P] * 8 + [_I] * 5 + [_P] * 5 + [_F, _F, _F, _P, _P],
+    'tamtr_detr_layers_bwd': [_P] * 10 + [_I] * 5 + [_F, _F, _F, _P, _P, _P],
+    'tamtr_detr_match_cost': [_P, _P, _P, _P, _LL, _I, _I, _F, _F, _F, _F, _F, _P, _P],
     'tamtr_xproj_dw_slices': [_I],
     'tamtr_xproj_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'tamtr_xproj_bwd_dx': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

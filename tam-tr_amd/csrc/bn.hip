@@ -307,6 +307,16 @@ __device__ __forceinline__ void fold_row_lanes(const float (&mine)[W], float* s_
 
 // part[c][chunk][3] = rows, mean, M2 of the chunk's rows in column c.  Sums are taken of (x - k), k = the chunk's first row (well
 // conditioned, and a load past the end of the map is redirected to that row: it adds 0).
+// A [N, C] map that lives as B image segments inside a wider buffer (level i of the MEH token memory [B, L_0 + L_1 + L_2, C], head.py:1202-1219:
+// row n = image n / rows, position n % rows): element offset of flat element e (C = 1 << cshift).  rows == 0: not segmented, row pitch ld.
+struct Seg { unsigned rows; size_t pitch; };
+__device__ __forceinline__ size_t seg_addr(size_t e, int C, int cshift, size_t ld, Seg sg) {
+  const size_t row = e >> cshift, col = e & (size_t)(C - 1);
+  if (!sg.rows) return row * ld + col;
+  const unsigned img = (unsigned)row / sg.rows;
+  return (size_t)img * sg.pitch + ((unsigned)row - img * sg.rows) * ld + col;
+}
+
 template <typename T, int V>
 __global__ __launch_bounds__(BN_THREADS) void bncl_stats_kernel(const T* __restrict__ x, float* __restrict__ part, size_t total, int C,
                                                                  int iters) {
@@ -345,7 +355,7 @@ template <typename T, int V>
 __global__ __launch_bounds__(BN_THREADS) void bncl_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean_rstd,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  const T* __restrict__ res, T* __restrict__ y, size_t total, int C, int iters,
-                                                                 int act) {
+                                                                 int act, Seg ysg = Seg{0, 0}, int cshift = 0) {
   const size_t piece = (size_t)BN_THREADS * V, start = (size_t)blockIdx.x * iters * piece, end = min(total, start + iters * piece);
   const int c0 = (threadIdx.x % (C / V)) * V;
   const size_t home = start + c0;   // first row of the chunk: where a load past the end is redirected
@@ -371,7 +381,7 @@ __global__ __launch_bounds__(BN_THREADS) void bncl_apply_kernel(const T* __restr
 #pragma unroll
         for (int j = 0; j < V; ++j) v[u][j] += r[j];
       }
-      if (e < end) Vec<T, V>::st(y + e, v[u]);
+      if (e < end) Vec<T, V>::st(y + (ysg.rows ? seg_addr(e, C, cshift, (size_t)C, ysg) : e), v[u]);
     }
   }
 }
@@ -524,7 +534,7 @@ template <typename T, int V>
 __global__ __launch_bounds__(BN_THREADS) void bncl_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restrict__ x,
                                                                       const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                                       const float* __restrict__ beta, float* __restrict__ part, size_t total,
-                                                                      int C, int iters, int act, size_t ldgy, int cshift) {
+                                                                      int C, int iters, int act, size_t ldgy, int cshift, Seg gsg = Seg{0, 0}) {
   __shared__ float s_acc[BN_THREADS * 2 * V];
   __shared__ float s_col[2 * 1024];
   const size_t piece = (size_t)BN_THREADS * V, start = (size_t)blockIdx.x * iters * piece, end = min(total, start + iters * piece);
@@ -543,7 +553,7 @@ __global__ __launch_bounds__(BN_THREADS) void bncl_bwd_reduce_kernel(const T* __
     for (int u = 0; u < CL_UNROLL; ++u) {
       const size_t e = e0 + (size_t)(it + u) * piece, ee = e < end ? e : home;
       Vec<T, V>::ld(x + ee, xv[u]);
-      Vec<T, V>::ld(gy + (ee >> cshift) * ldgy + (ee & (size_t)(C - 1)), gv[u]);   // gy may be a channel slice of a wider map
+      Vec<T, V>::ld(gy + seg_addr(ee, C, cshift, ldgy, gsg), gv[u]);   // gy may be a channel slice of a wider map
     }
 #pragma unroll
     for (int u = 0; u < CL_UNROLL; ++u) {
@@ -579,7 +589,7 @@ __global__ __launch_bounds__(BN_THREADS) void bncl_bwd_apply_kernel(const T* __r
                                                                      const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                                      const float* __restrict__ beta, const float* __restrict__ sums,
                                                                      T* __restrict__ gx, size_t total, int C, int iters, int act,
-                                                                     float inv_count, size_t ldgy, int cshift) {
+                                                                     float inv_count, size_t ldgy, int cshift, Seg gsg = Seg{0, 0}) {
   const size_t piece = (size_t)BN_THREADS * V, start = (size_t)blockIdx.x * iters * piece, end = min(total, start + iters * piece);
   const int c0 = (threadIdx.x % (C / V)) * V;
   const size_t home = start + c0;   // first row of the chunk: where a load past the end is redirected
@@ -596,7 +606,7 @@ __global__ __launch_bounds__(BN_THREADS) void bncl_bwd_apply_kernel(const T* __r
     for (int u = 0; u < CL_UNROLL; ++u) {
       const size_t e = e0 + (size_t)(it + u) * piece, ee = e < end ? e : home;
       Vec<T, V>::ld(x + ee, xv[u]);
-      Vec<T, V>::ld(gy + (ee >> cshift) * ldgy + (ee & (size_t)(C - 1)), gv[u]);   // gy may be a channel slice of a wider map
+      Vec<T, V>::ld(gy + seg_addr(ee, C, cshift, ldgy, gsg), gv[u]);   // gy may be a channel slice of a wider map
     }
 #pragma unroll
     for (int u = 0; u < CL_UNROLL; ++u) {
@@ -693,9 +703,9 @@ static int bncl_check(const void* a, const void* b, long long N, int C, int dtyp
   return TAMTR_OK;
 }
 
-extern "C" int tamtr_bncl_act_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                  const void* residual, void* y, float* mean_rstd, float* partials, long long N, int C, float eps,
-                                  float momentum, int act, int dtype, void* stream) {
+static int bncl_act_fwd_impl(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             const void* residual, void* y, float* mean_rstd, float* partials, long long N, int C, float eps,
+                             float momentum, int act, int dtype, void* stream, Seg ysg, int cshift) {
   const int rc = bncl_check(x, y, N, C, dtype, act);
   if (rc) return rc;
   if (!gamma || !beta || !mean_rstd || !partials) return TAMTR_EINVAL;
@@ -708,17 +718,36 @@ extern "C" int tamtr_bncl_act_fwd(const void* x, const float* gamma, const float
   else hipLaunchKernelGGL((bncl_stats_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)x, partials, total, C, iters);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_THREADS), 0, s, partials, mean_rstd, running_mean, running_var, S, eps, momentum);
   if (dtype == TAMTR_F32)
-    hipLaunchKernelGGL((bncl_apply_kernel<float, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const float*)x, mean_rstd, gamma, beta, (const float*)residual, (float*)y, total, C, iters, act);
+    hipLaunchKernelGGL((bncl_apply_kernel<float, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const float*)x, mean_rstd, gamma, beta, (const float*)residual, (float*)y, total, C, iters, act, ysg, cshift);
   else if (V == 8)
-    hipLaunchKernelGGL((bncl_apply_kernel<bf16_t, 8>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)x, mean_rstd, gamma, beta, (const bf16_t*)residual, (bf16_t*)y, total, C, iters, act);
+    hipLaunchKernelGGL((bncl_apply_kernel<bf16_t, 8>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)x, mean_rstd, gamma, beta, (const bf16_t*)residual, (bf16_t*)y, total, C, iters, act, ysg, cshift);
   else
-    hipLaunchKernelGGL((bncl_apply_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)x, mean_rstd, gamma, beta, (const bf16_t*)residual, (bf16_t*)y, total, C, iters, act);
+    hipLaunchKernelGGL((bncl_apply_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)x, mean_rstd, gamma, beta, (const bf16_t*)residual, (bf16_t*)y, total, C, iters, act, ysg, cshift);
   return tamtr_launch_status();
 }
 
-extern "C" int tamtr_bncl_act_bwd(const void* gy, long long ldgy, const void* x, const float* gamma, const float* beta,
-                                  const float* mean_rstd, void* gx, float* ggamma, float* gbeta, float* partials, long long N, int C, int act,
-                                  int dtype, void* stream) {
+extern "C" int tamtr_bncl_act_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                  const void* residual, void* y, float* mean_rstd, float* partials, long long N, int C, float eps,
+                                  float momentum, int act, int dtype, void* stream) {
+  return bncl_act_fwd_impl(x, gamma, beta, running_mean, running_var, residual, y, mean_rstd, partials, N, C, eps, momentum, act, dtype, stream,
+                           Seg{0, 0}, 0);
+}
+
+/* the same with the OUTPUT written as image segments of a wider buffer: y points at the first row of image 0's segment, image b's rows
+   start seg_pitch elements further each; N = images * seg_rows rows; C a power of two (see include/tamtr_hip.h) */
+extern "C" int tamtr_bncl_act_seg_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, void* y,
+                                      long long seg_rows, long long seg_pitch, float* mean_rstd, float* partials, long long N, int C, float eps,
+                                      float momentum, int act, int dtype, void* stream) {
+  if (seg_rows <= 0 || N % seg_rows || seg_pitch < seg_rows * C || seg_pitch % 8 || (C & (C - 1)) || seg_rows > 0x7fffffffLL) return TAMTR_EUNSUP;
+  int cshift = 0;
+  while ((1 << cshift) < C) ++cshift;
+  return bncl_act_fwd_impl(x, gamma, beta, running_mean, running_var, nullptr, y, mean_rstd, partials, N, C, eps, momentum, act, dtype, stream,
+                           Seg{(unsigned)seg_rows, (size_t)seg_pitch}, cshift);
+}
+
+static int bncl_act_bwd_impl(const void* gy, long long ldgy, const void* x, const float* gamma, const float* beta,
+                             const float* mean_rstd, void* gx, float* ggamma, float* gbeta, float* partials, long long N, int C, int act,
+                             int dtype, void* stream, Seg gsg) {
   const int rc = bncl_check(gy, x, N, C, dtype, act);
   if (rc) return rc;
   if (ldgy < C || ldgy % bncl_vec(C, dtype) || (C & (C - 1))) return TAMTR_EUNSUP;   // row pitch of gy in elements (C: packed)
@@ -731,19 +760,34 @@ extern "C" int tamtr_bncl_act_bwd(const void* gy, long long ldgy, const void* x,
   float* sums = partials + (size_t)C * S * 2;  // [C][2] after the per-chunk partials
   const float inv = 1.f / (float)N;
   if (dtype == TAMTR_F32)
-    hipLaunchKernelGGL((bncl_bwd_reduce_kernel<float, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const float*)gy, (const float*)x, mean_rstd, gamma, beta, partials, total, C, iters, act, (size_t)ldgy, cshift);
+    hipLaunchKernelGGL((bncl_bwd_reduce_kernel<float, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const float*)gy, (const float*)x, mean_rstd, gamma, beta, partials, total, C, iters, act, (size_t)ldgy, cshift, gsg);
   else if (V == 8)
-    hipLaunchKernelGGL((bncl_bwd_reduce_kernel<bf16_t, 8>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, partials, total, C, iters, act, (size_t)ldgy, cshift);
+    hipLaunchKernelGGL((bncl_bwd_reduce_kernel<bf16_t, 8>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, partials, total, C, iters, act, (size_t)ldgy, cshift, gsg);
   else
-    hipLaunchKernelGGL((bncl_bwd_reduce_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, partials, total, C, iters, act, (size_t)ldgy, cshift);
+    hipLaunchKernelGGL((bncl_bwd_reduce_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, partials, total, C, iters, act, (size_t)ldgy, cshift, gsg);
   hipLaunchKernelGGL(bncl_sum_kernel, dim3(C), dim3(BN_THREADS), 0, s, partials, sums, ggamma, gbeta, S);
   if (dtype == TAMTR_F32)
-    hipLaunchKernelGGL((bncl_bwd_apply_kernel<float, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const float*)gy, (const float*)x, mean_rstd, gamma, beta, sums, (float*)gx, total, C, iters, act, inv, (size_t)ldgy, cshift);
+    hipLaunchKernelGGL((bncl_bwd_apply_kernel<float, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const float*)gy, (const float*)x, mean_rstd, gamma, beta, sums, (float*)gx, total, C, iters, act, inv, (size_t)ldgy, cshift, gsg);
   else if (V == 8)
-    hipLaunchKernelGGL((bncl_bwd_apply_kernel<bf16_t, 8>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, sums, (bf16_t*)gx, total, C, iters, act, inv, (size_t)ldgy, cshift);
+    hipLaunchKernelGGL((bncl_bwd_apply_kernel<bf16_t, 8>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, sums, (bf16_t*)gx, total, C, iters, act, inv, (size_t)ldgy, cshift, gsg);
   else
-    hipLaunchKernelGGL((bncl_bwd_apply_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, sums, (bf16_t*)gx, total, C, iters, act, inv, (size_t)ldgy, cshift);
+    hipLaunchKernelGGL((bncl_bwd_apply_kernel<bf16_t, 4>), dim3(S), dim3(BN_THREADS), 0, s, (const bf16_t*)gy, (const bf16_t*)x, mean_rstd, gamma, beta, sums, (bf16_t*)gx, total, C, iters, act, inv, (size_t)ldgy, cshift, gsg);
   return tamtr_launch_status();
+}
+
+extern "C" int tamtr_bncl_act_bwd(const void* gy, long long ldgy, const void* x, const float* gamma, const float* beta,
+                                  const float* mean_rstd, void* gx, float* ggamma, float* gbeta, float* partials, long long N, int C, int act,
+                                  int dtype, void* stream) {
+  return bncl_act_bwd_impl(gy, ldgy, x, gamma, beta, mean_rstd, gx, ggamma, gbeta, partials, N, C, act, dtype, stream, Seg{0, 0});
+}
+
+/* the same with the incoming gradient read as image segments of a wider buffer (the gradient of tamtr_bncl_act_seg_fwd's output) */
+extern "C" int tamtr_bncl_act_seg_bwd(const void* gy, long long seg_rows, long long seg_pitch, const void* x, const float* gamma, const float* beta,
+                                      const float* mean_rstd, void* gx, float* ggamma, float* gbeta, float* partials, long long N, int C, int act,
+                                      int dtype, void* stream) {
+  if (seg_rows <= 0 || N % seg_rows || seg_pitch < seg_rows * C || seg_pitch % 8 || seg_rows > 0x7fffffffLL) return TAMTR_EUNSUP;
+  return bncl_act_bwd_impl(gy, C, x, gamma, beta, mean_rstd, gx, ggamma, gbeta, partials, N, C, act, dtype, stream,
+                           Seg{(unsigned)seg_rows, (size_t)seg_pitch});
 }
 
 // ---- y = act(bn1(x1) + bn2(x2)): both BatchNorms in training mode over the same [N, C] shape (RepConvN)

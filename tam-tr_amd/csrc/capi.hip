@@ -1,8 +1,8 @@
-// capi.hip - ABI version of libtamtr_hip.so (the kernels live in gate/msdeform/contrastive/selfattn/selscan/gemm_bf16/lsap/cpam/dwconv/ss2d_out/bn/conv3x3/imgaug/fold/optim/xproj.hip).
+// capi.hip - ABI version of libtamtr_hip.so (the kernels live in gate/msdeform/contrastive/selfattn/selscan/gemm_bf16/lsap/cpam/dwconv/ss2d_out/bn/conv3x3/imgaug/fold/optim/xproj/detrloss.hip).
 #include "common.h"
 #include <stdlib.h>
 
-extern "C" int tamtr_abi_version(void) { return 27; }
+extern "C" int tamtr_abi_version(void) { return 29; }
 
 
 // Node census of the graph a stream is currently capturing into: counts[t] = number of nodes of hipGraphNodeType t (t < n_types <= 16).

@@ -69,11 +69,11 @@ class ManbaWorldDecoder(nn.Module):
         hung in its timed loop after three synchronised warm-up steps had passed - so the levels run one after the other.)"""
         # VSS blocks run channels-last ([B,H,W,C], head.py:1136-1140); their outputs stay token-major: the 1x1 input projection
         # is a GEMM over tokens and its result is already in the [B, L, hd] layout of the token memory
-        outs = []
+        toks = []
         for i, (blk, f) in enumerate(zip(self.VSSBlocks, x)):
             f = f.permute(0, 2, 3, 1)
-            outs.append(self._project_level(i, blk(f) if drop_scales is None else blk(f, drop_scales[i])))
-        return torch.cat([o[0] for o in outs], 1), [o[1] for o in outs]
+            toks.append(blk(f) if drop_scales is None else blk(f, drop_scales[i]))
+        return self._get_encoder_input(toks)
 
     def decode(self, feats, shapes, text, batch=None):
         dn_embed, dn_bbox, attn_mask, dn_meta = get_cdn_group(batch, self.nc, self.num_queries,
@@ -110,22 +110,34 @@ class ManbaWorldDecoder(nn.Module):
         return a.to(dtype), valid
 
     def _get_encoder_input(self, toks):
-        """input_proj on channels-last tokens + concatenation over the levels (head.py:1202-1219).  toks: list of [B, H, W, C]."""
+        """input_proj on channels-last tokens + concatenation over the levels (head.py:1202-1219).  toks: list of [B, H, W, C].
+        On the GPU in training mode the three BatchNorms write straight into their segments of the token memory (ops.bn_cat_cl): the
+        550 MB concatenation copy and the slice copies of its gradient do not exist."""
+        ys = [self._project_linear(i, t) for i, t in enumerate(toks)]
+        bns = [p[1] for p in self.input_proj]
+        shapes = [[t.shape[1], t.shape[2]] for t in toks]
+        if ops.bn_cat_cl_ok(ys, bns):
+            return ops.bn_cat_cl(ys, bns, toks[0].shape[0]), shapes
         outs = [self._project_level(i, t) for i, t in enumerate(toks)]
         return torch.cat([o[0] for o in outs], 1), [o[1] for o in outs]
+
+    def _project_linear(self, i, t):
+        """The 1x1 convolution of input_proj[i] as a per-token linear map: t [B, H, W, C] -> [B*H*W, hd] (bf16: the MFMA kernel)."""
+        conv = self.input_proj[i][0]
+        B, H, W, C = t.shape
+        t2 = t.reshape(B * H * W, C)
+        w = conv.weight.view(conv.out_channels, C)
+        if t2.is_cuda and t2.dtype == torch.bfloat16 and C % 64 == 0 and conv.out_channels % 128 == 0:
+            return ops.linear_bf16(t2, w, None)
+        return torch.nn.functional.linear(t2, w.to(t2.dtype))
 
     def _project_level(self, i, t):
         """input_proj[i] (Conv1x1 no bias + BatchNorm, head.py:1087) on channels-last tokens t [B, H, W, C] -> ([B, H*W, hd], [H, W]).
         A 1x1 convolution IS a per-token linear map, so it runs as a [B*H*W, C] x [C, hd] GEMM (bf16: the MFMA kernel) and BatchNorm
         takes its batch statistics over the token axis - no NCHW round trip, no transposing concatenation."""
-        conv, bn = self.input_proj[i][0], self.input_proj[i][1]
+        bn = self.input_proj[i][1]
         B, H, W, C = t.shape
-        t2 = t.reshape(B * H * W, C)
-        w = conv.weight.view(conv.out_channels, C)
-        if t2.is_cuda and t2.dtype == torch.bfloat16 and C % 64 == 0 and conv.out_channels % 128 == 0:
-            y = ops.linear_bf16(t2, w, None)
-        else:
-            y = torch.nn.functional.linear(t2, w.to(t2.dtype))
+        y = self._project_linear(i, t)
         C2 = y.shape[1]
         if y.is_cuda and bn.training and ops.bn_cl_ok(C2, y.dtype):
             y = ops.bn_act(y, bn, False)  # channels-last BatchNorm kernels (csrc/bn.hip)

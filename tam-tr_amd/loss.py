@@ -19,6 +19,10 @@ from .hostio import stager
 _SCIPY_MATCHER = os.environ.get('TAMTR_MATCHER') == 'scipy'  # A/B switch: the reference's host round trip on GPU runs too
 
 
+import os as _os
+_TORCH_LOSS = _os.environ.get('TAMTR_LOSS') == 'torch'   # A/B switch: the elementwise torch form of the loss terms and of the matcher's cost
+
+
 class Matches(list):
     """list of per-image (query_idx, gt_idx) pairs as the reference returns them (models/utils/ops.py:117-119), plus
     `.flat` = (batch_idx, query_idx, gt_idx) device tensors over all images, which is what the loss terms consume."""
@@ -89,19 +93,24 @@ class HungarianMatcher(nn.Module):
         if sum(gt_groups) == 0:
             empty = [[(torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long)) for _ in range(bs)] for _ in range(Lr)]
             return empty if layered else empty[0]
-        ps = pred_scores.detach().float().reshape(-1, nc)
-        ps = (ps.sigmoid() if self.use_fl else ps.softmax(-1))[:, gt_cls]
-        pb = pred_bboxes.detach().float().reshape(-1, 4)
-        if self.use_fl:
-            neg = (1 - self.alpha) * ps ** self.gamma * (-(1 - ps + 1e-8).log())
-            pos = self.alpha * (1 - ps) ** self.gamma * (-(ps + 1e-8).log())
-            c_cls = pos - neg
+        if pred_scores.is_cuda and self.use_fl and not _TORCH_LOSS:
+            from . import ops   # one kernel for the cost matrices of all layers (csrc/detrloss.hip)
+            C = ops.detr_match_cost(pred_scores.detach(), pred_bboxes.detach(), gt_bboxes, gt_cls,
+                                    (self.cost_gain['class'], self.cost_gain['bbox'], self.cost_gain['giou']), self.alpha, self.gamma)
         else:
-            c_cls = -ps
-        c_l1 = (pb.unsqueeze(1) - gt_bboxes.unsqueeze(0)).abs().sum(-1)
-        c_iou = 1.0 - bbox_iou(pb.unsqueeze(1), gt_bboxes.unsqueeze(0), xywh=True, RIOU=True).squeeze(-1)
-        C = self.cost_gain['class'] * c_cls + self.cost_gain['bbox'] * c_l1 + self.cost_gain['giou'] * c_iou
-        C = torch.where(torch.isfinite(C), C, torch.zeros_like(C)).view(Lr, bs, nq, -1)
+            ps = pred_scores.detach().float().reshape(-1, nc)
+            ps = (ps.sigmoid() if self.use_fl else ps.softmax(-1))[:, gt_cls]
+            pb = pred_bboxes.detach().float().reshape(-1, 4)
+            if self.use_fl:
+                neg = (1 - self.alpha) * ps ** self.gamma * (-(1 - ps + 1e-8).log())
+                pos = self.alpha * (1 - ps) ** self.gamma * (-(ps + 1e-8).log())
+                c_cls = pos - neg
+            else:
+                c_cls = -ps
+            c_l1 = (pb.unsqueeze(1) - gt_bboxes.unsqueeze(0)).abs().sum(-1)
+            c_iou = 1.0 - bbox_iou(pb.unsqueeze(1), gt_bboxes.unsqueeze(0), xywh=True, RIOU=True).squeeze(-1)
+            C = self.cost_gain['class'] * c_cls + self.cost_gain['bbox'] * c_l1 + self.cost_gain['giou'] * c_iou
+            C = torch.where(torch.isfinite(C), C, torch.zeros_like(C)).view(Lr, bs, nq, -1)
         groups = [int(n) for n in gt_groups]
         sizes = [min(nq, n) for n in groups]
         res = []
@@ -233,6 +242,10 @@ class DETRLoss(nn.Module):
         n = int(flats[0][0].shape[0])  # matched pairs per layer (every layer matches all boxes: the same count)
         li = torch.arange(Lr, device=dev).repeat_interleave(n)
         bi, si, gi = (torch.cat([f[j] for f in flats]) for j in range(3))
+        if n and pb.is_cuda and self.use_vfl and not _TORCH_LOSS:
+            from . import ops   # the three terms of all layers in three launches (+ two backward): csrc/detrloss.hip
+            return ops.detr_layer_losses(pb, ps, gt_bboxes, gt_cls, li, bi, si, gi, n,
+                                         (self.loss_gain['class'], self.loss_gain['bbox'], self.loss_gain['giou']))
         p_sel, g_sel = pb[li, bi, si].float(), gt_bboxes[gi]
         targets = torch.full((Lr, bs, nq), self.nc, device=dev, dtype=gt_cls.dtype)
         targets[li, bi, si] = gt_cls[gi]

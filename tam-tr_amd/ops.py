@@ -1150,6 +1150,63 @@ def ln_gate(x, xz, gamma, beta, eps=1e-5):
     return _LNGate.apply(x, xz, gamma, beta, eps)
 
 
+# ------------------------------------------------------------------------------------------------ a-10 loss terms (csrc/detrloss.hip)
+class _DetrLayerLosses(torch.autograd.Function):
+    """(class, bbox, giou) terms of all stacked decoder layers of one DETRLoss._layers call (loss.py:85-166,282-326 of the reference's
+    models/utils: varifocal class loss on the matched IoU, 5 x L1, 2 x (1 - RIOU)) in three launches forward and two backward
+    (csrc/detrloss.hip) instead of ~190 elementwise / gather / scatter / reduce launches each way.  fp32; sums in a fixed order."""
+
+    @staticmethod
+    def forward(ctx, pb, ps, gt_bboxes, gt_cls, li, bi, si, gi, n, gains):
+        require_gpu(pb, ps, gt_bboxes, gt_cls, li, bi, si, gi)
+        pb, ps, gt_bboxes = _c(pb.float()), _c(ps.float()), _c(gt_bboxes.float())
+        gt_cls, li, bi, si, gi = (_c(t.long()) for t in (gt_cls, li, bi, si, gi))
+        Lr, B, nq, nc = ps.shape
+        dev = pb.device
+        tgt = torch.empty(Lr, B, nq, device=dev, dtype=torch.int64).fill_(nc)      # (fill kernels, not memsets: tam-tr_amd/graphs.py)
+        score = torch.empty(Lr, B, nq, device=dev, dtype=torch.float32).fill_(0.0)
+        pair = torch.empty(2, Lr * n, device=dev, dtype=torch.float32)
+        partial = torch.empty(Lr * _lib.lib().tamtr_detr_blocks(B * nq), device=dev, dtype=torch.float32)
+        out = torch.empty(3, Lr, device=dev, dtype=torch.float32)
+        gc, gb, gg = (float(v) for v in gains)
+        call('tamtr_detr_layers_fwd', ptr(pb), ptr(ps), ptr(gt_bboxes), ptr(gt_cls), ptr(li), ptr(bi), ptr(si), ptr(gi), Lr, B, nq, nc, n, ptr(tgt),
+             ptr(score), ptr(pair[0]), ptr(pair[1]), ptr(partial), gc, gb, gg, ptr(out), stream_ptr())
+        ctx.save_for_backward(pb, ps, gt_bboxes, li, bi, si, gi, tgt, score)
+        ctx.cfg = (n, gc, gb, gg)
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g_cls, g_box, g_iou):
+        pb, ps, gt_bboxes, li, bi, si, gi, tgt, score = ctx.saved_tensors
+        n, gc, gb, gg = ctx.cfg
+        Lr, B, nq, nc = ps.shape
+        up = torch.stack([g_cls, g_box, g_iou]).float().contiguous()
+        gpb = torch.empty_like(pb).fill_(0.0)
+        gps = torch.empty_like(ps)
+        call('tamtr_detr_layers_bwd', ptr(pb), ptr(ps), ptr(gt_bboxes), ptr(li), ptr(bi), ptr(si), ptr(gi), ptr(tgt), ptr(score), ptr(up), Lr, B, nq, nc, n,
+             gc, gb, gg, ptr(gpb), ptr(gps), stream_ptr())
+        return gpb, gps, None, None, None, None, None, None, None, None
+
+
+def detr_layer_losses(pb, ps, gt_bboxes, gt_cls, li, bi, si, gi, n, gains):
+    """pb [Lr,B,nq,4], ps [Lr,B,nq,nc], flat matched pairs (layer-major, n per layer) -> three [Lr] tensors (class, bbox, giou)."""
+    return _DetrLayerLosses.apply(pb, ps, gt_bboxes, gt_cls, li, bi, si, gi, int(n), tuple(gains))
+
+
+@torch.no_grad()
+def detr_match_cost(ps, pb, gt_bboxes, gt_cls, gains, alpha, gamma):
+    """The Hungarian matcher's cost (models/utils/ops.py:84-112) of all layers at once: ps [Lr,B,nq,nc] logits, pb [Lr,B,nq,4] ->
+    C f32 [Lr, B, nq, G] over the flattened box list, non-finite entries zeroed."""
+    require_gpu(ps, pb, gt_bboxes, gt_cls)
+    Lr, B, nq, nc = ps.shape
+    G = gt_bboxes.shape[0]
+    ps, pb, gt_bboxes, gt_cls = _c(ps.float()), _c(pb.float()), _c(gt_bboxes.float()), _c(gt_cls.long())
+    C = torch.empty(Lr, B, nq, G, device=ps.device, dtype=torch.float32)
+    call('tamtr_detr_match_cost', ptr(ps), ptr(pb), ptr(gt_bboxes), ptr(gt_cls), Lr * B * nq, nc, G, float(gains[0]), float(gains[1]), float(gains[2]),
+         float(alpha), float(gamma), ptr(C), stream_ptr())
+    return C
+
+
 # ------------------------------------------------------------------------------------------------ x_proj of SS2D (csrc/xproj.hip)
 _XPROJ_LIB = _os.environ.get('TAMTR_XPROJ') == 'torch'   # A/B switch: the torch-op form (cast, two batched library GEMMs, stack, ...)
 
@@ -1541,6 +1598,72 @@ class _BN2ActCL(torch.autograd.Function):
         call('tamtr_bncl2_act_bwd', ptr(gy), gy.stride(0), ptr(x1), ptr(x2), ptr(g1), ptr(b1), ptr(g2), ptr(b2), ptr(mr), ptr(gx1), ptr(gx2),
              gg[0].data_ptr(), gg[1].data_ptr(), gg[2].data_ptr(), gg[3].data_ptr(), ptr(part), N, C, act, dtype_code(x1), stream_ptr())
         return (gx1, gg[0].to(dt_g1), gg[1].to(dt_b1), None, None, gx2, gg[2].to(dt_g2), gg[3].to(dt_b2), None, None, None, None, None)
+
+
+class _BNCatCL(torch.autograd.Function):
+    """feats [B, sum L_i, C] = torch.cat([BatchNorm_i(y_i).view(B, L_i, C) for i], 1) with every level's BatchNorm (training mode, no
+    activation) written straight into its segment of the result, and the backward reading its segment of d(feats) where it lies
+    (csrc/bn.hip tamtr_bncl_act_seg_*): the MEH token memory (head.py:1087,1202-1219) without the 550 MB concatenation copy and the three
+    slice copies of its gradient.  y_i [B * L_i, C]; running statistics are updated in place like ops.bn_act."""
+
+    @staticmethod
+    def forward(ctx, B, eps, moms, n, *args):
+        ys, gammas, betas, rms, rvs = (args[k * n:(k + 1) * n] for k in range(5))
+        require_gpu(*ys)
+        ys = [_c(y) for y in ys]
+        C, dt = ys[0].shape[1], ys[0].dtype
+        Ls = [y.shape[0] // B for y in ys]
+        Lt = sum(Ls)
+        feats = torch.empty(B, Lt, C, device=ys[0].device, dtype=dt)
+        saved, off = [], 0
+        for y, ga, be, rm, rv, mom, L in zip(ys, gammas, betas, rms, rvs, moms, Ls):
+            N = B * L
+            g32, b32 = _c(ga.float()), _c(be.float())
+            mr = torch.empty(C, 2, device=y.device, dtype=torch.float32)
+            part = torch.empty(C * _lib.lib().tamtr_bncl_blocks(N, C, dtype_code(y)) * 3, device=y.device, dtype=torch.float32)
+            call('tamtr_bncl_act_seg_fwd', ptr(y), ptr(g32), ptr(b32), ptr(rm), ptr(rv), feats.data_ptr() + off * C * feats.element_size(), L, Lt * C,
+                 ptr(mr), ptr(part), N, C, float(eps), float(mom), 0, dtype_code(y), stream_ptr())
+            saved += [y, g32, b32, mr]
+            off += L
+        ctx.save_for_backward(*saved)
+        ctx.cfg = (B, n, Ls, [g.dtype for g in gammas], [b.dtype for b in betas])
+        return feats
+
+    @staticmethod
+    def backward(ctx, gf):
+        B, n, Ls, gdt, bdt = ctx.cfg
+        saved = ctx.saved_tensors
+        Lt = sum(Ls)
+        C = saved[0].shape[1]
+        gf = _c(gf.to(saved[0].dtype))
+        gxs, ggs, gbs, off = [], [], [], 0
+        for i, L in enumerate(Ls):
+            y, g32, b32, mr = saved[4 * i:4 * i + 4]
+            N = B * L
+            gx = torch.empty_like(y)
+            gg, gb = torch.empty(C, device=y.device, dtype=torch.float32), torch.empty(C, device=y.device, dtype=torch.float32)
+            part = torch.empty(C * _lib.lib().tamtr_bncl_blocks(N, C, dtype_code(y)) * 2 + 2 * C, device=y.device, dtype=torch.float32)
+            call('tamtr_bncl_act_seg_bwd', gf.data_ptr() + off * C * gf.element_size(), L, Lt * C, ptr(y), ptr(g32), ptr(b32), ptr(mr), ptr(gx), ptr(gg),
+                 ptr(gb), ptr(part), N, C, 0, dtype_code(y), stream_ptr())
+            gxs.append(gx); ggs.append(gg.to(gdt[i])); gbs.append(gb.to(bdt[i]))
+            off += L
+        return (None, None, None, None, *gxs, *ggs, *gbs, *([None] * (2 * n)))
+
+
+def bn_cat_cl(ys, bns, B):
+    """The token memory: per level y_i [B * L_i, C] -> BatchNorm_i (training mode, batch statistics, no activation) -> [B, sum L_i, C],
+    each level written into its segment directly.  All BatchNorms share eps; C a power of two."""
+    moms = [_bn_tick(bn) for bn in bns]
+    n = len(ys)
+    return _BNCatCL.apply(int(B), float(bns[0].eps), tuple(float(m) for m in moms), n, *ys, *[bn.weight for bn in bns], *[bn.bias for bn in bns],
+                          *[bn.running_mean for bn in bns], *[bn.running_var for bn in bns])
+
+
+def bn_cat_cl_ok(ys, bns):
+    C = ys[0].shape[1]
+    return (all(y.is_cuda and y.dim() == 2 and y.shape[1] == C and y.dtype == ys[0].dtype and y.dtype in (torch.float32, torch.bfloat16) for y in ys)
+            and C & (C - 1) == 0 and bn_cl_ok(C, ys[0].dtype) and all(bn.training and bn.track_running_stats and bn.affine and bn.eps == bns[0].eps for bn in bns)
+            and _os.environ.get('TAMTR_BN_CAT') != 'torch')
 
 
 _BN_COUNTERS = None

@@ -46,7 +46,12 @@ def assert_close(got, want, rtol=1e-4, atol=1e-5, what=''):
         err = (got[fin] - want[fin]).abs()
         tol = atol + rtol * want[fin].abs()
         bad = err > tol
-        assert not bad.any(), f'{what}: max err {err.max():.3e} (tol {tol[err.argmax()]:.3e}), {int(bad.sum())}/{bad.numel()} off'
+        if bad.any():
+            ratio = (err / tol).flatten()
+            top = torch.topk(ratio, min(6, ratio.numel()))
+            worst = ', '.join(f'{r:.2f}@{want[fin].flatten()[i]:.3g}' for r, i in zip(top.values.tolist(), top.indices.tolist()))
+            raise AssertionError(f'{what}: max err {err.max():.3e} (tol {tol[err.argmax()]:.3e}), {int(bad.sum())}/{bad.numel()} off; '
+                                 f'largest err/tol @ wanted value: {worst}; mean err/tol {ratio.mean():.3f}')
 
 
 def check_summary(fx, prefix, tensor, rtol=1e-4, atol=1e-5, l2rel=None):

@@ -213,11 +213,17 @@ BF16_BOUNDS = {'loss_rel': 7.5e-2, 'dn_term_rel_max': 4e-2, 'dn_box_abs_max': 4e
                'dn_cls_logit_abs_max': 4.0, 'dn_cls_logit_abs_mean': 0.5}
 
 
-def test_full_model_640_fp32_elementwise_with_the_oracles_choices(pkg, case640):
+@pytest.mark.parametrize('mode', ['nhwc', 'deterministic'])
+def test_full_model_640_fp32_elementwise_with_the_oracles_choices(pkg, case640, mode):
     """With the oracle's top-k picks and Hungarian pairs injected, nothing on the path is order- or tie-dependent any more: all 292
-    query rows of all three layers (boxes, class logits), the encoder proposals and the 12 terms are compared ELEMENTWISE at 1e-3."""
+    query rows of all three layers (boxes, class logits), the encoder proposals and the 12 terms are compared ELEMENTWISE at 1e-3.
+    Both trunks: channels-last on MIOpen's default solver set (the benchmarked layout) and NCHW on the deterministic solvers."""
     c = case640
-    loss, items, terms, db, ds, eb, es, meta = _run(c, None, forced=True)
+    if mode == 'deterministic':
+        with _Deterministic(c['model']):
+            loss, items, terms, db, ds, eb, es, meta = _run(c, None, forced=True)
+    else:
+        loss, items, terms, db, ds, eb, es, meta = _run(c, None, forced=True)
     assert abs(loss - float(c['loss'])) <= 1e-3 * abs(float(c['loss'])), (loss, float(c['loss']))
     for k, v in c['terms'].items():
         assert abs(terms[k] - float(v)) <= 1e-3 * abs(float(v)) + 1e-4, (k, terms[k], float(v))

@@ -600,6 +600,42 @@ def test_bn_channels_last_backward_reads_a_channel_slice(ops):
         assert_close(u.float(), v.float(), 1e-6, 1e-6, 'bncl backward, strided vs packed gy')
 
 
+@pytest.mark.parametrize('B,Ls,C,dt', [(3, (400, 100, 25), 256, torch.bfloat16), (2, (77, 30, 9), 64, torch.float32), (1, (640, 160, 40), 256, torch.bfloat16)])
+def test_bn_cat_writes_the_token_memory_in_place(ops, B, Ls, C, dt):
+    """ops.bn_cat_cl = torch.cat([BatchNorm_i(y_i).view(B, L_i, C)], 1) (head.py:1202-1219) with every level written straight into its
+    segment and the backward reading its segment of the gradient in place: the same kernels on other addresses, so every output,
+    running statistic and gradient is BIT-identical to the concatenation of ops.bn_act results."""
+    import copy
+    import torch.nn as nn
+    ys = [(rnd((B * L, C), 10 + i) * (1 + i) - 0.3 * i).to(dt).cuda() for i, L in enumerate(Ls)]
+    bns = []
+    for i in range(len(Ls)):
+        bn = nn.BatchNorm2d(C, eps=1e-5, momentum=0.1).cuda()
+        with torch.no_grad():
+            bn.weight.copy_(1 + 0.3 * rnd((C,), 20 + i).cuda()); bn.bias.copy_(0.2 * rnd((C,), 30 + i).cuda())
+        bns.append(bn)
+    cot = rnd((B, sum(Ls), C), 40).to(dt).cuda()
+    res = []
+    for seg in (False, True):
+        xs = [y.clone().requires_grad_() for y in ys]
+        ms = [copy.deepcopy(bn) for bn in bns]
+        if seg:
+            assert ops.bn_cat_cl_ok(xs, ms)
+            f = ops.bn_cat_cl(xs, ms, B)
+        else:
+            f = torch.cat([ops.bn_act(x, m, False).view(B, L, C) for x, m, L in zip(xs, ms, Ls)], 1)
+        assert f.shape == (B, sum(Ls), C) and f.is_contiguous()
+        (f.float() * cot.float()).sum().backward()
+        res.append([f.detach()] + [x.grad for x in xs] + [m.weight.grad for m in ms] + [m.bias.grad for m in ms]
+                   + [m.running_mean for m in ms] + [m.running_var for m in ms] + [m.num_batches_tracked for m in ms])
+    for k, (u, v) in enumerate(zip(*res)):
+        assert torch.equal(u, v), f'item {k}: segmented and concatenated forms differ by {(u.float() - v.float()).abs().max().item():.3e}'
+    # eval-mode BatchNorms (running statistics) are not this kernel's case
+    for m in bns:
+        m.eval()
+    assert not ops.bn_cat_cl_ok(ys, bns)
+
+
 @pytest.mark.parametrize('scale,dt', [(2.0, torch.bfloat16), (0.5, torch.bfloat16), (2.0, torch.float32), (0.5, torch.float32)])
 def test_nearest_resampling_channels_last(ops, scale, dt):
     """nn.Upsample(scale_factor=2.0 | 0.5, mode='nearest') (TAMTR.yaml layers 11/14/19/22/27/30) on a channels-last map: values
@@ -892,6 +928,51 @@ def test_xproj_kernels_vs_fp32_products_of_the_same_bf16_operands(ops, B, D, L, 
         assert_close(gu2[0][:, i].double(), ref, 1e-6, tol, f'd/d(u2) copy {i}')
         refw = torch.einsum('bml,bdl->md', r16(G), r16(u2[:, i]))
         assert_close(gws[i].double(), refw, 1e-4, 1e-4 * float(refw.abs().max()), f'dWcat copy {i}')
+
+
+@pytest.mark.parametrize('Lr,B,nq,nc,counts', [(4, 16, 100, 10, [8] * 16), (3, 4, 192, 10, [8, 3, 0, 5]), (2, 2, 37, 80, [1, 40]), (1, 3, 50, 7, [2, 2, 2])])
+def test_fused_loss_terms_and_matcher_cost_equal_the_torch_form(Lr, B, nq, nc, counts):
+    """csrc/detrloss.hip against the elementwise torch form of tam-tr_amd/loss.py (which the CPU suite pins on the reference's fixtures:
+    loss / matcher / riou): the matcher's cost matrices of all layers, the assignment that follows from them, the three terms per layer, and
+    their gradients with respect to boxes and logits - ragged box counts incl. an image without boxes, the dn branch's fixed pairs, 80 classes."""
+    import tamtr_amd.loss as LS
+    g = torch.Generator().manual_seed(Lr * 100 + nq)
+    G = sum(counts)
+    pb0 = torch.cat([0.2 + 0.6 * torch.rand(Lr, B, nq, 2, generator=g), 0.03 + 0.3 * torch.rand(Lr, B, nq, 2, generator=g)], -1).cuda()
+    ps0 = (torch.randn(Lr, B, nq, nc, generator=g) * 2 - 3).cuda()
+    gtb = torch.cat([0.2 + 0.6 * torch.rand(G, 2, generator=g), 0.03 + 0.3 * torch.rand(G, 2, generator=g)], -1).cuda()
+    gtc = torch.randint(0, nc, (G,), generator=g).cuda()
+    crit = LS.DETRLoss(nc=nc, use_vfl=True).cuda()
+    out, mats = {}, {}
+    LS._TORCH_LOSS = True
+    try:
+        ms_torch = crit.matcher(pb0, ps0, gtb, gtc, counts)
+    finally:
+        LS._TORCH_LOSS = False
+    for mode in ('torch', 'fused'):
+        LS._TORCH_LOSS = mode == 'torch'
+        try:
+            ms = crit.matcher(pb0, ps0, gtb, gtc, counts)
+            mats[mode] = [m.flat for m in ms]
+            for tag, match in (('hungarian', None), ('fixed', ms_torch[0])):      # `match` given = the dn branch (one pair list for every layer)
+                pb, ps = pb0.clone().requires_grad_(), ps0.clone().requires_grad_()
+                crit.fixed_matches = ms_torch if match is None else None      # the same pairs on both paths
+                terms = crit._layers(pb, ps, gtb, gtc, counts, match)
+                w = torch.arange(1, 3 * Lr + 1, device='cuda', dtype=torch.float32).view(3, Lr) / Lr          # distinct upstream gradients
+                gpb, gps = torch.autograd.grad((torch.stack(terms) * w).sum(), [pb, ps])
+                out[mode, tag] = ([t.detach() for t in terms], gpb, gps)
+        finally:
+            LS._TORCH_LOSS = False
+            crit.fixed_matches = None
+    for a, b in zip(mats['torch'], mats['fused']):
+        assert all(torch.equal(x, y) for x, y in zip(a, b)), 'assignments differ'
+    for tag in ('hungarian', 'fixed'):
+        (tt, bt, st), (tf, bf, sf) = out['torch', tag], out['fused', tag]
+        for name, x, y in zip(('class', 'bbox', 'giou'), tf, tt):
+            assert_close(x, y, 2e-5, 1e-6, f'{tag} {name} terms')
+        assert_close(bf, bt, 2e-4, 2e-6 * float(bt.abs().max()), f'{tag} d/d(boxes)')
+        assert_close(sf, st, 2e-4, 2e-6 * float(st.abs().max()), f'{tag} d/d(logits)')
+        assert int((bf != 0).any(-1).sum()) == int((bt != 0).any(-1).sum())      # exactly the matched rows carry a box gradient
 
 
 # ------------------------------------------------------------------------------------------------ next-3: proj_conv on MFMA
