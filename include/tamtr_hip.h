@@ -211,14 +211,18 @@ int tamtr_selective_scan_bwd(const float* gy, const float* u, const float* delta
  *      (plain stores) and d(Wdt) inside grow (see above); gdelta_ws: caller workspace [B,KD,L] - f32, or bf16 with ws_bf16 = 1 (L % 4 == 0):
  *      d(delta) is only the operand of gdtr = Wdt^T d(delta) there, so in bf16 mode - where the caller rounds gdtr to bf16 anyway - the
  *      workspace, the largest buffer the backward writes and re-reads, can be half the size.
+ *      bf16 PLANES (bf16 mode, L % 4 == 0): with planes_bf16 = 1 (forward) / bit 1 of bf16_flags (backward; bit 0 = the d(delta) workspace
+ *      above, required with it) the big time-indexed operands that cross HBM - u and y in the forward; gy, u and gu in the backward - are
+ *      bf16 arrays of the same shapes.  The recurrence, the states, the checkpoints, dtr / B / C and every gradient sum stay f32: only the
+ *      1.7 GB planes of a level are narrowed (what torch autocast makes of `u` anyway: the depthwise convolution's output is bf16 there).
  */
-int tamtr_selective_scan_dtproj_fwd(const float* u, const float* dtr, const float* Wdt, const float* A, const float* Bm,
-                                    const float* Cm, const float* D, const float* dbias, float* y, float* hstate, int B, int K,
-                                    int Dk, int N, int R, int L, int xmode, void* stream);
-int tamtr_selective_scan_dtproj_bwd(const float* gy, const float* u, const float* dtr, const float* Wdt, const float* A,
+int tamtr_selective_scan_dtproj_fwd(const void* u, const float* dtr, const float* Wdt, const float* A, const float* Bm,
+                                    const float* Cm, const float* D, const float* dbias, void* y, float* hstate, int B, int K,
+                                    int Dk, int N, int R, int L, int xmode, int planes_bf16, void* stream);
+int tamtr_selective_scan_dtproj_bwd(const void* gy, const void* u, const float* dtr, const float* Wdt, const float* A,
                                     const float* Bm, const float* Cm, const float* D, const float* dbias, const float* hstate,
-                                    float* gu, void* gdelta_ws, float* gdtr, float* grow, float* gB, float* gC, float* ws, int B,
-                                    int K, int Dk, int N, int R, int L, int xmode, int ws_bf16, void* stream);
+                                    void* gu, void* gdelta_ws, float* gdtr, float* grow, float* gB, float* gC, float* ws, int B,
+                                    int K, int Dk, int N, int R, int L, int xmode, int bf16_flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * a-10 / next-4  Device-side Hungarian assignment.  Replaces `C.cpu()` + scipy.optimize.linear_sum_assignment per
@@ -264,27 +268,30 @@ int tamtr_cpam_bwd(const void* gout, const void* x, const void* p, const float* 
  *      weight f32 [D, 9] (= conv2d.weight [D, 1, 3, 3]), bias f32 [D] or NULL
  *      u2     f32 [B, 2, D, H*W]: plane 0 = SiLU(conv) flattened row-major (h*W + w), plane 1 column-major (w*H + h)
  *      D % 32 == 0; x_pixel_stride a multiple of 16 bytes.
+ *      plane_dtype: TAMTR_F32, or TAMTR_BF16 (with dtype = TAMTR_BF16 only): u2 / g2 are bf16 arrays of the same shape ("bf16 PLANES",
+ *      tamtr_selective_scan_dtproj_fwd).
  */
-int tamtr_dwconv_silu_cross_fwd(const void* x, long long x_pixel_stride, const float* weight, const float* bias, float* u2, int B,
-                                int D, int H, int W, int dtype, void* stream);
+int tamtr_dwconv_silu_cross_fwd(const void* x, long long x_pixel_stride, const float* weight, const float* bias, void* u2, int B,
+                                int D, int H, int W, int dtype, int plane_dtype, void* stream);
 /*      Backward.  g2 f32 [B, 2, D, H*W] (gradient of u2) ->
  *      gx (T) channels-last, pixel stride gx_pixel_stride (D channels written per pixel),
  *      ws f32 [B, tamtr_dwconv_tiles(H, W), D, 10]: per-tile partial sums of d(weight) (9 taps) and d(bias) (caller sums
  *      over the first two axes; no atomics).
  */
 int tamtr_dwconv_tiles(int H, int W);
-int tamtr_dwconv_silu_cross_bwd(const float* g2, const void* x, long long x_pixel_stride, const float* weight, const float* bias,
-                                void* gx, long long gx_pixel_stride, float* ws, int B, int D, int H, int W, int dtype, void* stream);
+int tamtr_dwconv_silu_cross_bwd(const void* g2, const void* x, long long x_pixel_stride, const float* weight, const float* bias,
+                                void* gx, long long gx_pixel_stride, float* ws, int B, int D, int H, int W, int dtype, int plane_dtype,
+                                void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * a-9  SS2D back end.  tamtr_cross_merge_* replace CrossMerge (VManba/csms6s.py:26-34) and the transposition to channels-last:
  *          ymT[b, h*W+w, d] = y4[b,0,d,h*W+w] + y4[b,2,d,h*W+w] + y4[b,1,d,w*H+h] + y4[b,3,d,w*H+h]
  *      y4 f32 [B, 4, D, H*W] (scan outputs, un-reversed, as tamtr_selective_scan_* with xmode = 1 write them), ymT f32 [B, H*W, D];
  *      backward: gymT f32 [B, H*W, D] -> g2 f32 [B, 2, D, H*W], the gradient in pair layout that the scan backward reads with
- *      xmode = 3.  D % 32 == 0.
+ *      xmode = 3.  D % 32 == 0.  plane_dtype: the element type of y4 / g2 (TAMTR_F32 | TAMTR_BF16, "bf16 PLANES"); ymT / gymT stay f32.
  */
-int tamtr_cross_merge_fwd(const float* y4, float* ymT, int B, int D, int H, int W, void* stream);
-int tamtr_cross_merge_bwd(const float* gymT, float* g2, int B, int D, int H, int W, void* stream);
+int tamtr_cross_merge_fwd(const void* y4, float* ymT, int B, int D, int H, int W, int plane_dtype, void* stream);
+int tamtr_cross_merge_bwd(const float* gymT, void* g2, int B, int D, int H, int W, int plane_dtype, void* stream);
 
 /*      tamtr_ln_gate_* replace `y = self.out_norm(y); y = y * self.act(z)` (VManba/vmamba.py:1005-1008,1029-1036):
  *          out[t, :] = LayerNorm(x[t, :]; gamma, beta, eps) * SiLU(z[t, :]),  z[t, d] = xz[t * xz_token_stride + D + d]
@@ -450,12 +457,15 @@ int tamtr_optim_step(const void* const* p, const void* const* m, const void* con
  *                                   product did in two passes)
  *        part  f32 [B * tamtr_xproj_dw_slices(L), 2, 2C, D]   per-(image, 1 024-pixel slice) partial dWcat tiles; the caller adds them in
  *                                   order (tamtr_slab_sum_rows) and re-splits rows [0, C) / [C, 2C) of copy i into directions i / i + 2
- *      D % 16 == 0 (fwd), % 32 (dx), % 256 and L % 8 == 0 (dw); wcat / wT 16-byte aligned. */
+ *      D % 16 == 0 (fwd), % 32 (dx), % 256 and L % 8 == 0 (dw); wcat / wT 16-byte aligned.
+ *      plane_dtype = TAMTR_BF16 ("bf16 PLANES"): u2, gu and gu2 are bf16 arrays of the same shapes (L % 2 == 0); a lane then handles a pixel
+ *      PAIR (one dword), a wave 64 pixels; dtr / Bs / Cs / gdtr / gB / gC / part stay f32. */
 int tamtr_xproj_dw_slices(int L);
-int tamtr_xproj_fwd(const float* u2, const void* wcat, float* dtr, float* Bs, float* Cs, int B, int D, int L, int R, void* stream);
-int tamtr_xproj_bwd_dx(const float* gu, const float* gdtr, const float* gB, const float* gC, const void* wT, float* gu2, int B, int D, int L, int R,
+int tamtr_xproj_fwd(const void* u2, const void* wcat, float* dtr, float* Bs, float* Cs, int B, int D, int L, int R, int plane_dtype, void* stream);
+int tamtr_xproj_bwd_dx(const void* gu, const float* gdtr, const float* gB, const float* gC, const void* wT, void* gu2, int B, int D, int L, int R,
+                       int plane_dtype, void* stream);
+int tamtr_xproj_bwd_dw(const void* u2, const float* gdtr, const float* gB, const float* gC, float* part, int B, int D, int L, int R, int plane_dtype,
                        void* stream);
-int tamtr_xproj_bwd_dw(const float* u2, const float* gdtr, const float* gB, const float* gC, float* part, int B, int D, int L, int R, void* stream);
 
 /*      The per-layer terms of the RT-DETR loss and the matcher's cost matrix (a-10: ultralytics/models/utils/loss.py:85-166,282-326 - varifocal
  *      class loss on the matched IoU, 5 x L1, 2 x (1 - RIOU); RIOU: ultralytics/utils/metrics.py:91-130; cost: models/utils/ops.py:84-112), all

@@ -10,7 +10,7 @@ from ctypes import c_float, c_int, c_longlong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TAMTR_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libtamtr_hip.so')  # env override: kernel A/B experiments
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 F32, BF16 = 0, 1
 _ERR = {-1: 'TAMTR_EINVAL (bad argument)', -2: 'TAMTR_EUNSUP (shape/dtype outside what the kernels are built for)',
@@ -40,16 +40,16 @@ _SIGS = {
     'tamtr_selective_scan_bwd_slabs': [_I],
     'tamtr_selective_scan_row_sums': [],
     'tamtr_selective_scan_bwd': [_P] * 15 + [_I, _I, _I, _I, _I, _I, _P],
-    'tamtr_selective_scan_dtproj_fwd': [_P] * 10 + [_I] * 7 + [_P],
+    'tamtr_selective_scan_dtproj_fwd': [_P] * 10 + [_I] * 8 + [_P],
     'tamtr_selective_scan_dtproj_bwd': [_P] * 17 + [_I] * 8 + [_P],
     'tamtr_lsap_assign': [_P, _P, _I, _I, _I, _P, _P, _P, _P],
     'tamtr_img_augment_u8': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'tamtr_cpam_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'tamtr_cpam_bwd': [_P] * 8 + [_I, _I, _I, _I, _I, _P],
-    'tamtr_dwconv_silu_cross_fwd': [_P, _LL, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'tamtr_dwconv_silu_cross_fwd': [_P, _LL, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'tamtr_dwconv_tiles': [_I, _I],
-    'tamtr_cross_merge_fwd': [_P, _P, _I, _I, _I, _I, _P],
-    'tamtr_cross_merge_bwd': [_P, _P, _I, _I, _I, _I, _P],
+    'tamtr_cross_merge_fwd': [_P, _P, _I, _I, _I, _I, _I, _P],
+    'tamtr_cross_merge_bwd': [_P, _P, _I, _I, _I, _I, _I, _P],
     'tamtr_ln_gate_blocks': [_LL],
     'tamtr_bn_slices': [_I, _I],
     'tamtr_maxpool_out': [_I, _I, _I, _I],
@@ -68,9 +68,9 @@ _SIGS = {
     'tamtr_detr_layers_bwd': [_P] * 10 + [_I] * 5 + [_F, _F, _F, _P, _P, _P],
     'tamtr_detr_match_cost': [_P, _P, _P, _P, _LL, _I, _I, _F, _F, _F, _F, _F, _P, _P],
     'tamtr_xproj_dw_slices': [_I],
-    'tamtr_xproj_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    'tamtr_xproj_bwd_dx': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    'tamtr_xproj_bwd_dw': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'tamtr_xproj_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'tamtr_xproj_bwd_dx': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'tamtr_xproj_bwd_dw': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'tamtr_optim_chunk': [],
     'tamtr_optim_step': [_P] * 10 + [_I, _I, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _P],
     'tamtr_resample2': [_P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -94,7 +94,7 @@ _SIGS = {
     'tamtr_layernorm_bwd': [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _P],
     'tamtr_ln_gate_fwd': [_P, _P, _LL, _P, _P, _P, _P, _LL, _I, _F, _I, _P],
     'tamtr_ln_gate_bwd': [_P, _P, _P, _LL, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _P],
-    'tamtr_dwconv_silu_cross_bwd': [_P, _P, _LL, _P, _P, _P, _LL, _P, _I, _I, _I, _I, _I, _P],
+    'tamtr_dwconv_silu_cross_bwd': [_P, _P, _LL, _P, _P, _P, _LL, _P, _I, _I, _I, _I, _I, _I, _P],
 }
 EXPORTS = tuple(_SIGS)
 _lib = None

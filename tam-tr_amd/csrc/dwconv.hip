@@ -56,6 +56,18 @@ struct Vec16<bf16_t> {
   }
 };
 
+// one element of a cross-scan plane (u2 / d(u2): f32, or bf16 in the bf16 mode - see include/tamtr_hip.h, "bf16 PLANES")
+__device__ __forceinline__ void plane_st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void plane_st(bf16_t* p, float v) { *p = f2bf(v); }
+__device__ __forceinline__ float plane_ld(const float* p) { return *p; }
+__device__ __forceinline__ float plane_ld(const bf16_t* p) { return bf2f(*p); }
+// four consecutive elements (16- / 8-byte aligned)
+__device__ __forceinline__ float4 plane_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 plane_ld4(const bf16_t* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+}
+
 // stage the (TS + 2*HALO)^2 x CB halo tile of x (channels-last, pixel stride xs elements) into s[c][y][x], zero outside the image
 template <typename T, int CB, int HALO, int PITCH>
 __device__ __forceinline__ void stage_tile(const T* __restrict__ x, size_t xs, int b, int d0, int h0, int w0, int H, int W,
@@ -87,9 +99,9 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ x, size_t xs, i
   }
 }
 
-template <typename T>
+template <typename T, typename PT>
 __global__ __launch_bounds__(DW_THREADS) void dwconv_cross_fwd_kernel(const T* __restrict__ x, size_t xs, const float* __restrict__ wgt,
-                                                                       const float* __restrict__ bias, float* __restrict__ u2, int D,
+                                                                       const float* __restrict__ bias, PT* __restrict__ u2, int D,
                                                                        int H, int W, int tiles_w) {
   constexpr int CB = CB_FWD, SIDE = TS + 2, PITCH = SIDE + 1;
   __shared__ float s_in[CB][SIDE][PITCH];
@@ -110,20 +122,20 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_cross_fwd_kernel(const T* _
     const int tx = pass == 0 ? threadIdx.x % TS : threadIdx.x / TS;
     const int h = h0 + ty, w = w0 + tx;
     if (h >= H || w >= W) continue;
-    float* out = u2 + ((size_t)(b * 2 + pass) * D + d0) * L + (pass == 0 ? (size_t)h * W + w : (size_t)w * H + h);
+    PT* out = u2 + ((size_t)(b * 2 + pass) * D + d0) * L + (pass == 0 ? (size_t)h * W + w : (size_t)w * H + h);
     for (int c = 0; c < CB; ++c) {
       float acc = s_w[c][9];
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) acc = fmaf(s_w[c][ky * 3 + kx], s_in[c][ty + ky][tx + kx], acc);
-      out[(size_t)c * L] = silu_f(acc);
+      plane_st(out + (size_t)c * L, silu_f(acc));
     }
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(DW_THREADS) void dwconv_cross_bwd_kernel(const float* __restrict__ g2, const T* __restrict__ x, size_t xs,
+template <typename T, typename PT>
+__global__ __launch_bounds__(DW_THREADS) void dwconv_cross_bwd_kernel(const PT* __restrict__ g2, const T* __restrict__ x, size_t xs,
                                                                        const float* __restrict__ wgt, const float* __restrict__ bias,
                                                                        T* __restrict__ gx, size_t gxs, float* __restrict__ ws, int D,
                                                                        int H, int W, int tiles_w, int tiles) {
@@ -154,7 +166,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_cross_bwd_kernel(const floa
     constexpr int NV = 6, ITEMS_V = CB * GS * NV, N_ITV = (ITEMS_V + DW_THREADS - 1) / DW_THREADS;
 #pragma unroll
     for (int plane = 0; plane < 2; ++plane) {
-      const float* gp = g2 + ((size_t)(b * 2 + plane) * D + d0) * L;
+      const PT* gp = g2 + ((size_t)(b * 2 + plane) * D + d0) * L;
       float4 v[N_ITV];
 #pragma unroll
       for (int k = 0; k < N_ITV; ++k) {
@@ -164,7 +176,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_cross_bwd_kernel(const floa
         const int fixed = (plane == 0 ? h0 : w0) + line - 1, base = (plane == 0 ? w0 : h0) - 4 + 4 * q;
         const int nfix = plane == 0 ? H : W, nrun = plane == 0 ? W : H;
         const bool ok = fixed >= 0 && fixed < nfix && base >= 0 && base + 3 < nrun;
-        const float4 t = *reinterpret_cast<const float4*>(gp + (size_t)c * L + (size_t)min(max(fixed, 0), nfix - 1) * nrun + min(max(base, 0), nrun - 4));
+        const float4 t = plane_ld4(gp + (size_t)c * L + (size_t)min(max(fixed, 0), nfix - 1) * nrun + min(max(base, 0), nrun - 4));
         const float f = ok ? 1.f : 0.f;
         v[k] = make_float4(t.x * f, t.y * f, t.z * f, t.w * f);
       }
@@ -189,7 +201,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_cross_bwd_kernel(const floa
   } else {
   {
     constexpr int GB = 7, N_IT = ((CB * GS * GS + DW_THREADS - 1) / DW_THREADS + GB - 1) / GB * GB;   // whole batches (extra trips load a clamped item and write nothing)
-    const float* gp = g2 + ((size_t)(b * 2 + 0) * D + d0) * L;
+    const PT* gp = g2 + ((size_t)(b * 2 + 0) * D + d0) * L;
 #pragma unroll 1
     for (int k0 = 0; k0 < N_IT; k0 += GB) {
       float v[GB];
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_cross_bwd_kernel(const floa
         const int c = it / (GS * GS), r = it - c * (GS * GS), py = r / GS, px = r - py * GS;
         const int h = h0 + py - 1, w = w0 + px - 1;
         const bool ok = h >= 0 && h < H && w >= 0 && w < W;
-        v[k] = gp[(size_t)c * L + (size_t)min(max(h, 0), H - 1) * W + min(max(w, 0), W - 1)] * (ok ? 1.f : 0.f);
+        v[k] = plane_ld(gp + (size_t)c * L + (size_t)min(max(h, 0), H - 1) * W + min(max(w, 0), W - 1)) * (ok ? 1.f : 0.f);
       }
 #pragma unroll
       for (int k = 0; k < GB; ++k) {
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_cross_bwd_kernel(const floa
   __syncthreads();
   {
     constexpr int GB = 7, N_IT = ((CB * GS * GS + DW_THREADS - 1) / DW_THREADS + GB - 1) / GB * GB;   // whole batches (extra trips load a clamped item and write nothing)
-    const float* gp = g2 + ((size_t)(b * 2 + 1) * D + d0) * L;
+    const PT* gp = g2 + ((size_t)(b * 2 + 1) * D + d0) * L;
 #pragma unroll 1
     for (int k0 = 0; k0 < N_IT; k0 += GB) {
       float v[GB];
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv_cross_bwd_kernel(const floa
         const int c = it / (GS * GS), r = it - c * (GS * GS), px = r / GS, py = r - px * GS;
         const int h = h0 + py - 1, w = w0 + px - 1;
         const bool ok = h >= 0 && h < H && w >= 0 && w < W;
-        v[k] = gp[(size_t)c * L + (size_t)min(max(w, 0), W - 1) * H + min(max(h, 0), H - 1)] * (ok ? 1.f : 0.f);
+        v[k] = plane_ld(gp + (size_t)c * L + (size_t)min(max(w, 0), W - 1) * H + min(max(h, 0), H - 1)) * (ok ? 1.f : 0.f);
       }
 #pragma unroll
       for (int k = 0; k < GB; ++k) {
@@ -323,38 +335,47 @@ static int dwconv_check(const void* a, const void* b, const void* c, int B, int 
   return TAMTR_OK;
 }
 
-extern "C" int tamtr_dwconv_silu_cross_fwd(const void* x, long long x_pixel_stride, const float* weight, const float* bias, float* u2,
-                                           int B, int D, int H, int W, int dtype, void* stream) {
+extern "C" int tamtr_dwconv_silu_cross_fwd(const void* x, long long x_pixel_stride, const float* weight, const float* bias, void* u2,
+                                           int B, int D, int H, int W, int dtype, int plane_dtype, void* stream) {
   const int rc = dwconv_check(x, weight, u2, B, D, H, W, x_pixel_stride, dtype);
   if (rc) return rc;
+  if (plane_dtype != TAMTR_F32 && !(plane_dtype == TAMTR_BF16 && dtype == TAMTR_BF16)) return TAMTR_EINVAL;
   const int tiles_w = (W + TS - 1) / TS, tiles_h = (H + TS - 1) / TS;
   const dim3 grid(tiles_w * tiles_h, D / CB_FWD, B);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == TAMTR_F32)
-    hipLaunchKernelGGL(dwconv_cross_fwd_kernel<float>, grid, dim3(DW_THREADS), 0, s, (const float*)x, (size_t)x_pixel_stride, weight, bias,
-                       u2, D, H, W, tiles_w);
+    hipLaunchKernelGGL((dwconv_cross_fwd_kernel<float, float>), grid, dim3(DW_THREADS), 0, s, (const float*)x, (size_t)x_pixel_stride, weight, bias,
+                       (float*)u2, D, H, W, tiles_w);
+  else if (plane_dtype == TAMTR_F32)
+    hipLaunchKernelGGL((dwconv_cross_fwd_kernel<bf16_t, float>), grid, dim3(DW_THREADS), 0, s, (const bf16_t*)x, (size_t)x_pixel_stride, weight,
+                       bias, (float*)u2, D, H, W, tiles_w);
   else
-    hipLaunchKernelGGL(dwconv_cross_fwd_kernel<bf16_t>, grid, dim3(DW_THREADS), 0, s, (const bf16_t*)x, (size_t)x_pixel_stride, weight,
-                       bias, u2, D, H, W, tiles_w);
+    hipLaunchKernelGGL((dwconv_cross_fwd_kernel<bf16_t, bf16_t>), grid, dim3(DW_THREADS), 0, s, (const bf16_t*)x, (size_t)x_pixel_stride, weight,
+                       bias, (bf16_t*)u2, D, H, W, tiles_w);
   return tamtr_launch_status();
 }
 
 extern "C" int tamtr_dwconv_tiles(int H, int W) { return ((W + TS - 1) / TS) * ((H + TS - 1) / TS); }
 
-extern "C" int tamtr_dwconv_silu_cross_bwd(const float* g2, const void* x, long long x_pixel_stride, const float* weight, const float* bias,
+extern "C" int tamtr_dwconv_silu_cross_bwd(const void* g2, const void* x, long long x_pixel_stride, const float* weight, const float* bias,
                                            void* gx, long long gx_pixel_stride, float* ws, int B, int D, int H, int W, int dtype,
-                                           void* stream) {
+                                           int plane_dtype, void* stream) {
   const int rc = dwconv_check(x, weight, g2, B, D, H, W, x_pixel_stride, dtype);
   if (rc) return rc;
   if (!gx || !ws || gx_pixel_stride < D || gx_pixel_stride % (dtype == TAMTR_F32 ? 4 : 8)) return TAMTR_EINVAL;
+  if (plane_dtype != TAMTR_F32 && !(plane_dtype == TAMTR_BF16 && dtype == TAMTR_BF16)) return TAMTR_EINVAL;
+  if ((uintptr_t)g2 % 16) return TAMTR_EUNSUP;
   const int tiles_w = (W + TS - 1) / TS, tiles_h = (H + TS - 1) / TS;
   const dim3 grid(tiles_w * tiles_h, D / CB_BWD, B);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == TAMTR_F32)
-    hipLaunchKernelGGL(dwconv_cross_bwd_kernel<float>, grid, dim3(DW_THREADS), 0, s, g2, (const float*)x, (size_t)x_pixel_stride, weight,
-                       bias, (float*)gx, (size_t)gx_pixel_stride, ws, D, H, W, tiles_w, tiles_w * tiles_h);
+    hipLaunchKernelGGL((dwconv_cross_bwd_kernel<float, float>), grid, dim3(DW_THREADS), 0, s, (const float*)g2, (const float*)x, (size_t)x_pixel_stride,
+                       weight, bias, (float*)gx, (size_t)gx_pixel_stride, ws, D, H, W, tiles_w, tiles_w * tiles_h);
+  else if (plane_dtype == TAMTR_F32)
+    hipLaunchKernelGGL((dwconv_cross_bwd_kernel<bf16_t, float>), grid, dim3(DW_THREADS), 0, s, (const float*)g2, (const bf16_t*)x,
+                       (size_t)x_pixel_stride, weight, bias, (bf16_t*)gx, (size_t)gx_pixel_stride, ws, D, H, W, tiles_w, tiles_w * tiles_h);
   else
-    hipLaunchKernelGGL(dwconv_cross_bwd_kernel<bf16_t>, grid, dim3(DW_THREADS), 0, s, g2, (const bf16_t*)x, (size_t)x_pixel_stride, weight,
-                       bias, (bf16_t*)gx, (size_t)gx_pixel_stride, ws, D, H, W, tiles_w, tiles_w * tiles_h);
+    hipLaunchKernelGGL((dwconv_cross_bwd_kernel<bf16_t, bf16_t>), grid, dim3(DW_THREADS), 0, s, (const bf16_t*)g2, (const bf16_t*)x,
+                       (size_t)x_pixel_stride, weight, bias, (bf16_t*)gx, (size_t)gx_pixel_stride, ws, D, H, W, tiles_w, tiles_w * tiles_h);
   return tamtr_launch_status();
 }

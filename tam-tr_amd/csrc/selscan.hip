@@ -71,10 +71,29 @@ constexpr unsigned OOB = 0x7ffffff0u;  // byte offset no row reaches: the access
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float* rowp, int L) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rowp), 0, L * 4, 0x00020000);
 }
-template <bool VEC>
+// P16: the row is a row of bf16 (the u / y / d(y) / d(u) planes of the bf16 mode: the recurrence itself stays fp32, only what crosses
+// HBM is narrowed); 4 steps = 8 bytes per lane, vector path only.  `rowp` is then a bf16 pointer in disguise (plane_row below).
+template <bool P16>
+__device__ __forceinline__ const float* plane_row(const float* base, size_t elems) {
+  return P16 ? reinterpret_cast<const float*>(reinterpret_cast<const bf16_t*>(base) + elems) : base + elems;
+}
+template <bool P16>
+__device__ __forceinline__ float* plane_row(float* base, size_t elems) {
+  return P16 ? reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(base) + elems) : base + elems;
+}
+template <bool VEC, bool P16 = false>
 __device__ __forceinline__ Raw4 load4_issue(const float* __restrict__ rowp, int t, int L, bool rev) {
-  const __amdgpu_buffer_rsrc_t rs = row_rsrc(rowp, L);
   Raw4 r;
+  if constexpr (P16) {
+    static_assert(VEC, "bf16 planes: L % 4 == 0 only");
+    const __amdgpu_buffer_rsrc_t rs16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rowp), 0, L * 2, 0x00020000);
+    const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs16, t < L ? (rev ? L - 4 - t : t) * 2 : OOB, 0, 0);
+    static_assert(sizeof(v) == 8, "64-bit buffer load");
+    __builtin_memcpy(r.v, &v, 8);
+    r.v[2] = r.v[3] = 0.f;
+    return r;
+  }
+  const __amdgpu_buffer_rsrc_t rs = row_rsrc(rowp, L);
   if (VEC) {  // L % 4 == 0 and t % 4 == 0: all-or-nothing
     // (the builtin's 128-bit result type is whatever this clang gives it: moved by memcpy, not converted - a conversion to a
     // 4 x u32 vector type compiled to a ONE-dword load splat over the four elements)
@@ -88,13 +107,23 @@ __device__ __forceinline__ Raw4 load4_issue(const float* __restrict__ rowp, int 
   }
   return r;
 }
-template <bool VEC>
+template <bool VEC, bool P16 = false>
 __device__ __forceinline__ void load4_take(const Raw4& r, float (&o)[ITEMS], bool rev) {
+  if constexpr (P16) {
+    const unsigned w0 = __builtin_bit_cast(unsigned, r.v[0]), w1 = __builtin_bit_cast(unsigned, r.v[1]);
+    const float q[ITEMS] = {__builtin_bit_cast(float, w0 << 16), __builtin_bit_cast(float, w0 & 0xffff0000u),
+                            __builtin_bit_cast(float, w1 << 16), __builtin_bit_cast(float, w1 & 0xffff0000u)};
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) o[i] = rev ? q[ITEMS - 1 - i] : q[i];
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) o[i] = VEC ? (rev ? r.v[ITEMS - 1 - i] : r.v[i]) : r.v[i];
 }
-template <bool VEC>
+__device__ __forceinline__ void store4_bf16(bf16_t* __restrict__ rowp, int t, int L, const float (&v)[ITEMS], bool rev);
+template <bool VEC, bool P16 = false>
 __device__ __forceinline__ void store4(float* __restrict__ rowp, int t, int L, const float (&v)[ITEMS], bool rev) {
+  if constexpr (P16) { store4_bf16(reinterpret_cast<bf16_t*>(rowp), t, L, v, rev); return; }
   const __amdgpu_buffer_rsrc_t rs = row_rsrc(rowp, L);
   if (VEC) {
     float o[ITEMS];
@@ -367,7 +396,7 @@ __device__ __forceinline__ void dtproj_row(const float* __restrict__ Wrow, const
 // are 40 % of the forward's issue time at 4: the product runs IT = 8 (512-step chunks, 64 KB of B/C tiles: one workgroup of NW = 16
 // waves per CU instead of three of 8 - the same four waves per SIMD).  IT = 4 / NW = 8 remains for sequence lengths that are not a
 // multiple of 4.
-template <bool VEC, bool DTR, int IT, int NW>  // DTR: fused dt projection (delta formed in-kernel from dtr and Wdt) vs a materialised delta
+template <bool VEC, bool DTR, int IT, int NW, bool P16 = false>  // DTR: fused dt projection (delta formed in-kernel from dtr and Wdt) vs a materialised delta; P16: u and y are bf16 planes
 __global__ __launch_bounds__(NW* WAVE) void selscan_fwd_kernel(const float* __restrict__ u, const float* __restrict__ delta,
                                                                const float* __restrict__ Am, const float* __restrict__ Bm,
                                                                const float* __restrict__ Cm, const float* __restrict__ Dv,
@@ -405,7 +434,7 @@ __global__ __launch_bounds__(NW* WAVE) void selscan_fwd_kernel(const float* __re
   }
   const int nrow = min(FWD_RPW, Dk - d0);  // rows this wave really has (<= 0: none)
   // row d's operand rows (d clamped: a row past the end is loaded like the last one and never used)
-  auto urow = [&](int d) { d = min(d, Dk - 1); return xmode ? u + (((size_t)b * 2 + (k & 1)) * Dk + d) * L : u + (((size_t)b * K + k) * Dk + d) * L; };
+  auto urow = [&](int d) { d = min(d, Dk - 1); return plane_row<P16>(u, xmode ? (((size_t)b * 2 + (k & 1)) * Dk + d) * L : (((size_t)b * K + k) * Dk + d) * L); };
   auto drow = [&](int d) { return delta + (((size_t)b * K + k) * Dk + min(d, Dk - 1)) * L; };
 
 #ifndef SCAN_FPRIO
@@ -425,7 +454,7 @@ __global__ __launch_bounds__(NW* WAVE) void selscan_fwd_kernel(const float* __re
     Raw4 n_uu[H], n_dl[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-      n_uu[h] = load4_issue<VEC>(urow(d0), t + 4 * h, L, rev);
+      n_uu[h] = load4_issue<VEC, P16>(urow(d0), t + 4 * h, L, rev);
       n_dl[h] = n_uu[h];
       if (!DTR) n_dl[h] = load4_issue<VEC>(drow(d0), t + 4 * h, L, rev);
     }
@@ -439,13 +468,13 @@ __global__ __launch_bounds__(NW* WAVE) void selscan_fwd_kernel(const float* __re
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         float q4[ITEMS];
-        load4_take<VEC>(n_uu[h], q4, rev);
+        load4_take<VEC, P16>(n_uu[h], q4, rev);
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) uu[4 * h + i] = q4[i];
-        load4_take<VEC>(n_dl[h], q4, rev);
+        if (!DTR) load4_take<VEC>(n_dl[h], q4, rev);
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) dt[4 * h + i] = DTR ? 0.f : q4[i];
-        n_uu[h] = load4_issue<VEC>(urow(d + 1), t + 4 * h, L, rev);  // next row's streams, in flight behind this row's arithmetic
+        n_uu[h] = load4_issue<VEC, P16>(urow(d + 1), t + 4 * h, L, rev);  // next row's streams, in flight behind this row's arithmetic
         if (!DTR) n_dl[h] = load4_issue<VEC>(drow(d + 1), t + 4 * h, L, rev);
       }
       const float par = s_par[wr * 32 + (lane & 31)];
@@ -517,7 +546,7 @@ __global__ __launch_bounds__(NW* WAVE) void selscan_fwd_kernel(const float* __re
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         const float q4[ITEMS] = {yy[4 * h], yy[4 * h + 1], yy[4 * h + 2], yy[4 * h + 3]};
-        store4<VEC>(y + row * L, t + 4 * h, L, q4, rev);
+        store4<VEC, P16>(plane_row<P16>(y, row * L), t + 4 * h, L, q4, rev);
       }
       if (lane < NS) s_h[wr * NS + lane] = nh;
     }
@@ -541,13 +570,13 @@ __global__ __launch_bounds__(NW* WAVE) void selscan_fwd_kernel(const float* __re
 constexpr int ACC = 64;
 
 // u, gy of one row for one chunk
-template <bool VEC>
+template <bool VEC, bool P16 = false>
 __device__ __forceinline__ void bwd_fetch_row(const float* __restrict__ u, const float* __restrict__ gy, int b, int K, int k, int Dk,
                                               int d, int L, int t, bool rev, int xmode, Raw4& uu, Raw4& g) {
   const size_t row = ((size_t)b * K + k) * Dk + d;
   const size_t prow = ((size_t)b * 2 + (k & 1)) * Dk + d;
-  uu = load4_issue<VEC>(xmode ? u + prow * L : u + row * L, t, L, rev);
-  g = load4_issue<VEC>((xmode & 2) ? gy + prow * L : gy + row * L, t, L, rev);
+  uu = load4_issue<VEC, P16>(plane_row<P16>(u, (xmode ? prow : row) * L), t, L, rev);
+  g = load4_issue<VEC, P16>(plane_row<P16>(gy, ((xmode & 2) ? prow : row) * L), t, L, rev);
 }
 // the row's small operands in ONE register: lane n < 16: A[kd][n]; lane 16: D[kd]; lane 17: delta bias.  Read back per state with
 // v_readlane (wave-uniform operands of the VALU ops).
@@ -617,7 +646,8 @@ __device__ __forceinline__ float row_shr(float old, float v, int k) {
 // SETS: 16-value sets of d(Wdt) factors per row (0: materialised delta, no dt projection; 1: rank <= 16; 2: rank <= 32)
 // GD16: d(delta) is written as bf16 (dt-projection variant in bf16 mode: it is only the operand of gdtr = Wdt^T gdelta, whose result
 // the caller rounds to bf16 anyway; halves the 5.9 GB per step that this workspace is written and read)
-template <bool VEC, int SETS, bool GD16 = false>
+// P16: gy, u and gu are bf16 planes (bf16 mode, see load4_issue)
+template <bool VEC, int SETS, bool GD16 = false, bool P16 = false>
 __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
     const float* __restrict__ gy, const float* __restrict__ u, const float* __restrict__ delta, const float* __restrict__ Am,
     const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ Dv, const float* __restrict__ dbias,
@@ -687,7 +717,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
     float n_par, n_ck;
     {
       const int dd = min(d0, dlast);
-      bwd_fetch_row<VEC>(u, gy, b, K, k, Dk, dd, L, t, rev, xmode, n_uu, n_g);
+      bwd_fetch_row<VEC, P16>(u, gy, b, K, k, Dk, dd, L, t, rev, xmode, n_uu, n_g);
       n_par = bwd_fetch_param(Am, Dv, dbias, k * Dk + dd, lane);
       n_ck = bwd_fetch_ck(hstate, ((size_t)b * K + k) * Dk + dd, nblk, c, lane);
       n_dl = n_uu;
@@ -719,14 +749,14 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
       const float m0 = lane == 0 ? 1.f : 0.f;           // the lane that comes last in time: where the next chunk's carry enters
       {
         float dl[ITEMS];
-        load4_take<VEC>(n_uu, uu, rev);
-        load4_take<VEC>(n_g, g, rev);
-        load4_take<VEC>(n_dl, dl, rev);
+        load4_take<VEC, P16>(n_uu, uu, rev);
+        load4_take<VEC, P16>(n_g, g, rev);
+        if (!DTR) load4_take<VEC>(n_dl, dl, rev);
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) { S[i] = 0.f; ddtA[i] = 0.f; if (DTR) dl[i] = 0.f; }
         {  // next row's streams, in flight behind this row's arithmetic
           const int dn = min(d + 1, dlast);
-          bwd_fetch_row<VEC>(u, gy, b, K, k, Dk, dn, L, t, rev, xmode, n_uu, n_g);
+          bwd_fetch_row<VEC, P16>(u, gy, b, K, k, Dk, dn, L, t, rev, xmode, n_uu, n_g);
           n_par = bwd_fetch_param(Am, Dv, dbias, k * Dk + dn, lane);
           n_ck = bwd_fetch_ck(hstate, ((size_t)b * K + k) * Dk + dn, nblk, c, lane);
           if (!DTR) n_dl = load4_issue<VEC>(delta + (((size_t)b * K + k) * Dk + dn) * L, t, L, rev);
@@ -822,7 +852,7 @@ __global__ __launch_bounds__(BWD_WAVES* WAVE, 2) void selscan_bwd_kernel(
         dbs += gd[i];
         dD = fmaf(g[i], uu[i], dD);
       }
-      store4<VEC>(gu + row * L, t, L, du, rev);  // gu is always [B, K*Dk, L]; the host folds direction pairs in xmode
+      store4<VEC, P16>(plane_row<P16>(gu, row * L), t, L, du, rev);  // gu is always [B, K*Dk, L]; the host folds direction pairs in xmode
       if (GD16) store4_bf16(reinterpret_cast<bf16_t*>(gdelta) + row * L, t, L, gd, rev);
       else store4<VEC>(gdelta + row * L, t, L, gd, rev);
       // ---- per-row sums over the chunk's steps by reduce-scatter, two sets of 16 values at a time: the 16 dA_n travel with the
@@ -1055,11 +1085,12 @@ extern "C" int tamtr_selective_scan_bwd_slabs(int Dk) { return Dk > 0 ? (Dk + BW
 
 static int scan_fwd_launch(const float* u, const float* delta, const float* dtr, const float* Wdt, int R, const float* A,
                            const float* Bm, const float* Cm, const float* D, const float* dbias, float* y, float* hstate, int B,
-                           int K, int Dk, int N, int L, int xmode, void* stream) {
+                           int K, int Dk, int N, int L, int xmode, void* stream, int p16 = 0) {
   if (!u || (!delta && !dtr) || (dtr && !Wdt) || !A || !Bm || !Cm || !D || !dbias || !y || !hstate || B <= 0 || K <= 0 || Dk <= 0 ||
       L <= 0)
     return TAMTR_EINVAL;
   if (xmode != 0 && xmode != 1) return TAMTR_EINVAL;
+  if (p16 && (!dtr || L % 4 || ((uintptr_t)u | (uintptr_t)y) % 8)) return TAMTR_EUNSUP;   // bf16 planes: the dt-projection form on the vector path
   if (N != NS || (long long)B * K > 65535 || (xmode && K != 4) || (dtr && (R < 1 || R > RMAX))) return TAMTR_EUNSUP;
   hipStream_t s = (hipStream_t)stream;
   if (!dtr) R = 0;
@@ -1080,12 +1111,19 @@ static int scan_fwd_launch(const float* u, const float* delta, const float* dtr,
   const int nchunk = (L + ch - 1) / ch;
   dim3 grid((Dk + nw * FWD_RPW - 1) / (nw * FWD_RPW), B * K);
   const size_t dyn = ((size_t)2 * NS * ch + (size_t)R * ch + (size_t)nw * FWD_RPW * (RMAX + 32 + NS)) * sizeof(float);
-#define LAUNCH_FWD(VEC, DTR, IT, NW)                                                                                                   \
+#define LAUNCH_FWD(VEC, DTR, IT, NW) LAUNCH_FWD_(VEC, DTR, IT, NW, false)
+#define LAUNCH_FWD_(VEC, DTR, IT, NW, P16)                                                                                             \
   {                                                                                                                                    \
-    auto kern = selscan_fwd_kernel<VEC, DTR, IT, NW>;                                                                                  \
+    auto kern = selscan_fwd_kernel<VEC, DTR, IT, NW, P16>;                                                                             \
     if (dyn > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess)  \
       return TAMTR_ELAUNCH; /* (per call: the attribute belongs to the current device) */                                              \
     hipLaunchKernelGGL(kern, grid, dim3(NW * WAVE), dyn, s, u, delta, A, Bm, Cm, D, dbias, y, hstate, K, Dk, L, nchunk, xmode, dtr, Wdt, R); \
+  }
+  if (p16) {
+    if (it8 && wide) LAUNCH_FWD_(true, true, 2 * ITEMS, 2 * FWD_ROWS, true)
+    else if (it8) LAUNCH_FWD_(true, true, 2 * ITEMS, FWD_ROWS, true)
+    else LAUNCH_FWD_(true, true, ITEMS, FWD_ROWS, true)
+    return tamtr_launch_status();
   }
   if (it8 && wide) { if (dtr) LAUNCH_FWD(true, true, 2 * ITEMS, 2 * FWD_ROWS) else LAUNCH_FWD(true, false, 2 * ITEMS, 2 * FWD_ROWS) }
   if (it8 && !wide) { if (dtr) LAUNCH_FWD(true, true, 2 * ITEMS, FWD_ROWS) else LAUNCH_FWD(true, false, 2 * ITEMS, FWD_ROWS) }
@@ -1094,6 +1132,7 @@ static int scan_fwd_launch(const float* u, const float* delta, const float* dtr,
     else { if (dtr) LAUNCH_FWD(false, true, ITEMS, FWD_ROWS) else LAUNCH_FWD(false, false, ITEMS, FWD_ROWS) }
   }
 #undef LAUNCH_FWD
+#undef LAUNCH_FWD_
   return tamtr_launch_status();
 }
 
@@ -1103,11 +1142,11 @@ extern "C" int tamtr_selective_scan_fwd(const float* u, const float* delta, cons
   return scan_fwd_launch(u, delta, nullptr, nullptr, 0, A, Bm, Cm, D, dbias, y, hstate, B, K, Dk, N, L, xmode, stream);
 }
 
-extern "C" int tamtr_selective_scan_dtproj_fwd(const float* u, const float* dtr, const float* Wdt, const float* A, const float* Bm,
-                                               const float* Cm, const float* D, const float* dbias, float* y, float* hstate, int B,
-                                               int K, int Dk, int N, int R, int L, int xmode, void* stream) {
-  if (!dtr) return TAMTR_EINVAL;
-  return scan_fwd_launch(u, nullptr, dtr, Wdt, R, A, Bm, Cm, D, dbias, y, hstate, B, K, Dk, N, L, xmode, stream);
+extern "C" int tamtr_selective_scan_dtproj_fwd(const void* u, const float* dtr, const float* Wdt, const float* A, const float* Bm,
+                                               const float* Cm, const float* D, const float* dbias, void* y, float* hstate, int B,
+                                               int K, int Dk, int N, int R, int L, int xmode, int planes_bf16, void* stream) {
+  if (!dtr || (planes_bf16 != 0 && planes_bf16 != 1)) return TAMTR_EINVAL;
+  return scan_fwd_launch((const float*)u, nullptr, dtr, Wdt, R, A, Bm, Cm, D, dbias, (float*)y, hstate, B, K, Dk, N, L, xmode, stream, planes_bf16);
 }
 
 static int scan_bwd_launch(const float* gy, const float* u, const float* delta, const float* dtr, const float* Wdt, int R,
@@ -1126,15 +1165,17 @@ extern "C" int tamtr_selective_scan_bwd(const float* gy, const float* u, const f
                          N, L, xmode, 0, stream);
 }
 
-extern "C" int tamtr_selective_scan_dtproj_bwd(const float* gy, const float* u, const float* dtr, const float* Wdt, const float* A,
+extern "C" int tamtr_selective_scan_dtproj_bwd(const void* gy, const void* u, const float* dtr, const float* Wdt, const float* A,
                                                const float* Bm, const float* Cm, const float* D, const float* dbias,
-                                               const float* hstate, float* gu, void* gdelta_ws, float* gdtr, float* grow, float* gB,
-                                               float* gC, float* ws, int B, int K, int Dk, int N, int R, int L, int xmode, int ws_bf16,
+                                               const float* hstate, void* gu, void* gdelta_ws, float* gdtr, float* grow, float* gB,
+                                               float* gC, float* ws, int B, int K, int Dk, int N, int R, int L, int xmode, int bf16_flags,
                                                void* stream) {
-  if (!dtr || !Wdt || !gdtr || (ws_bf16 != 0 && ws_bf16 != 1)) return TAMTR_EINVAL;
-  if (ws_bf16 && L % 4) return TAMTR_EUNSUP;
-  return scan_bwd_launch(gy, u, nullptr, dtr, Wdt, R, A, Bm, Cm, D, dbias, hstate, gu, (float*)gdelta_ws, gdtr, grow, gB, gC, ws, B, K, Dk, N,
-                         L, xmode, ws_bf16, stream);
+  // bf16_flags: bit 0 - the d(delta) workspace is bf16; bit 1 - gy, u and gu are bf16 planes (needs bit 0)
+  if (!dtr || !Wdt || !gdtr || bf16_flags < 0 || bf16_flags > 3 || bf16_flags == 2) return TAMTR_EINVAL;
+  if (bf16_flags && L % 4) return TAMTR_EUNSUP;
+  if ((bf16_flags & 2) && ((uintptr_t)gy | (uintptr_t)u | (uintptr_t)gu) % 8) return TAMTR_EUNSUP;
+  return scan_bwd_launch((const float*)gy, (const float*)u, nullptr, dtr, Wdt, R, A, Bm, Cm, D, dbias, hstate, (float*)gu, (float*)gdelta_ws, gdtr,
+                         grow, gB, gC, ws, B, K, Dk, N, L, xmode, bf16_flags, stream);
 }
 
 static int scan_bwd_launch(const float* gy, const float* u, const float* delta, const float* dtr, const float* Wdt, int R,
@@ -1162,7 +1203,13 @@ static int scan_bwd_launch(const float* gy, const float* u, const float* delta, 
 #define LAUNCH_BWD16(SETS)                                                                                                             \
   hipLaunchKernelGGL((selscan_bwd_kernel<true, SETS, true>), grid, dim3(BWD_WAVES * WAVE), dyn, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, gu, \
                      gdelta, grow, wsB, wsC, K, Dk, L, nchunk, slab, xmode, dtr, Wdt, R)
-  if (gd16 && dtr) {
+#define LAUNCH_BWD16P(SETS)                                                                                                            \
+  hipLaunchKernelGGL((selscan_bwd_kernel<true, SETS, true, true>), grid, dim3(BWD_WAVES * WAVE), dyn, s, gy, u, delta, A, Bm, Cm, D, dbias, hstate, \
+                     gu, gdelta, grow, wsB, wsC, K, Dk, L, nchunk, slab, xmode, dtr, Wdt, R)
+  if ((gd16 & 2) && dtr) {
+    if (R <= 16) LAUNCH_BWD16P(1); else LAUNCH_BWD16P(2);
+    gd16 = 1;
+  } else if (gd16 && dtr) {
     if (R <= 16) LAUNCH_BWD16(1); else LAUNCH_BWD16(2);
   } else if (L % 4 == 0) {
     if (R == 0) LAUNCH_BWD(true, 0); else if (R <= 16) LAUNCH_BWD(true, 1); else LAUNCH_BWD(true, 2);
@@ -1171,6 +1218,7 @@ static int scan_bwd_launch(const float* gy, const float* u, const float* delta, 
   }
 #undef LAUNCH_BWD
 #undef LAUNCH_BWD16
+#undef LAUNCH_BWD16P
   // dB / dC: the workgroups' slabs added in slab order (this also frees the workspace for the split gdtr product below)
   const size_t n4 = slab / 4;  // N = 16 makes slab a multiple of 4
   const unsigned blocks = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);

@@ -16,13 +16,20 @@ namespace {
 
 constexpr int TS = 16, CB = 32, MT_THREADS = 256, PITCH = TS + 1;
 
-__global__ __launch_bounds__(MT_THREADS) void cross_merge_fwd_kernel(const float* __restrict__ y4, float* __restrict__ ymT, int D, int H,
+// one element of a scan plane (f32, or bf16 in the bf16 mode: include/tamtr_hip.h "bf16 PLANES")
+__device__ __forceinline__ float pl_ld(const float* p) { return *p; }
+__device__ __forceinline__ float pl_ld(const bf16_t* p) { return bf2f(*p); }
+__device__ __forceinline__ void pl_st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void pl_st(bf16_t* p, float v) { *p = f2bf(v); }
+
+template <typename PT>
+__global__ __launch_bounds__(MT_THREADS) void cross_merge_fwd_kernel(const PT* __restrict__ y4, float* __restrict__ ymT, int D, int H,
                                                                       int W, int tiles_w) {
   __shared__ float s[CB][TS][PITCH];
   const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
   const int d0 = blockIdx.y * CB, b = blockIdx.z, h0 = th * TS, w0 = tw * TS;
   const size_t L = (size_t)H * W;
-  const float* yb = y4 + (size_t)b * 4 * D * L;
+  const PT* yb = y4 + (size_t)b * 4 * D * L;
   // (round 4: the 2 x 32 row loads of a thread used to sit one by one behind `in image ? load : 0` - a queue drain per channel, 2.1 TB/s;
   // now clamped addresses, eight channels = 16 loads in flight, and only the final store is predicated)
   {  // directions 0 and 2: row-major flattening, lanes along x
@@ -32,7 +39,7 @@ __global__ __launch_bounds__(MT_THREADS) void cross_merge_fwd_kernel(const float
     for (int c0 = 0; c0 < CB; c0 += 8) {
       float a[8], c2[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { a[j] = yb[(size_t)(d0 + c0 + j) * L + p]; c2[j] = yb[((size_t)2 * D + d0 + c0 + j) * L + p]; }
+      for (int j = 0; j < 8; ++j) { a[j] = pl_ld(yb + (size_t)(d0 + c0 + j) * L + p); c2[j] = pl_ld(yb + ((size_t)2 * D + d0 + c0 + j) * L + p); }
 #pragma unroll
       for (int j = 0; j < 8; ++j) s[c0 + j][ty][tx] = a[j] + c2[j];
     }
@@ -45,7 +52,7 @@ __global__ __launch_bounds__(MT_THREADS) void cross_merge_fwd_kernel(const float
     for (int c0 = 0; c0 < CB; c0 += 8) {
       float a[8], c2[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { a[j] = yb[((size_t)D + d0 + c0 + j) * L + p]; c2[j] = yb[((size_t)3 * D + d0 + c0 + j) * L + p]; }
+      for (int j = 0; j < 8; ++j) { a[j] = pl_ld(yb + ((size_t)D + d0 + c0 + j) * L + p); c2[j] = pl_ld(yb + ((size_t)3 * D + d0 + c0 + j) * L + p); }
 #pragma unroll
       for (int j = 0; j < 8; ++j) s[c0 + j][ty][tx] += a[j] + c2[j];
     }
@@ -60,7 +67,8 @@ __global__ __launch_bounds__(MT_THREADS) void cross_merge_fwd_kernel(const float
   }
 }
 
-__global__ __launch_bounds__(MT_THREADS) void cross_merge_bwd_kernel(const float* __restrict__ gT, float* __restrict__ g2, int D, int H,
+template <typename PT>
+__global__ __launch_bounds__(MT_THREADS) void cross_merge_bwd_kernel(const float* __restrict__ gT, PT* __restrict__ g2, int D, int H,
                                                                       int W, int tiles_w) {
   __shared__ float s[CB][TS][PITCH];
   const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
@@ -86,16 +94,16 @@ __global__ __launch_bounds__(MT_THREADS) void cross_merge_bwd_kernel(const float
     }
   }
   __syncthreads();
-  float* gb = g2 + (size_t)b * 2 * D * L;
+  PT* gb = g2 + (size_t)b * 2 * D * L;
   {
     const int ty = threadIdx.x / TS, tx = threadIdx.x % TS, h = h0 + ty, w = w0 + tx;
     if (h < H && w < W)
-      for (int c = 0; c < CB; ++c) gb[(size_t)(d0 + c) * L + (size_t)h * W + w] = s[c][ty][tx];
+      for (int c = 0; c < CB; ++c) pl_st(gb + (size_t)(d0 + c) * L + (size_t)h * W + w, s[c][ty][tx]);
   }
   {
     const int ty = threadIdx.x % TS, tx = threadIdx.x / TS, h = h0 + ty, w = w0 + tx;
     if (h < H && w < W)
-      for (int c = 0; c < CB; ++c) gb[((size_t)D + d0 + c) * L + (size_t)w * H + h] = s[c][ty][tx];
+      for (int c = 0; c < CB; ++c) pl_st(gb + ((size_t)D + d0 + c) * L + (size_t)w * H + h, s[c][ty][tx]);
   }
 }
 
@@ -332,21 +340,27 @@ __global__ __launch_bounds__(LG_WAVES* WAVE) void ln_bwd_kernel(const T* __restr
 
 }  // namespace
 
-extern "C" int tamtr_cross_merge_fwd(const float* y4, float* ymT, int B, int D, int H, int W, void* stream) {
-  if (!y4 || !ymT || B <= 0 || D <= 0 || H <= 0 || W <= 0) return TAMTR_EINVAL;
+extern "C" int tamtr_cross_merge_fwd(const void* y4, float* ymT, int B, int D, int H, int W, int plane_dtype, void* stream) {
+  if (!y4 || !ymT || B <= 0 || D <= 0 || H <= 0 || W <= 0 || (plane_dtype != TAMTR_F32 && plane_dtype != TAMTR_BF16)) return TAMTR_EINVAL;
   if (D % CB || B > 65535 || D / CB > 65535) return TAMTR_EUNSUP;
   const int tiles_w = (W + TS - 1) / TS, tiles_h = (H + TS - 1) / TS;
-  hipLaunchKernelGGL(cross_merge_fwd_kernel, dim3(tiles_w * tiles_h, D / CB, B), dim3(MT_THREADS), 0, (hipStream_t)stream, y4, ymT, D, H,
-                     W, tiles_w);
+  const dim3 grid(tiles_w * tiles_h, D / CB, B);
+  if (plane_dtype == TAMTR_F32)
+    hipLaunchKernelGGL(cross_merge_fwd_kernel<float>, grid, dim3(MT_THREADS), 0, (hipStream_t)stream, (const float*)y4, ymT, D, H, W, tiles_w);
+  else
+    hipLaunchKernelGGL(cross_merge_fwd_kernel<bf16_t>, grid, dim3(MT_THREADS), 0, (hipStream_t)stream, (const bf16_t*)y4, ymT, D, H, W, tiles_w);
   return tamtr_launch_status();
 }
 
-extern "C" int tamtr_cross_merge_bwd(const float* gymT, float* g2, int B, int D, int H, int W, void* stream) {
-  if (!gymT || !g2 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return TAMTR_EINVAL;
+extern "C" int tamtr_cross_merge_bwd(const float* gymT, void* g2, int B, int D, int H, int W, int plane_dtype, void* stream) {
+  if (!gymT || !g2 || B <= 0 || D <= 0 || H <= 0 || W <= 0 || (plane_dtype != TAMTR_F32 && plane_dtype != TAMTR_BF16)) return TAMTR_EINVAL;
   if (D % CB || B > 65535 || D / CB > 65535) return TAMTR_EUNSUP;
   const int tiles_w = (W + TS - 1) / TS, tiles_h = (H + TS - 1) / TS;
-  hipLaunchKernelGGL(cross_merge_bwd_kernel, dim3(tiles_w * tiles_h, D / CB, B), dim3(MT_THREADS), 0, (hipStream_t)stream, gymT, g2, D, H,
-                     W, tiles_w);
+  const dim3 grid(tiles_w * tiles_h, D / CB, B);
+  if (plane_dtype == TAMTR_F32)
+    hipLaunchKernelGGL(cross_merge_bwd_kernel<float>, grid, dim3(MT_THREADS), 0, (hipStream_t)stream, gymT, (float*)g2, D, H, W, tiles_w);
+  else
+    hipLaunchKernelGGL(cross_merge_bwd_kernel<bf16_t>, grid, dim3(MT_THREADS), 0, (hipStream_t)stream, gymT, (bf16_t*)g2, D, H, W, tiles_w);
   return tamtr_launch_status();
 }
 

@@ -87,6 +87,61 @@ __global__ __launch_bounds__(256) void xproj_fwd_kernel(const float* __restrict_
     }
 }
 
+// ---- forward on a bf16 plane (bf16 mode: include/tamtr_hip.h "bf16 PLANES"): a lane's dword holds two neighbouring pixels, so a wave owns
+// 64 pixels - the even ones in one B fragment, the odd ones in the other (two v_perm per register pair instead of eight conversions) -
+// and every output row is written as 256 contiguous bytes (float2 per lane)
+__device__ __forceinline__ s16x8 xp_halves(const uint32_t (&d)[8], bool odd) {
+  uint32_t w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w[q] = odd ? __builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x07060302u) : __builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x05040100u);
+  s16x8 f;
+  __builtin_memcpy(&f, w, 16);
+  return f;
+}
+template <int MB>
+__global__ __launch_bounds__(256) void xproj_fwd16_kernel(const bf16_t* __restrict__ u2, const bf16_t* __restrict__ wcat, float* __restrict__ dtr,
+                                                          float* __restrict__ Bs, float* __restrict__ Cs, int D, int L, int R) {
+  const int i = blockIdx.y, b = blockIdx.z, C = R + 2 * XP_N;
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE, lr = lane & 31, lh = lane >> 5;
+  const int p0 = (blockIdx.x * 4 + wave) * 64;
+  if (p0 >= L) return;                                    // (wave-uniform)
+  const int p = min(p0 + 2 * lr, L - 2);                  // L % 2 == 0: a pixel pair is inside or outside as a whole
+  const uint32_t* U = reinterpret_cast<const uint32_t*>(u2 + ((size_t)b * 2 + i) * D * (size_t)L + p + (size_t)(8 * lh) * L);
+  const size_t Ld = (size_t)L / 2;                        // row pitch in dwords
+  const bf16_t* W = wcat + ((size_t)i * MB * 32 + lr) * D + 8 * lh;
+  f32x16 acc[2][MB];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[e][mb][r] = 0.f;
+
+  for (int k0 = 0; k0 < D; k0 += 16) {
+    uint32_t uv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) uv[j] = U[(size_t)(k0 + j) * Ld];
+    s16x8 af[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) af[mb] = *reinterpret_cast<const s16x8*>(W + (size_t)mb * 32 * D + k0);
+    const s16x8 be = xp_halves(uv, false), bo = xp_halves(uv, true);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      acc[0][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], be, acc[0][mb], 0, 0, 0);
+      acc[1][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bo, acc[1][mb], 0, 0, 0);
+    }
+  }
+  if (p0 + 2 * lr >= L) return;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float* dst = xp_row(dtr, Bs, Cs, b, i, m, R, C, (size_t)L);
+      if (dst) *reinterpret_cast<float2*>(dst + p0 + 2 * lr) = make_float2(xp_round(acc[0][mb][r]), xp_round(acc[1][mb][r]));
+    }
+}
+
 // ---- backward, d/d(u2): a wave owns 32 pixels of (b, i); its B operand = the 2C gradient rows of those pixels, kept for all D / 32 row blocks
 template <int KS>   // k-steps of 16 gradient rows: KS * 16 >= 2C
 __global__ __launch_bounds__(256) void xproj_bwd_dx_kernel(const float* __restrict__ gu, const float* __restrict__ gdtr, const float* __restrict__ gB,
@@ -132,8 +187,64 @@ __global__ __launch_bounds__(256) void xproj_bwd_dx_kernel(const float* __restri
   }
 }
 
+// ---- the same on bf16 planes: gu [B, 4, D, L] and the result [B, 2, D, L] are bf16; a wave owns 64 pixels (a dword = a pixel pair per lane)
+template <int KS>
+__global__ __launch_bounds__(256) void xproj_bwd_dx16_kernel(const bf16_t* __restrict__ gu, const float* __restrict__ gdtr, const float* __restrict__ gB,
+                                                             const float* __restrict__ gC, const bf16_t* __restrict__ wT, bf16_t* __restrict__ gu2,
+                                                             int D, int L, int R) {
+  const int i = blockIdx.y, b = blockIdx.z, C = R + 2 * XP_N;
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE, lr = lane & 31, lh = lane >> 5;
+  const int p0 = (blockIdx.x * 4 + wave) * 64;
+  if (p0 >= L) return;
+  const int p = min(p0 + 2 * lr, L - 2);
+  s16x8 ge[KS], go[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    float ve[8], vo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float* row = xp_row(gdtr, gB, gC, b, i, 16 * ks + 8 * lh + j, R, C, (size_t)L);
+      const float2 v = row ? *reinterpret_cast<const float2*>(row + p) : make_float2(0.f, 0.f);
+      ve[j] = v.x; vo[j] = v.y;
+    }
+    ge[ks] = xp_pack(ve); go[ks] = xp_pack(vo);
+  }
+  const bool live = p0 + 2 * lr < L;
+  const size_t plane = (size_t)D * L;
+  const bf16_t* g0 = gu + ((size_t)b * 4 + i) * plane + p;            // direction i; direction i + 2 sits two planes further
+  bf16_t* out = gu2 + ((size_t)b * 2 + i) * plane + p;
+  const bf16_t* W = wT + ((size_t)i * D + lr) * (KS * 16) + 8 * lh;
+  for (int db = 0; db < D / 32; ++db) {
+    f32x16 ae, ao;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ae[r] = 0.f; ao[r] = 0.f; }
+    uint32_t a0[16], a2[16];   // the folded planes' pixel pairs: requested before the products
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const size_t o = (size_t)(32 * db + (r & 3) + 8 * (r >> 2) + 4 * lh) * L;
+      a0[r] = *reinterpret_cast<const uint32_t*>(g0 + o);
+      a2[r] = *reinterpret_cast<const uint32_t*>(g0 + o + 2 * plane);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const s16x8 af = *reinterpret_cast<const s16x8*>(W + (size_t)db * 32 * (KS * 16) + 16 * ks);
+      ae = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ge[ks], ae, 0, 0, 0);
+      ao = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, go[ks], ao, 0, 0, 0);
+    }
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const size_t o = (size_t)(32 * db + (r & 3) + 8 * (r >> 2) + 4 * lh) * L;
+        const float se = __uint_as_float(a0[r] << 16) + __uint_as_float(a2[r] << 16) + xp_round(ae[r]);
+        const float so = __uint_as_float(a0[r] & 0xffff0000u) + __uint_as_float(a2[r] & 0xffff0000u) + xp_round(ao[r]);
+        *reinterpret_cast<uint32_t*>(out + o) = xp_pk(se, so);
+      }
+    }
+  }
+}
+
 // ---- backward, weight gradient: a workgroup = (1 024-pixel slice, 256-channel group, b, i); wave w: channels 64 w .. 64 w + 63 of the group x all rows
-template <int MB>
+template <int MB, bool P16 = false>   // P16: u2 is a bf16 plane - eight pixels of a row are one 16-byte load and already the MFMA fragment
 __global__ __launch_bounds__(256) void xproj_bwd_dw_kernel(const float* __restrict__ u2, const float* __restrict__ gdtr, const float* __restrict__ gB,
                                                            const float* __restrict__ gC, float* __restrict__ part, int D, int L, int R, int nslice) {
   const int C = R + 2 * XP_N, ngrp = D / 256;
@@ -146,7 +257,10 @@ __global__ __launch_bounds__(256) void xproj_bwd_dw_kernel(const float* __restri
   const int d0 = grp * 256 + wave * 64;
   const float* urow[2];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) urow[q] = u2 + (((size_t)b * 2 + i) * D + d0 + 32 * q + lr) * (size_t)L;
+  for (int q = 0; q < 2; ++q) {
+    const size_t e = (((size_t)b * 2 + i) * D + d0 + 32 * q + lr) * (size_t)L;
+    urow[q] = P16 ? reinterpret_cast<const float*>(reinterpret_cast<const bf16_t*>(u2) + e) : u2 + e;
+  }
   f32x16 acc[2][MB];
 #pragma unroll
   for (int q = 0; q < 2; ++q)
@@ -174,13 +288,19 @@ __global__ __launch_bounds__(256) void xproj_bwd_dw_kernel(const float* __restri
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const float4 x0 = *reinterpret_cast<const float4*>(urow[q] + pc), x1 = *reinterpret_cast<const float4*>(urow[q] + pc + 4);
-      float uv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-      if (!in) {
+      if constexpr (P16) {
+        uint4 x = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(urow[q]) + pc);
+        if (!in) x = make_uint4(0u, 0u, 0u, 0u);
+        __builtin_memcpy(&bf[q], &x, 16);
+      } else {
+        const float4 x0 = *reinterpret_cast<const float4*>(urow[q] + pc), x1 = *reinterpret_cast<const float4*>(urow[q] + pc + 4);
+        float uv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        if (!in) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) uv[j] = 0.f;
+          for (int j = 0; j < 8; ++j) uv[j] = 0.f;
+        }
+        bf[q] = xp_pack(uv);
       }
-      bf[q] = xp_pack(uv);
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -207,39 +327,61 @@ inline bool xp_args_ok(int B, int D, int L, int R) { return B > 0 && B <= 65535 
 extern "C" int tamtr_xproj_dw_slices(int L) { return L > 0 ? (L + XP_SLICE - 1) / XP_SLICE : 0; }
 
 /* see include/tamtr_hip.h */
-extern "C" int tamtr_xproj_fwd(const float* u2, const void* wcat, float* dtr, float* Bs, float* Cs, int B, int D, int L, int R, void* stream) {
-  if (!u2 || !wcat || !dtr || !Bs || !Cs || !xp_args_ok(B, D, L, R)) return TAMTR_EINVAL;
+extern "C" int tamtr_xproj_fwd(const void* u2, const void* wcat, float* dtr, float* Bs, float* Cs, int B, int D, int L, int R, int plane_dtype,
+                               void* stream) {
+  if (!u2 || !wcat || !dtr || !Bs || !Cs || !xp_args_ok(B, D, L, R) || (plane_dtype != TAMTR_F32 && plane_dtype != TAMTR_BF16)) return TAMTR_EINVAL;
   const int MB = (2 * (R + 2 * XP_N) + 31) / 32;
   if (D % 16 || (uintptr_t)wcat % 16 || MB < 3 || MB > 4) return TAMTR_EUNSUP;
-  const dim3 grid((L + 127) / 128, 2, B);
   hipStream_t s = (hipStream_t)stream;
-  if (MB == 3) hipLaunchKernelGGL(xproj_fwd_kernel<3>, grid, dim3(256), 0, s, u2, (const bf16_t*)wcat, dtr, Bs, Cs, D, L, R);
-  else hipLaunchKernelGGL(xproj_fwd_kernel<4>, grid, dim3(256), 0, s, u2, (const bf16_t*)wcat, dtr, Bs, Cs, D, L, R);
+  if (plane_dtype == TAMTR_BF16) {
+    if (L % 2 || ((uintptr_t)u2 | (uintptr_t)dtr | (uintptr_t)Bs | (uintptr_t)Cs) % 8) return TAMTR_EUNSUP;
+    const dim3 grid((L + 255) / 256, 2, B);
+    if (MB == 3) hipLaunchKernelGGL(xproj_fwd16_kernel<3>, grid, dim3(256), 0, s, (const bf16_t*)u2, (const bf16_t*)wcat, dtr, Bs, Cs, D, L, R);
+    else hipLaunchKernelGGL(xproj_fwd16_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)u2, (const bf16_t*)wcat, dtr, Bs, Cs, D, L, R);
+    return tamtr_launch_status();
+  }
+  const dim3 grid((L + 127) / 128, 2, B);
+  if (MB == 3) hipLaunchKernelGGL(xproj_fwd_kernel<3>, grid, dim3(256), 0, s, (const float*)u2, (const bf16_t*)wcat, dtr, Bs, Cs, D, L, R);
+  else hipLaunchKernelGGL(xproj_fwd_kernel<4>, grid, dim3(256), 0, s, (const float*)u2, (const bf16_t*)wcat, dtr, Bs, Cs, D, L, R);
   return tamtr_launch_status();
 }
 
-extern "C" int tamtr_xproj_bwd_dx(const float* gu, const float* gdtr, const float* gB, const float* gC, const void* wT, float* gu2, int B, int D,
-                                  int L, int R, void* stream) {
-  if (!gu || !gdtr || !gB || !gC || !wT || !gu2 || !xp_args_ok(B, D, L, R)) return TAMTR_EINVAL;
+extern "C" int tamtr_xproj_bwd_dx(const void* gu, const float* gdtr, const float* gB, const float* gC, const void* wT, void* gu2, int B, int D,
+                                  int L, int R, int plane_dtype, void* stream) {
+  if (!gu || !gdtr || !gB || !gC || !wT || !gu2 || !xp_args_ok(B, D, L, R) || (plane_dtype != TAMTR_F32 && plane_dtype != TAMTR_BF16)) return TAMTR_EINVAL;
   const int KS = (2 * (R + 2 * XP_N) + 15) / 16;
   if (D % 32 || (uintptr_t)wT % 16 || KS < 5 || KS > 8) return TAMTR_EUNSUP;
-  const dim3 grid((L + 127) / 128, 2, B);
   hipStream_t s = (hipStream_t)stream;
-#define GO(K) hipLaunchKernelGGL(xproj_bwd_dx_kernel<K>, grid, dim3(256), 0, s, gu, gdtr, gB, gC, (const bf16_t*)wT, gu2, D, L, R)
+  if (plane_dtype == TAMTR_BF16) {
+    if (L % 2 || ((uintptr_t)gu | (uintptr_t)gu2) % 4 || ((uintptr_t)gdtr | (uintptr_t)gB | (uintptr_t)gC) % 8) return TAMTR_EUNSUP;
+    const dim3 grid((L + 255) / 256, 2, B);
+#define GO(K) hipLaunchKernelGGL(xproj_bwd_dx16_kernel<K>, grid, dim3(256), 0, s, (const bf16_t*)gu, gdtr, gB, gC, (const bf16_t*)wT, (bf16_t*)gu2, D, L, R)
+    switch (KS) { case 5: GO(5); break; case 6: GO(6); break; case 7: GO(7); break; default: GO(8); break; }
+#undef GO
+    return tamtr_launch_status();
+  }
+  const dim3 grid((L + 127) / 128, 2, B);
+#define GO(K) hipLaunchKernelGGL(xproj_bwd_dx_kernel<K>, grid, dim3(256), 0, s, (const float*)gu, gdtr, gB, gC, (const bf16_t*)wT, (float*)gu2, D, L, R)
   switch (KS) { case 5: GO(5); break; case 6: GO(6); break; case 7: GO(7); break; default: GO(8); break; }
 #undef GO
   return tamtr_launch_status();
 }
 
-extern "C" int tamtr_xproj_bwd_dw(const float* u2, const float* gdtr, const float* gB, const float* gC, float* part, int B, int D, int L, int R,
-                                  void* stream) {
-  if (!u2 || !gdtr || !gB || !gC || !part || !xp_args_ok(B, D, L, R)) return TAMTR_EINVAL;
+extern "C" int tamtr_xproj_bwd_dw(const void* u2, const float* gdtr, const float* gB, const float* gC, float* part, int B, int D, int L, int R,
+                                  int plane_dtype, void* stream) {
+  if (!u2 || !gdtr || !gB || !gC || !part || !xp_args_ok(B, D, L, R) || (plane_dtype != TAMTR_F32 && plane_dtype != TAMTR_BF16)) return TAMTR_EINVAL;
   const int MB = (2 * (R + 2 * XP_N) + 31) / 32;
   if (D % 256 || L % 8 || MB < 3 || MB > 4 || ((uintptr_t)u2 | (uintptr_t)gdtr | (uintptr_t)gB | (uintptr_t)gC) % 16) return TAMTR_EUNSUP;
   const int nslice = tamtr_xproj_dw_slices(L);
   const dim3 grid(nslice * (D / 256), 2, B);
   hipStream_t s = (hipStream_t)stream;
-  if (MB == 3) hipLaunchKernelGGL(xproj_bwd_dw_kernel<3>, grid, dim3(256), 0, s, u2, gdtr, gB, gC, part, D, L, R, nslice);
-  else hipLaunchKernelGGL(xproj_bwd_dw_kernel<4>, grid, dim3(256), 0, s, u2, gdtr, gB, gC, part, D, L, R, nslice);
+  const float* u = (const float*)u2;
+  if (plane_dtype == TAMTR_BF16) {
+    if (MB == 3) hipLaunchKernelGGL((xproj_bwd_dw_kernel<3, true>), grid, dim3(256), 0, s, u, gdtr, gB, gC, part, D, L, R, nslice);
+    else hipLaunchKernelGGL((xproj_bwd_dw_kernel<4, true>), grid, dim3(256), 0, s, u, gdtr, gB, gC, part, D, L, R, nslice);
+  } else {
+    if (MB == 3) hipLaunchKernelGGL((xproj_bwd_dw_kernel<3, false>), grid, dim3(256), 0, s, u, gdtr, gB, gC, part, D, L, R, nslice);
+    else hipLaunchKernelGGL((xproj_bwd_dw_kernel<4, false>), grid, dim3(256), 0, s, u, gdtr, gB, gC, part, D, L, R, nslice);
+  }
   return tamtr_launch_status();
 }

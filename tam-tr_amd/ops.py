@@ -905,7 +905,7 @@ class _SelectiveScanDtProj(torch.autograd.Function):
         y = torch.empty(Bn, KD, L, device=u.device, dtype=torch.float32)
         hstate = torch.empty(Bn, KD, nchunk, N, device=u.device, dtype=torch.float32)
         call('tamtr_selective_scan_dtproj_fwd', ptr(u), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(dbias), ptr(y),
-             ptr(hstate), Bn, K, KD // K, N, R, L, int(xmode), stream_ptr())
+             ptr(hstate), Bn, K, KD // K, N, R, L, int(xmode), 0, stream_ptr())
         ctx.save_for_backward(u, dtr, Wdt, A, Bm, Cm, D, dbias, hstate)
         ctx.xmode = int(xmode)
         return y
@@ -972,7 +972,7 @@ class _DWConvSiluCross(torch.autograd.Function):
         w = _c(weight.float().reshape(D, 9))
         bvec = _c(bias.float()) if bias is not None else None
         u2 = torch.empty(B, 2, D, H * W, device=xz.device, dtype=torch.float32)
-        call('tamtr_dwconv_silu_cross_fwd', ptr(xz), C2, ptr(w), ptr(bvec), ptr(u2), B, D, H, W, dtype_code(xz), stream_ptr())
+        call('tamtr_dwconv_silu_cross_fwd', ptr(xz), C2, ptr(w), ptr(bvec), ptr(u2), B, D, H, W, dtype_code(xz), 0, stream_ptr())
         ctx.save_for_backward(xz, w, bvec if bvec is not None else w.new_empty(0))
         ctx.cfg = (D, weight.shape, weight.dtype, None if bias is None else bias.dtype)
         return u2
@@ -986,7 +986,7 @@ class _DWConvSiluCross(torch.autograd.Function):
         gxz = torch.zeros_like(xz)  # the second half (z) gets its gradient from the gate path; autograd adds the two
         ws = torch.empty(B, tiles, D, 10, device=xz.device, dtype=torch.float32)
         call('tamtr_dwconv_silu_cross_bwd', ptr(_c(g2.float())), ptr(xz), C2, ptr(w), ptr(bvec if b_dt is not None else None), ptr(gxz), C2,
-             ptr(ws), B, D, H, W, dtype_code(xz), stream_ptr())
+             ptr(ws), B, D, H, W, dtype_code(xz), 0, stream_ptr())
         gwb = slab_sum(ws.view(-1, D, 10))
         gw = gwb[:, :9].reshape(w_shape).to(w_dt)
         gb = gwb[:, 9].to(b_dt) if b_dt is not None else None
@@ -1066,12 +1066,12 @@ class _SelectiveScanCrossMerged(torch.autograd.Function):
         y = torch.empty(Bn, K, Dk, L, device=u2.device, dtype=torch.float32)
         hstate = torch.empty(Bn, K * Dk, nchunk, N, device=u2.device, dtype=torch.float32)
         call('tamtr_selective_scan_dtproj_fwd', ptr(u2), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(dbias), ptr(y),
-             ptr(hstate), Bn, K, Dk, N, R, L, 1, stream_ptr())
+             ptr(hstate), Bn, K, Dk, N, R, L, 1, 0, stream_ptr())
         ctx.save_for_backward(u2, dtr, Wdt, A, Bm, Cm, D, dbias, hstate)
         ctx.hw = (H, W, token_major)
         if token_major:  # CrossMerge straight into [B, L, Dk] (what out_norm / out_proj consume): one tiled-transpose kernel
             ymT = torch.empty(Bn, L, Dk, device=u2.device, dtype=torch.float32)
-            call('tamtr_cross_merge_fwd', ptr(y), ptr(ymT), Bn, Dk, H, W, stream_ptr())
+            call('tamtr_cross_merge_fwd', ptr(y), ptr(ymT), Bn, Dk, H, W, 0, stream_ptr())
             return ymT
         ym = y[:, 0] + y[:, 2]
         ym += (y[:, 1] + y[:, 3]).view(Bn, Dk, W, H).transpose(2, 3).reshape(Bn, Dk, L)
@@ -1086,7 +1086,7 @@ class _SelectiveScanCrossMerged(torch.autograd.Function):
         KD = K * Dk
         g2 = torch.empty(Bn, 2, Dk, L, device=u2.device, dtype=torch.float32)
         if token_major:
-            call('tamtr_cross_merge_bwd', ptr(_c(gm.float())), ptr(g2), Bn, Dk, H, W, stream_ptr())
+            call('tamtr_cross_merge_bwd', ptr(_c(gm.float())), ptr(g2), Bn, Dk, H, W, 0, stream_ptr())
         else:
             g2[:, 0] = gm
             g2[:, 1].view(Bn, Dk, W, H).copy_(gm.view(Bn, Dk, H, W).transpose(2, 3))
@@ -1208,6 +1208,15 @@ def detr_match_cost(ps, pb, gt_bboxes, gt_cls, gains, alpha, gamma):
 
 
 # ------------------------------------------------------------------------------------------------ x_proj of SS2D (csrc/xproj.hip)
+_SS2D_PLANES_F32 = _os.environ.get('TAMTR_SS2D_PLANES') == 'f32'   # A/B switch: the cross-scan planes in fp32 also in bf16 mode (rounds 1-3)
+
+
+def ss2d_bf16_planes(dtype, D, L, R, N):
+    """bf16 mode keeps SS2D's big time-indexed planes in bf16 (include/tamtr_hip.h "bf16 PLANES"): every kernel of the chain has that form
+    only on its vector path and with the own x_proj kernels."""
+    return dtype == torch.bfloat16 and not _SS2D_PLANES_F32 and L % 8 == 0 and xproj_ok(dtype, D, L, R, N)
+
+
 _XPROJ_LIB = _os.environ.get('TAMTR_XPROJ') == 'torch'   # A/B switch: the torch-op form (cast, two batched library GEMMs, stack, ...)
 
 
@@ -1250,8 +1259,12 @@ class _SS2DCore(torch.autograd.Function):
         # front end
         cw = _c(conv_w.float().reshape(D, 9))
         cb = _c(conv_b.float()) if conv_b is not None else None
-        u2 = torch.empty(B, 2, D, L, device=xz.device, dtype=torch.float32)
-        call('tamtr_dwconv_silu_cross_fwd', ptr(xz), C2, ptr(cw), ptr(cb), ptr(u2), B, D, H, W, dtype_code(xz), stream_ptr())
+        # bf16 mode: the big time-indexed planes that only cross HBM between kernels (u2, y, and in the backward d(y), d(u), d(u2)) are bf16;
+        # the recurrence, its states and every gradient sum stay fp32 (include/tamtr_hip.h "bf16 PLANES")
+        p16 = ss2d_bf16_planes(xz.dtype, D, L, R, N)
+        pdt, pc = (torch.bfloat16, 1) if p16 else (torch.float32, 0)
+        u2 = torch.empty(B, 2, D, L, device=xz.device, dtype=pdt)
+        call('tamtr_dwconv_silu_cross_fwd', ptr(xz), C2, ptr(cw), ptr(cb), ptr(u2), B, D, H, W, dtype_code(xz), pc, stream_ptr())
         # x_proj on the two copies (directions k and k + 2 share one)
         cdt = xz.dtype if xz.dtype == torch.bfloat16 else torch.float32
         C = R + 2 * N
@@ -1259,7 +1272,7 @@ class _SS2DCore(torch.autograd.Function):
         if own_xp:   # csrc/xproj.hip: u2 read once as f32, the three outputs written in the scan's layout
             wcat = xproj_pack_weight(wx)
             dtr, Bs, Cs = (torch.empty(B, K, n, L, device=xz.device, dtype=torch.float32) for n in (R, N, N))
-            call('tamtr_xproj_fwd', ptr(u2), ptr(wcat), ptr(dtr), ptr(Bs), ptr(Cs), B, D, L, R, stream_ptr())
+            call('tamtr_xproj_fwd', ptr(u2), ptr(wcat), ptr(dtr), ptr(Bs), ptr(Cs), B, D, L, R, pc, stream_ptr())
             ub = wa = wb = None
         else:
             wcat = None
@@ -1272,12 +1285,12 @@ class _SS2DCore(torch.autograd.Function):
         # scan + cross-merge, token-major
         Wdt32, A32, D32, db32 = (_c(t.float()) for t in (Wdt, A, Ds, dbias))
         chunk = _lib.lib().tamtr_selective_scan_chunk()
-        y = torch.empty(B, K, D, L, device=xz.device, dtype=torch.float32)
+        y = torch.empty(B, K, D, L, device=xz.device, dtype=pdt)
         hstate = torch.empty(B, K * D, (L + chunk - 1) // chunk, N, device=xz.device, dtype=torch.float32)
         call('tamtr_selective_scan_dtproj_fwd', ptr(u2), ptr(dtr), ptr(Wdt32), ptr(A32), ptr(Bs), ptr(Cs), ptr(D32), ptr(db32), ptr(y),
-             ptr(hstate), B, K, D, N, R, L, 1, stream_ptr())
+             ptr(hstate), B, K, D, N, R, L, 1, pc, stream_ptr())
         ymT = torch.empty(B, L, D, device=xz.device, dtype=torch.float32)
-        call('tamtr_cross_merge_fwd', ptr(y), ptr(ymT), B, D, H, W, stream_ptr())
+        call('tamtr_cross_merge_fwd', ptr(y), ptr(ymT), B, D, H, W, pc, stream_ptr())
         del y
         # out_norm x SiLU(z)
         g32, b32 = _c(gamma.float()), _c(beta.float())
@@ -1311,12 +1324,14 @@ class _SS2DCore(torch.autograd.Function):
              dtype_code(xz), stream_ptr())
         gsum = slab_sum(part)
         # cross-merge and scan
-        g2 = torch.empty(B, 2, D, L, device=dev, dtype=torch.float32)
-        call('tamtr_cross_merge_bwd', ptr(gy), ptr(g2), B, D, H, W, stream_ptr())
+        pdt = u2.dtype                       # the planes' element type (forward's choice)
+        pc = 1 if pdt == torch.bfloat16 else 0
+        g2 = torch.empty(B, 2, D, L, device=dev, dtype=pdt)
+        call('tamtr_cross_merge_bwd', ptr(gy), ptr(g2), B, D, H, W, pc, stream_ptr())
         del gy
-        gu = torch.empty(B, K * D, L, device=dev, dtype=torch.float32)
+        gu = torch.empty(B, K * D, L, device=dev, dtype=pdt)
         # d(delta) workspace: only the operand of gdtr = Wdt^T d(delta); in bf16 mode (gdtr is rounded to bf16 below anyway) kept in bf16
-        ws16 = xz.dtype == torch.bfloat16 and L % 4 == 0
+        ws16 = pc or (xz.dtype == torch.bfloat16 and L % 4 == 0)
         gdelta = torch.empty(B, K * D, L, device=dev, dtype=torch.bfloat16 if ws16 else torch.float32)
         gdtr = torch.empty_like(dtr)
         gB, gC = torch.empty_like(Bs), torch.empty_like(Cs)
@@ -1325,18 +1340,18 @@ class _SS2DCore(torch.autograd.Function):
         ws = torch.empty(2 * nslab * Bs.numel(), device=dev, dtype=torch.float32)
         call('tamtr_selective_scan_dtproj_bwd', ptr(g2), ptr(u2), ptr(dtr), ptr(Wdt32), ptr(A32), ptr(Bs), ptr(Cs), ptr(D32), ptr(db32),
              ptr(hstate), ptr(gu), ptr(gdelta), ptr(gdtr), ptr(grow), ptr(gB), ptr(gC), ptr(ws), B, K, D, N, R, L,
-             3, int(ws16), stream_ptr())
+             3, int(bool(ws16)) | (2 * pc), stream_ptr())
         gW, gA, gD, gdb = _split_row_sums(grow, R)
         del gdelta, ws, g2
-        gu2 = torch.empty(B, 2, D, L, device=dev, dtype=torch.float32)
+        gu2 = torch.empty(B, 2, D, L, device=dev, dtype=pdt)
         if ctx.own_xp:
             # csrc/xproj.hip: d/d(u2) = fold of the scan's four planes + Wcat^T G in one pass; dWcat as per-slice partial tiles + ordered sum
             wT = xproj_pack_weight_t(wcat, C)
-            call('tamtr_xproj_bwd_dx', ptr(gu), ptr(gdtr), ptr(gB), ptr(gC), ptr(wT), ptr(gu2), B, D, L, R, stream_ptr())
+            call('tamtr_xproj_bwd_dx', ptr(gu), ptr(gdtr), ptr(gB), ptr(gC), ptr(wT), ptr(gu2), B, D, L, R, pc, stream_ptr())
             del gu
             nsl = _lib.lib().tamtr_xproj_dw_slices(L)
             part = torch.empty(B * nsl, 2, 2 * C, D, device=dev, dtype=torch.float32)
-            call('tamtr_xproj_bwd_dw', ptr(u2), ptr(gdtr), ptr(gB), ptr(gC), ptr(part), B, D, L, R, stream_ptr())
+            call('tamtr_xproj_bwd_dw', ptr(u2), ptr(gdtr), ptr(gB), ptr(gC), ptr(part), B, D, L, R, pc, stream_ptr())
             gws = slab_sum(part)
             del part
         else:
@@ -1358,7 +1373,7 @@ class _SS2DCore(torch.autograd.Function):
         tiles = _lib.lib().tamtr_dwconv_tiles(H, W)
         wsd = torch.empty(B, tiles, D, 10, device=dev, dtype=torch.float32)
         call('tamtr_dwconv_silu_cross_bwd', ptr(gu2), ptr(xz), C2, ptr(cw), ptr(cb if cb_dt is not None else None), ptr(gxz), C2, ptr(wsd), B,
-             D, H, W, dtype_code(xz), stream_ptr())
+             D, H, W, dtype_code(xz), pc, stream_ptr())
         gwb = slab_sum(wsd.view(-1, D, 10))
         gcw = gwb[:, :9].reshape(cw_shape).to(cw_dt)
         gcb = gwb[:, 9].to(cb_dt) if cb_dt is not None else None

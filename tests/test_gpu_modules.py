@@ -681,15 +681,24 @@ def test_ss2d_core_node_equals_the_chained_nodes(pkg, monkeypatch):
     x = (rnd((2, 20, 24, 128), 3)).cuda().bfloat16()
     cot = rnd((2, 20, 24, 128), 4).cuda()
     res = []
-    for split in ('0', '1'):
-        monkeypatch.setenv('TAMTR_SS2D_SPLIT', split)
+    for split in ('0', '1', 'planes16'):
+        # (the identity below is between the two forms on the SAME planes: fp32; the third run is the product's form in bf16 mode, bf16 planes)
+        monkeypatch.setattr(pkg.ops, '_SS2D_PLANES_F32', split != 'planes16')
+        monkeypatch.setenv('TAMTR_SS2D_SPLIT', '0' if split == 'planes16' else split)
         blk.zero_grad(set_to_none=True)
         xd = x.clone().requires_grad_()
         with torch.autocast('cuda', dtype=torch.bfloat16):
             out = blk(xd)
         (out.float() * cot).sum().backward()
         res.append((out.detach().float(), xd.grad.float(), {k: p.grad.clone() for k, p in blk.named_parameters()}))
-    (o0, g0, p0), (o1, g1, p1) = res
+    (o0, g0, p0), (o1, g1, p1), (o2, g2, p2) = res
+    # bf16 planes (u2, y, d(y), d(u), d(u2) rounded to bf16 where they cross HBM) against fp32 planes: bf16-level differences
+    assert pkg.ops.ss2d_bf16_planes(torch.bfloat16, 256, 480, 8, 16)
+    assert not torch.equal(o2, o0), 'the bf16-plane form did not run'
+    assert_close(o2, o0, 2e-2, 2e-2 * float(o0.abs().max()), 'ss2d out, bf16 planes')
+    assert_close(g2, g0, 3e-2, 3e-2 * float(g0.abs().max()), 'ss2d dx, bf16 planes')
+    for k in p0:
+        assert_close(p2[k].float(), p0[k].float(), 3e-2, 3e-2 * max(1e-6, float(p0[k].abs().max())), 'ss2d grad, bf16 planes ' + k)
     assert_close(o0, o1, 1e-6, 1e-6, 'ss2d out')                 # same kernels, same order: identical forward
     assert_close(g0, g1, 2e-2, 2e-2 * float(g1.abs().max()), 'ss2d dx')   # d(xz) halves meet in one bf16 buffer instead of an fp32-free sum
     assert set(p0) == set(p1)

@@ -313,12 +313,12 @@ def test_cross_merge_kernels(ops, B, D, H, W):
     L = H * W
     y4 = dev(rnd((B, 4, D, L), 1))
     ymT = torch.empty(B, L, D, device='cuda')
-    call('tamtr_cross_merge_fwd', ptr(y4), ptr(ymT), B, D, H, W, stream_ptr())
+    call('tamtr_cross_merge_fwd', ptr(y4), ptr(ymT), B, D, H, W, 0, stream_ptr())
     ref = y4[:, 0] + y4[:, 2] + (y4[:, 1] + y4[:, 3]).view(B, D, W, H).transpose(2, 3).reshape(B, D, L)
     assert_close(ymT, ref.transpose(1, 2), 1e-6, 1e-6, 'cross merge fwd')
     g = dev(rnd((B, L, D), 2))
     g2 = torch.empty(B, 2, D, L, device='cuda')
-    call('tamtr_cross_merge_bwd', ptr(g), ptr(g2), B, D, H, W, stream_ptr())
+    call('tamtr_cross_merge_bwd', ptr(g), ptr(g2), B, D, H, W, 0, stream_ptr())
     gm = g.transpose(1, 2)
     assert torch.equal(g2[:, 0], gm.contiguous())
     assert torch.equal(g2[:, 1], gm.reshape(B, D, H, W).transpose(2, 3).reshape(B, D, L))
@@ -881,6 +881,98 @@ def test_fused_optim_step_equals_clip_adamw_ema():
     assert float(ob.state[b.fc.weight]['step']) == 7.0
 
 
+@pytest.mark.parametrize('B,D,H,W,R', [(2, 256, 24, 40, 8), (1, 512, 16, 24, 16), (1, 1024, 8, 16, 32), (1, 256, 36, 28, 8)])
+def test_ss2d_bf16_planes_are_the_f32_kernels_rounded_once(ops, B, D, H, W, R):
+    """bf16 mode keeps SS2D's big time-indexed planes (u2, y, d(y), d(u), d(u2)) in bf16 between the kernels (include/tamtr_hip.h "bf16
+    PLANES").  Every kernel of the chain in that form against its fp32-plane form: fed the SAME (bf16-representable) values it must
+    produce the same numbers - bit for bit where the output is fp32, and exactly the fp32 form's output rounded to bf16 where it is a plane."""
+    import tamtr_amd._lib as L_
+    from tamtr_amd._lib import call, ptr, stream_ptr
+    L, N, K, C = H * W, 16, 4, R + 32
+    g = torch.Generator(device='cuda').manual_seed(D + L)
+    rn = lambda *sh: torch.randn(*sh, device='cuda', generator=g)   # noqa: E731
+    sp = stream_ptr()
+    # ---- front end: depthwise conv + SiLU -> u2
+    xz = rn(B, H, W, 2 * D).bfloat16()
+    cw, cb = rn(D, 9) * 0.3, rn(D) * 0.1
+    u32, u16 = torch.empty(B, 2, D, L, device='cuda'), torch.empty(B, 2, D, L, device='cuda', dtype=torch.bfloat16)
+    call('tamtr_dwconv_silu_cross_fwd', ptr(xz), 2 * D, ptr(cw), ptr(cb), ptr(u32), B, D, H, W, 1, 0, sp)
+    call('tamtr_dwconv_silu_cross_fwd', ptr(xz), 2 * D, ptr(cw), ptr(cb), ptr(u16), B, D, H, W, 1, 1, sp)
+    assert torch.equal(u16, u32.bfloat16()), 'dwconv forward plane'
+    uf = u16.float()
+    # ---- x_proj forward
+    wx = rn(4, C, D) * D ** -0.5
+    wcat = ops.xproj_pack_weight(wx)
+    o32 = [torch.empty(B, 4, n, L, device='cuda') for n in (R, N, N)]
+    o16 = [torch.empty(B, 4, n, L, device='cuda') for n in (R, N, N)]
+    call('tamtr_xproj_fwd', ptr(uf), ptr(wcat), ptr(o32[0]), ptr(o32[1]), ptr(o32[2]), B, D, L, R, 0, sp)
+    call('tamtr_xproj_fwd', ptr(u16), ptr(wcat), ptr(o16[0]), ptr(o16[1]), ptr(o16[2]), B, D, L, R, 1, sp)
+    for a, b, nm in zip(o16, o32, ('dtr', 'Bs', 'Cs')):
+        assert torch.equal(a, b), 'x_proj forward ' + nm
+    dtr, Bs, Cs = o32
+    # ---- scan forward
+    Wdt, A, Dv, db = rn(K * D, R) * R ** -0.5, -torch.exp(rn(K * D, N) * 0.5), rn(K * D), rn(K * D) * 0.5 - 1.0
+    chunk = L_.lib().tamtr_selective_scan_chunk()
+    nck = (L + chunk - 1) // chunk
+    y32, y16 = torch.empty(B, K, D, L, device='cuda'), torch.empty(B, K, D, L, device='cuda', dtype=torch.bfloat16)
+    h32, h16 = torch.empty(B, K * D, nck, N, device='cuda'), torch.empty(B, K * D, nck, N, device='cuda')
+    call('tamtr_selective_scan_dtproj_fwd', ptr(uf), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bs), ptr(Cs), ptr(Dv), ptr(db), ptr(y32), ptr(h32), B, K, D, N, R, L, 1, 0, sp)
+    call('tamtr_selective_scan_dtproj_fwd', ptr(u16), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bs), ptr(Cs), ptr(Dv), ptr(db), ptr(y16), ptr(h16), B, K, D, N, R, L, 1, 1, sp)
+    assert torch.isfinite(y32).all()
+    assert torch.equal(h16, h32), 'scan checkpoints'
+    assert torch.equal(y16, y32.bfloat16()), 'scan forward plane'
+    # ---- cross merge forward / backward
+    m32, m16 = torch.empty(B, L, D, device='cuda'), torch.empty(B, L, D, device='cuda')
+    call('tamtr_cross_merge_fwd', ptr(y16.float()), ptr(m32), B, D, H, W, 0, sp)
+    call('tamtr_cross_merge_fwd', ptr(y16), ptr(m16), B, D, H, W, 1, sp)
+    assert torch.equal(m16, m32), 'cross merge forward'
+    gm = rn(B, L, D)
+    g32, g16 = torch.empty(B, 2, D, L, device='cuda'), torch.empty(B, 2, D, L, device='cuda', dtype=torch.bfloat16)
+    call('tamtr_cross_merge_bwd', ptr(gm), ptr(g32), B, D, H, W, 0, sp)
+    call('tamtr_cross_merge_bwd', ptr(gm), ptr(g16), B, D, H, W, 1, sp)
+    assert torch.equal(g16, g32.bfloat16()), 'cross merge backward plane'
+    # ---- scan backward
+    nslab = L_.lib().tamtr_selective_scan_bwd_slabs(D)
+    outs = []
+    for p16 in (0, 1):
+        gu = torch.empty(B, K * D, L, device='cuda', dtype=torch.bfloat16 if p16 else torch.float32)
+        gdelta = torch.empty(B, K * D, L, device='cuda', dtype=torch.bfloat16)
+        gdtr, gB, gC = torch.empty_like(dtr), torch.empty_like(Bs), torch.empty_like(Cs)
+        grow = torch.empty(B, K * D, L_.lib().tamtr_selective_scan_row_sums(), device='cuda')
+        ws = torch.empty(2 * nslab * Bs.numel(), device='cuda')
+        call('tamtr_selective_scan_dtproj_bwd', ptr(g16 if p16 else g16.float()), ptr(u16 if p16 else uf), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bs), ptr(Cs), ptr(Dv),
+             ptr(db), ptr(h32), ptr(gu), ptr(gdelta), ptr(gdtr), ptr(grow), ptr(gB), ptr(gC), ptr(ws), B, K, D, N, R, L, 3, 1 | (2 * p16), sp)
+        outs.append((gu, gdtr, gB, gC, grow))
+    assert torch.equal(outs[1][0], outs[0][0].bfloat16()), 'scan backward d(u) plane'
+    for a, b, nm in zip(outs[1][1:], outs[0][1:], ('gdtr', 'gB', 'gC', 'row sums')):
+        assert torch.equal(a, b), 'scan backward ' + nm
+    gu16, gdtr, gB, gC, _ = outs[1]
+    # ---- x_proj backward
+    wT = ops.xproj_pack_weight_t(wcat, C)
+    d32, d16 = torch.empty(B, 2, D, L, device='cuda'), torch.empty(B, 2, D, L, device='cuda', dtype=torch.bfloat16)
+    call('tamtr_xproj_bwd_dx', ptr(gu16.float()), ptr(gdtr), ptr(gB), ptr(gC), ptr(wT), ptr(d32), B, D, L, R, 0, sp)
+    call('tamtr_xproj_bwd_dx', ptr(gu16), ptr(gdtr), ptr(gB), ptr(gC), ptr(wT), ptr(d16), B, D, L, R, 1, sp)
+    assert torch.equal(d16, d32.bfloat16()), 'x_proj backward d(u2) plane'
+    nsl = L_.lib().tamtr_xproj_dw_slices(L)
+    p32, p16_ = (torch.full((B * nsl, 2, 2 * C, D), float('nan'), device='cuda') for _ in range(2))
+    call('tamtr_xproj_bwd_dw', ptr(uf), ptr(gdtr), ptr(gB), ptr(gC), ptr(p32), B, D, L, R, 0, sp)
+    call('tamtr_xproj_bwd_dw', ptr(u16), ptr(gdtr), ptr(gB), ptr(gC), ptr(p16_), B, D, L, R, 1, sp)
+    assert torch.isfinite(p32).all() and torch.equal(p16_, p32), 'x_proj weight gradient'
+    # ---- front end backward
+    tiles = L_.lib().tamtr_dwconv_tiles(H, W)
+    res = []
+    for pc, gpl in ((0, d16.float()), (1, d16)):
+        gxz, wsd = torch.zeros_like(xz), torch.empty(B, tiles, D, 10, device='cuda')
+        call('tamtr_dwconv_silu_cross_bwd', ptr(gpl), ptr(xz), 2 * D, ptr(cw), ptr(cb), ptr(gxz), 2 * D, ptr(wsd), B, D, H, W, 1, pc, sp)
+        res.append((gxz, wsd))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), 'dwconv backward'
+    # argument checks: bf16 planes only beside bf16 activations, only on the vector path
+    with pytest.raises(L_.TamtrHipError):
+        call('tamtr_dwconv_silu_cross_fwd', ptr(xz.float()), 2 * D, ptr(cw), ptr(cb), ptr(u16), B, D, H, W, 0, 1, sp)
+    with pytest.raises(L_.TamtrHipError):
+        call('tamtr_selective_scan_dtproj_fwd', ptr(u16), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bs), ptr(Cs), ptr(Dv), ptr(db), ptr(y16), ptr(h16), B, K, D, N, R, L - 1, 1, 1, sp)
+
+
 @pytest.mark.parametrize('B,D,L,R', [(2, 256, 1048, 8), (1, 512, 400, 16), (1, 1024, 136, 32), (3, 256, 64, 8)])
 def test_xproj_kernels_vs_fp32_products_of_the_same_bf16_operands(ops, B, D, L, R):
     """csrc/xproj.hip (x_proj of SS2D on the pair layout, vmamba.py:962-975): the forward's three outputs, d/d(u2) with the fold of the
@@ -897,7 +989,7 @@ def test_xproj_kernels_vs_fp32_products_of_the_same_bf16_operands(ops, B, D, L, 
     assert wcat.shape == (2, -(-2 * C // 32) * 32, D) and wcat.dtype == torch.bfloat16
     outs = [[torch.empty(B, 4, n, L, device='cuda') for n in (R, N, N)] for _ in range(2)]
     for o in outs:
-        ops.call('tamtr_xproj_fwd', ops.ptr(u2), ops.ptr(wcat), ops.ptr(o[0]), ops.ptr(o[1]), ops.ptr(o[2]), B, D, L, R, ops.stream_ptr())
+        ops.call('tamtr_xproj_fwd', ops.ptr(u2), ops.ptr(wcat), ops.ptr(o[0]), ops.ptr(o[1]), ops.ptr(o[2]), B, D, L, R, 0, ops.stream_ptr())
     assert all(torch.equal(a, b) for a, b in zip(*outs))
     dtr, Bs, Cs = outs[0]
     for i in range(2):
@@ -911,12 +1003,12 @@ def test_xproj_kernels_vs_fp32_products_of_the_same_bf16_operands(ops, B, D, L, 
     assert wT.shape == (2, D, -(-2 * C // 16) * 16)
     gu2 = [torch.empty(B, 2, D, L, device='cuda') for _ in range(2)]
     for o in gu2:
-        ops.call('tamtr_xproj_bwd_dx', ops.ptr(gu), ops.ptr(gdtr), ops.ptr(gB), ops.ptr(gC), ops.ptr(wT), ops.ptr(o), B, D, L, R, ops.stream_ptr())
+        ops.call('tamtr_xproj_bwd_dx', ops.ptr(gu), ops.ptr(gdtr), ops.ptr(gB), ops.ptr(gC), ops.ptr(wT), ops.ptr(o), B, D, L, R, 0, ops.stream_ptr())
     assert torch.equal(*gu2)
     nsl = L_.lib().tamtr_xproj_dw_slices(L)
     parts = [torch.full((B * nsl, 2, 2 * C, D), float('nan'), device='cuda') for _ in range(2)]
     for o in parts:
-        ops.call('tamtr_xproj_bwd_dw', ops.ptr(u2), ops.ptr(gdtr), ops.ptr(gB), ops.ptr(gC), ops.ptr(o), B, D, L, R, ops.stream_ptr())
+        ops.call('tamtr_xproj_bwd_dw', ops.ptr(u2), ops.ptr(gdtr), ops.ptr(gB), ops.ptr(gC), ops.ptr(o), B, D, L, R, 0, ops.stream_ptr())
     assert torch.equal(*parts) and torch.isfinite(parts[0]).all()
     gws = ops.slab_sum(parts[0])
     for i in range(2):

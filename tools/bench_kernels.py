@@ -186,6 +186,67 @@ def bench_lsap():
         print(f'lsap nq={nq} boxes/img={groups[0]} x {len(groups)} images: {a * 1e3:.0f} us avg, {mn * 1e3:.0f} us min (one launch, no host round trip)')
 
 
+def bench_planes():
+    """Every kernel of the SS2D chain with its big planes in fp32 and in bf16 (include/tamtr_hip.h "bf16 PLANES") at the three level shapes:
+    time and algorithmic bytes per second of the planes + the other operands it reads / writes."""
+    import tamtr_amd._lib as L_
+    from tamtr_amd._lib import call, ptr, stream_ptr
+    B, K, N = 16, 4, 16
+    sp = stream_ptr()
+    for D, H, R in [(256, 160, 8), (512, 80, 16), (1024, 40, 32)]:
+        W, L, C = H, H * H, R + 32
+        rn = lambda *sh: torch.randn(*sh, device='cuda')   # noqa: E731
+        xz = rn(B, H, W, 2 * D).bfloat16()
+        cw, cb = rn(D, 9) * 0.3, rn(D) * 0.1
+        wx = rn(4, C, D) * D ** -0.5
+        wcat = ops.xproj_pack_weight(wx)
+        wT = ops.xproj_pack_weight_t(wcat, C)
+        Wdt, A, Dv, db = rn(K * D, R) * R ** -0.5, -torch.exp(rn(K * D, N) * 0.5), rn(K * D), rn(K * D) * 0.5 - 1.0
+        chunk = L_.lib().tamtr_selective_scan_chunk()
+        hst = torch.empty(B, K * D, (L + chunk - 1) // chunk, N, device='cuda')
+        dtr, Bs, Cs = (torch.empty(B, 4, n, L, device='cuda') for n in (R, N, N))
+        ymT, gm = torch.empty(B, L, D, device='cuda'), rn(B, L, D)
+        gdelta = torch.empty(B, K * D, L, device='cuda', dtype=torch.bfloat16)
+        gdtr, gB, gC = torch.empty_like(dtr), torch.empty_like(Bs), torch.empty_like(Cs)
+        grow = torch.empty(B, K * D, L_.lib().tamtr_selective_scan_row_sums(), device='cuda')
+        ws = torch.empty(2 * L_.lib().tamtr_selective_scan_bwd_slabs(D) * Bs.numel(), device='cuda')
+        nsl = L_.lib().tamtr_xproj_dw_slices(L)
+        part = torch.empty(B * nsl, 2, 2 * C, D, device='cuda')
+        gxz = torch.zeros_like(xz)
+        wsd = torch.empty(B, L_.lib().tamtr_dwconv_tiles(H, W), D, 10, device='cuda')
+        pl = B * D * L                       # elements of one [B, D, L] plane
+        small = (R + 2 * N) * 4 * B * L * 4  # dtr + Bs + Cs (or their gradients), f32
+        rows = []
+        for pc, pdt in ((0, torch.float32), (1, torch.bfloat16)):
+            e = 2 if pc else 4
+            u2, y = torch.empty(B, 2, D, L, device='cuda', dtype=pdt), torch.empty(B, K, D, L, device='cuda', dtype=pdt)
+            g2, gu, gu2 = torch.empty_like(u2), torch.empty(B, K * D, L, device='cuda', dtype=pdt), torch.empty_like(u2)
+            steps = [
+                ('dwconv_cross_fwd', lambda: call('tamtr_dwconv_silu_cross_fwd', ptr(xz), 2 * D, ptr(cw), ptr(cb), ptr(u2), B, D, H, W, 1, pc, sp), pl * 2 + 2 * pl * e),
+                ('xproj_fwd', lambda: call('tamtr_xproj_fwd', ptr(u2), ptr(wcat), ptr(dtr), ptr(Bs), ptr(Cs), B, D, L, R, pc, sp), 2 * pl * e + small),
+                ('selscan_fwd', lambda: call('tamtr_selective_scan_dtproj_fwd', ptr(u2), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bs), ptr(Cs), ptr(Dv), ptr(db), ptr(y), ptr(hst), B, K, D, N, R, L, 1, pc, sp), 8 * pl * e + small),
+                ('cross_merge_fwd', lambda: call('tamtr_cross_merge_fwd', ptr(y), ptr(ymT), B, D, H, W, pc, sp), 4 * pl * e + pl * 4),
+                ('cross_merge_bwd', lambda: call('tamtr_cross_merge_bwd', ptr(gm), ptr(g2), B, D, H, W, pc, sp), pl * 4 + 2 * pl * e),
+                ('selscan_bwd', lambda: call('tamtr_selective_scan_dtproj_bwd', ptr(g2), ptr(u2), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bs), ptr(Cs), ptr(Dv), ptr(db), ptr(hst), ptr(gu), ptr(gdelta),
+                                             ptr(gdtr), ptr(grow), ptr(gB), ptr(gC), ptr(ws), B, K, D, N, R, L, 3, 1 | (2 * pc), sp), 12 * pl * e + 8 * pl * 2 + 2 * small),
+                ('xproj_bwd_dx', lambda: call('tamtr_xproj_bwd_dx', ptr(gu), ptr(gdtr), ptr(gB), ptr(gC), ptr(wT), ptr(gu2), B, D, L, R, pc, sp), 6 * pl * e + small),
+                ('xproj_bwd_dw', lambda: call('tamtr_xproj_bwd_dw', ptr(u2), ptr(gdtr), ptr(gB), ptr(gC), ptr(part), B, D, L, R, pc, sp), 2 * pl * e + small),
+                ('dwconv_cross_bwd', lambda: call('tamtr_dwconv_silu_cross_bwd', ptr(gu2), ptr(xz), 2 * D, ptr(cw), ptr(cb), ptr(gxz), 2 * D, ptr(wsd), B, D, H, W, 1, pc, sp), 2 * pl * e + 2 * pl * 2),
+            ]
+            # realistic values in the planes the later kernels read
+            u2.copy_(rn(B, 2, D, L)); g2.copy_(rn(B, 2, D, L)); gu.copy_(rn(B, K * D, L)); gu2.copy_(rn(B, 2, D, L))
+            for name, fn, byt in steps:
+                a, mn = timeit(fn, n=10, warm=2)
+                rows.append((name, pc, mn, byt))
+            del u2, y, g2, gu, gu2
+        tot = [0.0, 0.0]
+        for i in range(len(rows) // 2):
+            (name, _, t32, b32), (_, _, t16, b16) = rows[i], rows[i + len(rows) // 2]
+            tot[0] += t32; tot[1] += t16
+            print(f'planes d_inner={D} L={L}: {name:18s} f32 {t32 * 1e3:7.0f} us ({b32 / t32 / 1e9:5.2f} TB/s)   bf16 {t16 * 1e3:7.0f} us ({b16 / t16 / 1e9:5.2f} TB/s)   {t16 / t32:.2f}x')
+        print(f'planes d_inner={D} L={L}: chain total      f32 {tot[0] * 1e3:7.0f} us   bf16 {tot[1] * 1e3:7.0f} us   saves {(tot[0] - tot[1]) * 1e3:.0f} us')
+
+
 def bench_projconv():
     """The gate's value branch at the five TIAGELAN sites (three shapes, 16 images, bf16 channels-last slice of the cv1 output): the MFMA
     kernel with the statistics in its epilogue against the library convolution + tamtr_bncl_stats."""
@@ -209,6 +270,6 @@ def bench_projconv():
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['all']
-    for name in ('scan', 'gemm', 'gate', 'gatecl', 'msda', 'attn', 'cpam', 'dwconv', 'lsap', 'projconv'):
+    for name in ('scan', 'gemm', 'gate', 'gatecl', 'msda', 'attn', 'cpam', 'dwconv', 'lsap', 'projconv', 'planes'):
         if name in which or 'all' in which:
             globals()['bench_' + name]()

@@ -13,7 +13,7 @@ u2, dtr, Wdt = rn(B, 2, Dk, L), rn(B, K, R, L), rn(K * Dk, R) * R ** -0.5
 A, Bm, Cm, D, bias = -torch.exp(rn(K * Dk, N) * 0.3), rn(B, K, N, L), rn(B, K, N, L), rn(K * Dk), rn(K * Dk) - 3
 chunk = lib().tamtr_selective_scan_chunk(); nchunk = (L + chunk - 1) // chunk
 y = torch.empty(B, K, Dk, L, device='cuda'); hstate = torch.empty(B, K * Dk, nchunk, N, device='cuda')
-call('tamtr_selective_scan_dtproj_fwd', ptr(u2), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(bias), ptr(y), ptr(hstate), B, K, Dk, N, R, L, 1, stream_ptr())
+call('tamtr_selective_scan_dtproj_fwd', ptr(u2), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bm), ptr(Cm), ptr(D), ptr(bias), ptr(y), ptr(hstate), B, K, Dk, N, R, L, 1, 0, stream_ptr())
 gy = rn(B, K * Dk, L)
 gu, gdelta, gdtr = torch.empty(B, K * Dk, L, device='cuda'), torch.empty(B, K * Dk, L, device='cuda'), torch.empty_like(dtr)
 gW, gA, gB, gC, gD, gb = torch.zeros_like(Wdt), torch.zeros_like(A), torch.empty_like(Bm), torch.empty_like(Cm), torch.zeros_like(D), torch.zeros_like(bias)
