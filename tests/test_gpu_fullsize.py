@@ -249,8 +249,10 @@ BF16_FORCED_BOUNDS = {'loss_rel': 1.0e-1, 'term_rel_max': 1.4e-1, 'box_abs_max':
 # random-fill weights, BASELINE configs[1]'s "bf16 ... rest PyTorch-ROCm" - carries all of it (trunk alone: loss 4.99e-2, logits 1.67 max).
 # Everything this repo hand-writes behind the trunk (VSS blocks, input projection, query selection, decoder, heads) in bf16 ON AN fp32
 # TRUNK measured loss 1.63e-4, worst term 1.06e-3, boxes 1.66e-3 max / 6.5e-5 mean, class logits 0.40 max / 0.008 mean, encoder scores 0.032
-# (row "vss+proj+enc+decoder"): bounds at 2x in test_bf16_error_of_the_hip_path_on_an_fp32_trunk.
-BF16_HIP_PATH_BOUNDS = {'loss_rel': 3.5e-4, 'term_rel_max': 2.2e-3, 'box_abs_max': 3.4e-3, 'box_abs_mean': 1.3e-4, 'cls_logit_abs_max': 0.8,
+# (row "vss+proj+enc+decoder").  With SS2D's big planes in bf16 between its kernels (ops.ss2d_bf16_planes, later in round 4; deterministic,
+# gpurun_out/r4o): loss 8.3e-5, worst term 2.56e-3 (loss_class), boxes 2.0e-3 max / 6.6e-5 mean, class logits 0.27 max / 0.0077 mean,
+# encoder scores 0.032.  Bounds at 2x these in test_bf16_error_of_the_hip_path_on_an_fp32_trunk.
+BF16_HIP_PATH_BOUNDS = {'loss_rel': 1.7e-4, 'term_rel_max': 5.2e-3, 'box_abs_max': 4.0e-3, 'box_abs_mean': 1.3e-4, 'cls_logit_abs_max': 0.55,
                         'cls_logit_abs_mean': 0.016, 'enc_score_abs_max': 0.065}
 
 
