@@ -349,7 +349,8 @@ extern "C" int tamtr_dwconv_silu_cross_fwd(const void* x, long long x_pixel_stri
   else if (plane_dtype == TAMTR_F32)
     hipLaunchKernelGGL((dwconv_cross_fwd_kernel<bf16_t, float>), grid, dim3(DW_THREADS), 0, s, (const bf16_t*)x, (size_t)x_pixel_stride, weight,
                        bias, (float*)u2, D, H, W, tiles_w);
-  else
+  else   // (a 32 x 32-tile form with dword stores was built and measured for the bf16 planes: 310 against 319 us at level 0, slower at the
+         // 80^2 / 40^2 levels - this kernel is bound by its LDS reads and the SiLU, not by its stores; profiles/r04_ss2d_bf16_planes.txt)
     hipLaunchKernelGGL((dwconv_cross_fwd_kernel<bf16_t, bf16_t>), grid, dim3(DW_THREADS), 0, s, (const bf16_t*)x, (size_t)x_pixel_stride, weight,
                        bias, (bf16_t*)u2, D, H, W, tiles_w);
   return tamtr_launch_status();

@@ -107,6 +107,131 @@ __global__ __launch_bounds__(MT_THREADS) void cross_merge_bwd_kernel(const float
   }
 }
 
+// ---- bf16 planes (bf16 mode), H and W even: 32 x 32 pixel x 16 channel tiles.  A 16-pixel run of a bf16 plane is 32 bytes - half a
+// 64-byte request - and the 16 x 16 tiles above moved bf16 planes no faster than fp32 ones (profiles/r04_ss2d_bf16_planes.txt: 0.91x / 1.12x
+// at level 0).  Here a lane moves a pixel PAIR (one dword), 16 lanes a 64-byte run along the plane's own contiguous axis, and the token-major
+// side is 16 channels = 64 bytes of fp32 per pixel.  LDS: [16][32][34] floats + 2 per channel plane (70 KB: two workgroups per CU).
+constexpr int T2 = 32, C2B = 16, P2 = T2 + 2, PL2 = T2 * P2 + 2;
+
+__global__ __launch_bounds__(MT_THREADS) void cross_merge_fwd16_kernel(const bf16_t* __restrict__ y4, float* __restrict__ ymT, int D, int H,
+                                                                        int W, int tiles_w) {
+  extern __shared__ __attribute__((aligned(16))) float s2[];   // [C2B][PL2]
+  const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
+  const int d0 = blockIdx.y * C2B, b = blockIdx.z, h0 = th * T2, w0 = tw * T2;
+  const size_t L = (size_t)H * W;
+  const bf16_t* yb = y4 + (size_t)b * 4 * D * L;
+  const int lo = threadIdx.x % 16, hi = threadIdx.x / 16;   // lo: the pixel pair along the plane's contiguous axis; hi, hi + 16: the lines
+  {  // directions 0 and 2: row-major flattening (pairs along w)
+    const int w = min(w0 + 2 * lo, W - 2);
+    size_t p[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) p[r] = (size_t)min(h0 + hi + 16 * r, H - 1) * W + w;
+#pragma unroll
+    for (int c0 = 0; c0 < C2B; c0 += 4) {
+      uint32_t a[4][2], c2[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          a[j][r] = *reinterpret_cast<const uint32_t*>(yb + (size_t)(d0 + c0 + j) * L + p[r]);
+          c2[j][r] = *reinterpret_cast<const uint32_t*>(yb + ((size_t)2 * D + d0 + c0 + j) * L + p[r]);
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+          *reinterpret_cast<float2*>(&s2[(c0 + j) * PL2 + (hi + 16 * r) * P2 + 2 * lo]) =
+              make_float2(__uint_as_float(a[j][r] << 16) + __uint_as_float(c2[j][r] << 16),
+                          __uint_as_float(a[j][r] & 0xffff0000u) + __uint_as_float(c2[j][r] & 0xffff0000u));
+    }
+  }
+  __syncthreads();
+  {  // directions 1 and 3: column-major flattening (pairs along h)
+    const int h = min(h0 + 2 * lo, H - 2);
+    size_t p[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) p[r] = (size_t)min(w0 + hi + 16 * r, W - 1) * H + h;
+#pragma unroll
+    for (int c0 = 0; c0 < C2B; c0 += 4) {
+      uint32_t a[4][2], c2[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          a[j][r] = *reinterpret_cast<const uint32_t*>(yb + ((size_t)D + d0 + c0 + j) * L + p[r]);
+          c2[j][r] = *reinterpret_cast<const uint32_t*>(yb + ((size_t)3 * D + d0 + c0 + j) * L + p[r]);
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          float* q = &s2[(c0 + j) * PL2 + (2 * lo) * P2 + hi + 16 * r];
+          q[0] += __uint_as_float(a[j][r] << 16) + __uint_as_float(c2[j][r] << 16);
+          q[P2] += __uint_as_float(a[j][r] & 0xffff0000u) + __uint_as_float(c2[j][r] & 0xffff0000u);
+        }
+    }
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < T2 * T2 * (C2B / 4); it += MT_THREADS) {
+    const int pix = it / (C2B / 4), g = it - pix * (C2B / 4), py = pix / T2, px = pix - py * T2;
+    const int h = h0 + py, w = w0 + px;
+    const float* q = &s2[(g * 4) * PL2 + py * P2 + px];
+    if (h < H && w < W)
+      *reinterpret_cast<float4*>(ymT + ((size_t)b * L + (size_t)h * W + w) * D + d0 + g * 4) = make_float4(q[0], q[PL2], q[2 * PL2], q[3 * PL2]);
+  }
+}
+
+__global__ __launch_bounds__(MT_THREADS) void cross_merge_bwd16_kernel(const float* __restrict__ gT, bf16_t* __restrict__ g2, int D, int H,
+                                                                        int W, int tiles_w) {
+  extern __shared__ __attribute__((aligned(16))) float s2[];   // [C2B][PL2]
+  const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
+  const int d0 = blockIdx.y * C2B, b = blockIdx.z, h0 = th * T2, w0 = tw * T2;
+  const size_t L = (size_t)H * W;
+  {
+    constexpr int N_IT = T2 * T2 * (C2B / 4) / MT_THREADS;   // 16 float4 per thread, eight in flight at a time
+#pragma unroll
+    for (int k0 = 0; k0 < N_IT; k0 += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int it = threadIdx.x + (k0 + k) * MT_THREADS;
+        const int pix = it / (C2B / 4), g = it - pix * (C2B / 4), py = pix / T2, px = pix - py * T2;
+        const int h = min(h0 + py, H - 1), w = min(w0 + px, W - 1);
+        v[k] = *reinterpret_cast<const float4*>(gT + ((size_t)b * L + (size_t)h * W + w) * D + d0 + g * 4);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int it = threadIdx.x + (k0 + k) * MT_THREADS;
+        const int pix = it / (C2B / 4), g = it - pix * (C2B / 4), py = pix / T2, px = pix - py * T2;
+        float* q = &s2[(g * 4) * PL2 + py * P2 + px];
+        q[0] = v[k].x; q[PL2] = v[k].y; q[2 * PL2] = v[k].z; q[3 * PL2] = v[k].w;
+      }
+    }
+  }
+  __syncthreads();
+  bf16_t* gb = g2 + (size_t)b * 2 * D * L;
+  const int lo = threadIdx.x % 16, hi = threadIdx.x / 16;
+  auto pk = [](float a, float c) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(c) << 16); };
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {  // row-major plane: pixel pairs along w
+    const int h = h0 + hi + 16 * r, w = w0 + 2 * lo;
+    if (h < H && w < W)
+      for (int c = 0; c < C2B; ++c) {
+        const float2 v = *reinterpret_cast<const float2*>(&s2[c * PL2 + (hi + 16 * r) * P2 + 2 * lo]);
+        *reinterpret_cast<uint32_t*>(gb + (size_t)(d0 + c) * L + (size_t)h * W + w) = pk(v.x, v.y);
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {  // column-major plane: pixel pairs along h
+    const int w = w0 + hi + 16 * r, h = h0 + 2 * lo;
+    if (h < H && w < W)
+      for (int c = 0; c < C2B; ++c) {
+        const float* q = &s2[c * PL2 + (2 * lo) * P2 + hi + 16 * r];
+        *reinterpret_cast<uint32_t*>(gb + ((size_t)D + d0 + c) * L + (size_t)w * H + h) = pk(q[0], q[P2]);
+      }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int LG_WAVES = 4;       // tokens in flight per workgroup (one wave each)
 constexpr int LG_TOK_BWD = 16;    // tokens walked by each wave of the backward kernel (d(gamma)/d(beta) accumulate in registers)
@@ -347,7 +472,13 @@ extern "C" int tamtr_cross_merge_fwd(const void* y4, float* ymT, int B, int D, i
   const dim3 grid(tiles_w * tiles_h, D / CB, B);
   if (plane_dtype == TAMTR_F32)
     hipLaunchKernelGGL(cross_merge_fwd_kernel<float>, grid, dim3(MT_THREADS), 0, (hipStream_t)stream, (const float*)y4, ymT, D, H, W, tiles_w);
-  else
+  else if (H % 2 == 0 && W % 2 == 0 && (uintptr_t)y4 % 4 == 0 && (uintptr_t)ymT % 16 == 0) {
+    const int t2w = (W + T2 - 1) / T2, t2h = (H + T2 - 1) / T2;
+    const size_t dyn = (size_t)C2B * PL2 * sizeof(float);
+    if (hipFuncSetAttribute((const void*)cross_merge_fwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return TAMTR_ELAUNCH;
+    hipLaunchKernelGGL(cross_merge_fwd16_kernel, dim3(t2w * t2h, D / C2B, B), dim3(MT_THREADS), dyn, (hipStream_t)stream, (const bf16_t*)y4, ymT, D, H,
+                       W, t2w);
+  } else
     hipLaunchKernelGGL(cross_merge_fwd_kernel<bf16_t>, grid, dim3(MT_THREADS), 0, (hipStream_t)stream, (const bf16_t*)y4, ymT, D, H, W, tiles_w);
   return tamtr_launch_status();
 }
@@ -359,7 +490,16 @@ extern "C" int tamtr_cross_merge_bwd(const float* gymT, void* g2, int B, int D, 
   const dim3 grid(tiles_w * tiles_h, D / CB, B);
   if (plane_dtype == TAMTR_F32)
     hipLaunchKernelGGL(cross_merge_bwd_kernel<float>, grid, dim3(MT_THREADS), 0, (hipStream_t)stream, gymT, (float*)g2, D, H, W, tiles_w);
-  else
+  else if (H % 2 == 0 && W % 2 == 0 && (uintptr_t)g2 % 4 == 0 && (uintptr_t)gymT % 16 == 0 &&
+           (long long)((W + T2 - 1) / T2) * ((H + T2 - 1) / T2) * T2 * T2 * 4 <= (long long)H * W * 5) {
+    // (the 32 x 32 tiles where they cover the map with at most 25 % overhang: 160^2 189 against 338 us; 80^2 = 2.5 tiles a side 148 / 152 us;
+    // 40^2 95 against 64 us - profiles/r04_ss2d_bf16_planes.txt)
+    const int t2w = (W + T2 - 1) / T2, t2h = (H + T2 - 1) / T2;
+    const size_t dyn = (size_t)C2B * PL2 * sizeof(float);
+    if (hipFuncSetAttribute((const void*)cross_merge_bwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return TAMTR_ELAUNCH;
+    hipLaunchKernelGGL(cross_merge_bwd16_kernel, dim3(t2w * t2h, D / C2B, B), dim3(MT_THREADS), dyn, (hipStream_t)stream, gymT, (bf16_t*)g2, D, H, W,
+                       t2w);
+  } else
     hipLaunchKernelGGL(cross_merge_bwd_kernel<bf16_t>, grid, dim3(MT_THREADS), 0, (hipStream_t)stream, gymT, (bf16_t*)g2, D, H, W, tiles_w);
   return tamtr_launch_status();
 }
