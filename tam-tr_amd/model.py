@@ -200,7 +200,10 @@ class RTDETRDetectionWorldModel(nn.Module):
                 args = (x, txt) if isinstance(m, TIAGELAN) else (x,)
                 names = _conv_weight_names(m) if grouped_cast else ()
                 if names:  # this layer's conv weights as bf16 copies from one kernel (see _CastGroup); same values autocast would use
-                    w16 = _CastGroup.apply(*[m.get_parameter(n) for n in names])
+                    masters = [m.get_parameter(n) for n in names]
+                    w16 = _CastGroup.apply(*masters)
+                    for c, p in zip(w16, masters):   # ops.conv2d_module sends a 1x1 convolution's fp32 weight gradient straight to the master
+                        c._tamtr_master = p
                     x = torch.func.functional_call(m, dict(zip(names, w16)), args)
                 else:
                     x = m(*args)

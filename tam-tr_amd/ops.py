@@ -713,6 +713,9 @@ def linear_bf16(x, weight, bias=None):
 
 
 # ------------------------------------------------------------------------------------------------ trunk: 1x1 convolutions' weight gradient
+_CONV1X1_NO_MASTER = _os.environ.get('TAMTR_CONV1X1_MASTER') == '0'   # A/B switch: the weight gradient rounded to bf16 for the cast group's copy
+
+
 class _Conv1x1CL(torch.autograd.Function):
     """y = conv2d(x, w) for a 1x1 / stride 1 / ungrouped convolution on a channels-last map, with the WEIGHT gradient taken off MIOpen.
     The forward stays on the library (tuned tables).  MIOpen's weight-gradient solvers for these shapes (and, for some, its input-gradient
@@ -723,9 +726,13 @@ class _Conv1x1CL(torch.autograd.Function):
     batched product + ordered slab sum of the tall linears (dw_splitk, slab_sum) - fp32 result, bitwise reproducible, no memset, no atomics."""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, master=None):
+        # master: the fp32 parameter `w` is this step's bf16 copy of (model._CastGroup).  The weight gradient comes out of the slab sum in
+        # fp32: it goes to the master as it is - not rounded to bf16 for the copy's sake and widened again by the cast group's backward
+        # (one cast kernel per 1x1 convolution and step, ~100 on the TAM-TR-s trunk) - and the copy gets no gradient.
         xp = x if _is_cl(x) else _pack_cl(x)            # a channel slice of a wider map: packed once, kept for the backward
         ctx.save_for_backward(xp, w)
+        ctx.to_master = master is not None
         return torch.nn.functional.conv2d(xp, w)
 
     @staticmethod
@@ -739,9 +746,11 @@ class _Conv1x1CL(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:   # dX [M, C1] = dY [M, C2] W [C2, C1]: a library GEMM (MIOpen's input-gradient solvers for some of these shapes memset too)
             gx = torch.mm(g2, w.view(C2, C1)).view(B, H, W, C1).permute(0, 3, 1, 2)
+        if ctx.to_master:
+            return gx, None, (dw_splitk(g2, x2).view(C2, C1, 1, 1) if ctx.needs_input_grad[2] else None)
         if ctx.needs_input_grad[1]:
             gw = dw_splitk(g2, x2).view(C2, C1, 1, 1).to(w.dtype)
-        return gx, gw
+        return gx, gw, None
 
 
 def _pack_cl(x):
@@ -757,7 +766,8 @@ def conv1x1_cl_ok(x, conv):
     weight needs a gradient: the case _Conv1x1CL serves."""
     return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and torch.is_grad_enabled()
             and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
-            and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and conv.weight.requires_grad
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+            and (conv.weight.requires_grad or getattr(conv.weight, '_tamtr_master', None) is not None)
             and bool(_cl_pitch(x)) and not x.is_contiguous() and x.shape[1] % 8 == 0 and x.data_ptr() % 16 == 0 and _cl_pitch(x) % 8 == 0)
 
 
@@ -769,6 +779,9 @@ def conv2d_module(conv, x):
         if torch.is_autocast_enabled('cuda') and w.dtype != x.dtype and x.dtype == torch.get_autocast_dtype('cuda'):
             w = w.to(x.dtype)    # (what autocast does inside conv2d; the trunk normally hands in the layer's bf16 copies already)
         if w.dtype == x.dtype:
+            master = None if _CONV1X1_NO_MASTER else getattr(w, '_tamtr_master', None)   # set by model.token_memory on the cast group's copies
+            if master is not None and master.requires_grad and master.dtype == torch.float32 and master.shape == w.shape:
+                return _Conv1x1CL.apply(x, w, master)
             return _Conv1x1CL.apply(x, w)
     return conv(x)
 

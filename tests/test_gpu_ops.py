@@ -811,6 +811,21 @@ def test_conv1x1_weight_gradient_off_the_library(ops, B, C1, C2, H, W, dt, slice
     assert_close(gw.double(), ref, tol, tol * float(ref.abs().max()), 'dW')
     err_own, err_lib = float((gw.double() - ref).norm() / ref.norm()), float((gwr.double() - ref).norm() / ref.norm())
     assert err_own <= 1.5 * err_lib + 1e-6, (err_own, err_lib)                              # no worse than the library's own weight gradient
+    if dt == torch.bfloat16:
+        # the weight as a bf16 COPY of an fp32 master (model._CastGroup): the fp32 slab sum goes to the master unrounded, the copy gets nothing
+        master = conv.weight.detach().clone().requires_grad_()
+        x, copy16 = x0.detach().clone(memory_format=torch.preserve_format).requires_grad_(), master.detach().to(dt).requires_grad_()
+        if sliced:
+            x = wide.detach().clone(memory_format=torch.preserve_format).requires_grad_().chunk(2, 1)[1]
+        copy16._tamtr_master = master
+        m = nn.Conv2d(C1, C2, 1, bias=False).cuda()
+        del m.weight
+        m.weight = copy16           # (what torch.func.functional_call does for the duration of the layer's forward)
+        ym = ops.conv2d_module(m, x)
+        gm, gc = torch.autograd.grad(ym, [master, copy16], cot, allow_unused=True)
+        assert gc is None and gm.dtype == torch.float32 and torch.equal(ym, y)
+        assert torch.equal(gm.to(dt), gw), 'the master receives the same sum, before its rounding to bf16'
+        assert float((gm.double() - ref).norm() / ref.norm()) <= err_own + 1e-9
 
 
 def test_fused_optim_step_equals_clip_adamw_ema():
