@@ -275,6 +275,8 @@ def main():
                          'tam-tr_amd/tuned/miopen (default), a fresh search (minutes), or its heuristic')
     ap.add_argument('--conv-db', default=None, help='directory the search writes its tables to (--conv-tuning search)')
     ap.add_argument('--grad-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire (N > 1)')
+    ap.add_argument('--weight-shadows', default='on', choices=['on', 'off'],
+                    help='bf16 mode with --optim-step fused: the optimizer kernel maintains the bf16 copies of the weights (engine.FusedOptimStep(shadows=True))')
     ap.add_argument('--optim-step', default='fused', choices=['fused', 'torch'],
                     help='clip + AdamW + EMA as the table-driven kernels of csrc/optim.hip (engine.FusedOptimStep) or as the three torch calls')
     ap.add_argument('--no-graph-check', action='store_true', help='skip the graph-vs-eager step and the standalone roofline_other launches after the timed loop (profiling runs: keeps the trace to the timed steps)')
@@ -314,7 +316,9 @@ def main():
     from tamtr_amd.engine import FusedOptimStep, ModelEMA
     ema = ModelEMA(model)   # the reference's optimizer_step ends with ema.update(model) on every rank (trainer.py:259,478-479)
     # clip_grad_norm_(0.1) + AdamW.step() + ema.update() as four launches over a device table (csrc/optim.hip); --optim-step torch: the three torch calls
-    stepper = FusedOptimStep.create(model, opt, ema, max_norm=0.1) if args.optim_step == 'fused' else None
+    # --weight-shadows on: the update kernel also keeps the bf16 compute copies of the weights (what autocast casts per use)
+    shadows = args.weight_shadows == 'on' and args.dtype == 'bf16'
+    stepper = FusedOptimStep.create(model, opt, ema, max_norm=0.1, shadows=shadows) if args.optim_step == 'fused' else None
     reducer = None
     if world > 1:
         reducer = tdist.GradReducer(model.named_parameters(), skip=lambda n: '.attn.' in n, late=lambda n: 'denoising_class_embed' in n,
@@ -428,7 +432,7 @@ def main():
                        'reduced_precision': 'bf16 (BASELINE configs[4] names fp16: this build serves every reduced-precision configuration as bf16 - same MFMA rate on gfx950, fp32 exponent range, no loss scaler; DESIGN 7)', 'final_loss': float(loss.detach()),
                        'bf16_vs_fp32': mode_err, 'dist_backend': backend, 'dist_world_size': world,
                        'grad_bucket_dtype': (args.grad_dtype if world > 1 else None), 'static_part': static_part,
-                       'optim_step': 'fused (csrc/optim.hip)' if stepper is not None else 'torch', 'static_part_check': _brief(getattr(model, 'static_part_check', None)), 'graph_vs_eager': gve, 'conv_tuning': conv_tuning,
+                       'optim_step': 'fused (csrc/optim.hip)' if stepper is not None else 'torch', 'weight_shadows': bool(stepper is not None and stepper.use_shadows), 'static_part_check': _brief(getattr(model, 'static_part_check', None)), 'graph_vs_eager': gve, 'conv_tuning': conv_tuning,
                        'hbm_GiB_peak': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
             'roofline': None if ks is None else {
                 'bound': 'mfma', 'kernel': 'linear_bf16_wstat_kernel<512> (MEH value_proj x3 + enc_output and their dX, M=%d N=K=512)'

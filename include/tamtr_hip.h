@@ -437,9 +437,13 @@ int tamtr_img_augment_u8(const uint8_t* src, const double* inv_affine, const uin
  *                     pieces of tamtr_optim_chunk() elements;  grads: THIS step's gradient addresses (0: none - Adam skipped, EMA still taken).
  *        partial f32 [nchunks], normcoef f32 [2] workspaces; normcoef = {total gradient norm, clip coefficient} afterwards (device side:
  *                     nothing is read back).  lr, wd: HOST arrays [ngroups <= 4].  max_norm <= 0: no clipping.  do_ema == 0: EMA untouched.
- *      The clipped gradient is written back to the gradient buffers, as clip_grad_norm_ leaves it. */
+ *      The clipped gradient is written back to the gradient buffers, as clip_grad_norm_ leaves it.
+ *        shadow       NULL, or a device array of addresses of bf16 arrays with the element order of p (0: none): the updated value of every
+ *                     tensor that has a gradient this step is ALSO stored there rounded to bf16 - the compute copy that bf16 autocast casts out
+ *                     of the fp32 master at every use (trainer.py:343 `torch.cuda.amp.autocast`); engine.FusedOptimStep(shadows=True). */
 int tamtr_optim_chunk(void);
-int tamtr_optim_step(const void* const* p, const void* const* m, const void* const* v, const void* const* e, float* step, const long long* numel,
+int tamtr_optim_step(const void* const* p, const void* const* m, const void* const* v, const void* const* e, const void* const* shadow, float* step,
+                     const long long* numel,
                      const unsigned char* group, const int* chunk_tensor, const long long* chunk_off, const void* const* grads, int ntensors,
                      int nchunks, float* partial, float* normcoef, const float* lr, const float* wd, int ngroups, float beta1, float beta2, float eps,
                      float max_norm, float ema_decay, int do_ema, void* stream);

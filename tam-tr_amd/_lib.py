@@ -10,7 +10,7 @@ from ctypes import c_float, c_int, c_longlong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TAMTR_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libtamtr_hip.so')  # env override: kernel A/B experiments
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 F32, BF16 = 0, 1
 _ERR = {-1: 'TAMTR_EINVAL (bad argument)', -2: 'TAMTR_EUNSUP (shape/dtype outside what the kernels are built for)',
@@ -72,7 +72,7 @@ _SIGS = {
     'tamtr_xproj_bwd_dx': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'tamtr_xproj_bwd_dw': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'tamtr_optim_chunk': [],
-    'tamtr_optim_step': [_P] * 10 + [_I, _I, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _P],
+    'tamtr_optim_step': [_P] * 11 + [_I, _I, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _P],
     'tamtr_resample2': [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     'tamtr_cat_rows': [_P, _P, _P, _I, _P, _LL, _LL, _I, _P],
     'tamtr_copy_rows': [_P, _LL, _P, _LL, _LL, _I, _I, _P],

@@ -10,6 +10,8 @@
 //   pass 3  update     per chunk: g *= coef (written back: the clipped gradient is what clip_grad_norm_ leaves in .grad), decoupled
 //                      weight decay, Adam moments, bias-corrected step (torch's FusedAdamKernel arithmetic, fp32), and the EMA
 //                      v = d v + (1 - d) p of the NEW parameter value in the same pass (p is not re-read)       (g p m v e: 5 reads, 5 writes)
+//                      + optionally the bf16 SHADOW of the new value: the copy autocast would cast out of the fp32 master at every use of the
+//                      weight in the next step (~400 cast launches per step on this graph) is written here, where the value is in registers
 // The norm never visits the host.  A tensor without a gradient this step (grad pointer 0: the 30 discarded-gate parameters, SURVEY D2;
 // denoising_class_embed on a batch without boxes) skips Adam exactly like torch (its step count does not advance) but still takes part
 // in the EMA; EMA-only entries (BatchNorm running statistics) have no moment buffers at all.  All sums are in a fixed order.
@@ -25,6 +27,7 @@ struct OptTable {                    // device arrays, one entry per tensor (bui
   float* const* m;                   // exp_avg        (0: EMA-only entry)
   float* const* v;                   // exp_avg_sq
   float* const* e;                   // EMA copy       (0: no EMA)
+  unsigned short* const* sh;         // bf16 shadow of the parameter (array may be null; entry 0: none): the compute copy bf16 mode casts per use
   float* step;                       // per-tensor Adam step counts (float, as torch keeps them)
   const long long* numel;
   const unsigned char* group;        // parameter group (lr / weight decay) of the tensor
@@ -91,8 +94,8 @@ struct OptScalars {
 
 template <bool VEC>
 __device__ __forceinline__ void opt_update_span(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                float* __restrict__ e, long long n, float coef, float lr, float wd, float b1, float b2, float eps,
-                                                float step_size, float bc2_sqrt, float d) {
+                                                float* __restrict__ e, unsigned short* __restrict__ sh, long long n, float coef, float lr, float wd,
+                                                float b1, float b2, float eps, float step_size, float bc2_sqrt, float d) {
   constexpr int W = VEC ? 4 : 1;
   for (long long i = (long long)threadIdx.x * W; i + W <= n; i += (long long)OPT_THREADS * W) {
     float pv[W], ev[W];
@@ -117,7 +120,8 @@ __device__ __forceinline__ void opt_update_span(float* __restrict__ p, float* __
         *reinterpret_cast<float4*>(g + i) = make_float4(gv[0], gv[1], gv[2], gv[3]);
         *reinterpret_cast<float4*>(m + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
         *reinterpret_cast<float4*>(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-      } else { p[i] = pv[0]; g[i] = gv[0]; m[i] = mv[0]; v[i] = vv[0]; }
+        if (sh) *reinterpret_cast<uint2*>(sh + i) = make_uint2((uint32_t)f2bf(pv[0]) | ((uint32_t)f2bf(pv[1]) << 16), (uint32_t)f2bf(pv[2]) | ((uint32_t)f2bf(pv[3]) << 16));
+      } else { p[i] = pv[0]; g[i] = gv[0]; m[i] = mv[0]; v[i] = vv[0]; if (sh) sh[i] = f2bf(pv[0]); }
     } else if (e) {
       if constexpr (VEC) { const float4 a = *reinterpret_cast<const float4*>(p + i); pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w; }
       else pv[0] = p[i];
@@ -141,6 +145,7 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_update_kernel(OptTable T, flo
   float* m = T.m[ti];
   float* g = m ? grads[ti] : nullptr;
   float* e = do_ema ? T.e[ti] : nullptr;
+  unsigned short* sh = (g && T.sh) ? T.sh[ti] : nullptr;   // (a tensor without a gradient keeps its value: its shadow stays valid)
   if (!g && !e) return;
   float* v = nullptr;
   float step_size = 0.f, bc2_sqrt = 1.f;
@@ -152,17 +157,18 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_update_kernel(OptTable T, flo
     bc2_sqrt = sqrtf(1.f - powf(S.beta2, step));
   }
   if (e) e += off;
+  if (sh) sh += off;
   const uintptr_t al = reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
-                       reinterpret_cast<uintptr_t>(e);
+                       reinterpret_cast<uintptr_t>(e) | (reinterpret_cast<uintptr_t>(sh) << 1);   // (8-byte aligned bf16 quads)
   const float coef = normcoef[1];
   if ((al & 15) == 0) {
     const long long n4 = n / 4 * 4;
-    opt_update_span<true>(p, g, m, v, e, n4, coef, S.lr[grp], S.wd[grp], S.beta1, S.beta2, S.eps, step_size, bc2_sqrt, S.ema_decay);
+    opt_update_span<true>(p, g, m, v, e, sh, n4, coef, S.lr[grp], S.wd[grp], S.beta1, S.beta2, S.eps, step_size, bc2_sqrt, S.ema_decay);
     if (n4 < n)
-      opt_update_span<false>(p + n4, g ? g + n4 : g, m ? m + n4 : m, v ? v + n4 : v, e ? e + n4 : e, n - n4, coef, S.lr[grp], S.wd[grp], S.beta1, S.beta2,
+      opt_update_span<false>(p + n4, g ? g + n4 : g, m ? m + n4 : m, v ? v + n4 : v, e ? e + n4 : e, sh ? sh + n4 : sh, n - n4, coef, S.lr[grp], S.wd[grp], S.beta1, S.beta2,
                              S.eps, step_size, bc2_sqrt, S.ema_decay);
   } else {
-    opt_update_span<false>(p, g, m, v, e, n, coef, S.lr[grp], S.wd[grp], S.beta1, S.beta2, S.eps, step_size, bc2_sqrt, S.ema_decay);
+    opt_update_span<false>(p, g, m, v, e, sh, n, coef, S.lr[grp], S.wd[grp], S.beta1, S.beta2, S.eps, step_size, bc2_sqrt, S.ema_decay);
   }
 }
 
@@ -177,7 +183,8 @@ __global__ void opt_step_count_kernel(OptTable T, const float* const* __restrict
 extern "C" int tamtr_optim_chunk(void) { return OPT_CHUNK; }
 
 /* see include/tamtr_hip.h */
-extern "C" int tamtr_optim_step(const void* const* p, const void* const* m, const void* const* v, const void* const* e, float* step,
+extern "C" int tamtr_optim_step(const void* const* p, const void* const* m, const void* const* v, const void* const* e, const void* const* shadow,
+                                float* step,
                                 const long long* numel, const unsigned char* group, const int* chunk_tensor, const long long* chunk_off,
                                 const void* const* grads, int ntensors, int nchunks, float* partial, float* normcoef, const float* lr,
                                 const float* wd, int ngroups, float beta1, float beta2, float eps, float max_norm, float ema_decay, int do_ema,
@@ -186,7 +193,7 @@ extern "C" int tamtr_optim_step(const void* const* p, const void* const* m, cons
     return TAMTR_EINVAL;
   if (ntensors <= 0 || nchunks <= 0 || ngroups <= 0) return TAMTR_EINVAL;
   if (ngroups > 4) return TAMTR_EUNSUP;
-  OptTable T{(float* const*)p, (float* const*)m, (float* const*)v, (float* const*)e, step, numel, group, chunk_tensor, chunk_off};
+  OptTable T{(float* const*)p, (float* const*)m, (float* const*)v, (float* const*)e, (unsigned short* const*)shadow, step, numel, group, chunk_tensor, chunk_off};
   OptScalars S;
   for (int i = 0; i < 4; ++i) { S.lr[i] = lr[i < ngroups ? i : 0]; S.wd[i] = wd[i < ngroups ? i : 0]; }
   S.beta1 = beta1; S.beta2 = beta2; S.eps = eps; S.ema_decay = ema_decay;

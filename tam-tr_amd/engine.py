@@ -126,16 +126,46 @@ class FusedOptimStep:
     """
 
     @staticmethod
-    def create(model, optimizer, ema=None, max_norm=0.1):
+    def create(model, optimizer, ema=None, max_norm=0.1, shadows=False):
+        """shadows=True: the update kernel also stores every new parameter value rounded to bf16 (`p._tamtr_bf16`, ops.bf16_of): the compute
+        copies that bf16 autocast would cast out of the fp32 masters at every use in the next step.  They follow the masters as long as the
+        masters are changed by THIS object's step() (or by load_state_dict on the model: a hook refreshes them); ops.bf16_of re-checks the
+        tensor version on every use and falls back to a cast, so a stale copy is never read on the eager path - recorded graphs read the
+        shadows' memory directly, so re-capture (model.capture_static_part) after switching shadows on or off."""
         ps = [p for g in optimizer.param_groups for p in g['params']]
         ok = (type(optimizer) is torch.optim.AdamW and len(optimizer.param_groups) <= 4 and ps
               and all(p.is_cuda and p.dtype == torch.float32 and (p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)) for p in ps)
               and not any(g.get('amsgrad') or g.get('maximize') or g.get('capturable') or g.get('differentiable') for g in optimizer.param_groups))
-        return FusedOptimStep(model, optimizer, ema, max_norm) if ok else None
+        if not ok:
+            return None
+        st = FusedOptimStep(model, optimizer, ema, max_norm, shadows)
+        if shadows:
+            st._build()          # the copies exist before the first forward (and before a graph capture records their addresses)
+        return st
 
-    def __init__(self, model, optimizer, ema=None, max_norm=0.1):
+    def __init__(self, model, optimizer, ema=None, max_norm=0.1, shadows=False):
         self.model, self.opt, self.ema, self.max_norm = model, optimizer, ema, float(max_norm)
+        self.use_shadows = bool(shadows)
+        self.shadows = []        # (parameter, bf16 copy) pairs
         self._key = None
+        self._hook = None
+
+    def refresh_shadows(self):
+        """Re-derive every bf16 copy from its master (after the masters were changed by anything but step())."""
+        with torch.no_grad():
+            if self.shadows:
+                torch._foreach_copy_([s for _, s in self.shadows], [p for p, _ in self.shadows])
+            for p, s in self.shadows:
+                s._tamtr_version = p._version
+
+    def drop_shadows(self):
+        for p, _ in self.shadows:
+            if hasattr(p, '_tamtr_bf16'):
+                del p._tamtr_bf16
+        self.shadows = []
+        if self._hook is not None:
+            self._hook.remove()
+            self._hook = None
 
     def _state_key(self):
         first = self.opt.param_groups[0]['params'][0]
@@ -165,8 +195,18 @@ class FusedOptimStep:
                     ema_of[id(v)] = esd[k]
         n = len(entries)
         steps = torch.zeros(n, device=dev, dtype=torch.float32)
-        P, M, V, E, numel, group = [], [], [], [], [], []
+        P, M, V, E, SH, numel, group = [], [], [], [], [], [], []
+        old_sh = {id(p): s for p, s in self.shadows}
+        self.shadows = []
         for i, (t, gi, adam) in enumerate(entries):
+            sh = None
+            if adam and self.use_shadows:
+                sh = old_sh.get(id(t))
+                if sh is None or sh.shape != t.shape or sh.stride() != t.stride() or sh.device != t.device:
+                    sh = torch.empty_like(t, dtype=torch.bfloat16, memory_format=torch.preserve_format)
+                t._tamtr_bf16 = sh
+                self.shadows.append((t, sh))
+            SH.append(sh.data_ptr() if sh is not None else 0)
             m = v = None
             if adam:
                 st = self.opt.state[t]
@@ -190,7 +230,10 @@ class FusedOptimStep:
             for off in range(0, nel, chunk):
                 ct.append(i); co.append(off)
         I64 = lambda x: torch.tensor(x, dtype=torch.int64, device=dev)   # noqa: E731
-        self.tab = {'p': I64(P), 'm': I64(M), 'v': I64(V), 'e': I64(E), 'numel': I64(numel), 'group': torch.tensor(group, dtype=torch.uint8, device=dev),
+        self.refresh_shadows()
+        if self.use_shadows and self._hook is None and hasattr(self.model, 'register_load_state_dict_post_hook'):
+            self._hook = self.model.register_load_state_dict_post_hook(lambda *_: self.refresh_shadows())
+        self.tab = {'p': I64(P), 'm': I64(M), 'v': I64(V), 'e': I64(E), 'sh': I64(SH) if self.use_shadows else None, 'numel': I64(numel), 'group': torch.tensor(group, dtype=torch.uint8, device=dev),
                     'ct': torch.tensor(ct, dtype=torch.int32, device=dev), 'co': I64(co), 'step': steps,
                     'partial': torch.empty(len(ct), device=dev, dtype=torch.float32), 'norm': torch.zeros(2, device=dev, dtype=torch.float32)}
         self.entries, self.n, self.nchunks, self.dev = entries, n, len(ct), dev
@@ -229,9 +272,26 @@ class FusedOptimStep:
             do_ema, d = 1, self.ema.decay(self.ema.updates)
         T = self.tab
         P = _lib.ptr
-        _lib.call('tamtr_optim_step', P(T['p']), P(T['m']), P(T['v']), P(T['e']), P(T['step']), P(T['numel']), P(T['group']), P(T['ct']), P(T['co']),
+        _lib.call('tamtr_optim_step', P(T['p']), P(T['m']), P(T['v']), P(T['e']), P(T['sh']), P(T['step']), P(T['numel']), P(T['group']), P(T['ct']), P(T['co']),
                   P(gptr), self.n, self.nchunks, P(T['partial']), P(T['norm']), ctypes.cast(lr, ctypes.c_void_p), ctypes.cast(wd, ctypes.c_void_p), ng,
                   float(b1), float(b2), float(groups[0]['eps']), self.max_norm, float(d), do_ema, _lib.stream_ptr())
+        if self.shadows:   # the kernel rewrote the copy of every tensor that had a gradient; anything else that changed under us is re-derived
+            stale = []
+            k = 0
+            for i, (t, _, adam) in enumerate(self.entries):
+                if not adam:
+                    continue
+                s = self.shadows[k][1]
+                k += 1
+                if s._tamtr_version != t._version:
+                    if ptrs[i]:
+                        s._tamtr_version = t._version
+                    else:
+                        stale.append((t, s))
+            if stale:
+                torch._foreach_copy_([s for _, s in stale], [t for t, _ in stale])
+                for t, s in stale:
+                    s._tamtr_version = t._version
         return T['norm']
 
 
@@ -473,7 +533,7 @@ def fit(model, train_loader, prepare, epochs, val_loader=None, lr0=1e-4, lrf=1.0
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lf)
     ema = ModelEMA(model) if rank == 0 else None
     # clip + optimizer step + EMA as one table-driven launch group when the combination is served (AdamW, fp32 parameters on the GPU)
-    stepper = FusedOptimStep.create(model, opt, ema, max_norm=0.1)
+    stepper = FusedOptimStep.create(model, opt, ema, max_norm=0.1, shadows=getattr(model, 'autocast_dtype', None) == torch.bfloat16)
     history, best, steps, start = [], None, 0, 0
     if resume is not None:
         start = int(resume.get('epoch', -1)) + 1

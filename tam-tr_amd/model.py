@@ -100,6 +100,28 @@ class _CastGroup(torch.autograd.Function):
         return tuple(res)
 
 
+class _ShadowGroup(torch.autograd.Function):
+    """_CastGroup when the optimizer keeps the bf16 copies up to date itself (engine.FusedOptimStep(shadows=True)): the forward hands out
+    aliases of those copies - no kernel - and the backward is _CastGroup's (one multi-tensor cast of the bf16 gradients to fp32)."""
+
+    @staticmethod
+    def forward(ctx, n, *ts):
+        ctx.set_materialize_grads(False)
+        return tuple(s.view_as(s) for s in ts[n:])
+
+    @staticmethod
+    def backward(ctx, *gs):
+        return (None,) + _CastGroup.backward(ctx, *gs) + (None,) * len(gs)
+
+
+def _cast_group(masters):
+    from . import ops
+    sh = [ops.bf16_shadow(p) for p in masters]
+    if all(s is not None for s in sh):
+        return _ShadowGroup.apply(len(masters), *masters, *sh)
+    return _CastGroup.apply(*masters)
+
+
 def _conv_weight_names(m):
     names = getattr(m, '_tamtr_conv_names', None)
     if names is None:
@@ -201,7 +223,7 @@ class RTDETRDetectionWorldModel(nn.Module):
                 names = _conv_weight_names(m) if grouped_cast else ()
                 if names:  # this layer's conv weights as bf16 copies from one kernel (see _CastGroup); same values autocast would use
                     masters = [m.get_parameter(n) for n in names]
-                    w16 = _CastGroup.apply(*masters)
+                    w16 = _cast_group(masters)
                     for c, p in zip(w16, masters):   # ops.conv2d_module sends a 1x1 convolution's fp32 weight gradient straight to the master
                         c._tamtr_master = p
                     x = torch.func.functional_call(m, dict(zip(names, w16)), args)

@@ -95,7 +95,7 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i, lin in enumerate(self.layers):
-            x = lin(x)
+            x = ops.linear(x, lin)
             if i + 1 < self.num_layers:
                 x = F.relu(x)
         return x
@@ -177,7 +177,7 @@ class MSDeformAttn(nn.Module):
         else:
             raise ValueError(f'Last dim of reference_points must be 2 or 4, but got {n}.')
         out = ops.ms_deform_attn_core(v, value_shapes, loc, aw)
-        return self.output_proj(out.to(query.dtype))
+        return ops.linear(out.to(query.dtype), self.output_proj)
 
 
 class _SelfAttention(nn.Module):
@@ -196,11 +196,11 @@ class _SelfAttention(nn.Module):
     def forward(self, qk, v, attn_mask=None):
         B, Q, C = qk.shape
         w, b = self.in_proj_weight, self.in_proj_bias
-        qk_p = F.linear(qk, w[:2 * C], b[:2 * C])  # q and k share their input: one GEMM
-        v_p = F.linear(v, w[2 * C:], b[2 * C:])
+        qk_p = ops.linear_rows(qk, w, b, 0, 2 * C)  # q and k share their input: one GEMM
+        v_p = ops.linear_rows(v, w, b, 2 * C, 3 * C)
         q, k = qk_p[..., :C], qk_p[..., C:]
         o = ops.self_attention(q, k, v_p, self.num_heads, attn_mask)
-        return self.out_proj(o)
+        return ops.linear(o, self.out_proj)
 
 
 class DeformableTransformerDecoderLayer(nn.Module):
@@ -222,7 +222,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, tgt):
-        return self.norm3(tgt + self.linear2(self.act(self.linear1(tgt))))
+        return self.norm3(tgt + ops.linear(self.act(ops.linear(tgt, self.linear1)), self.linear2))
 
     def forward(self, embed, refer_bbox, feats, shapes, padding_mask=None, attn_mask=None, query_pos=None):
         qk = self.with_pos_embed(embed, query_pos)

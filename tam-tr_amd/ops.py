@@ -515,16 +515,110 @@ def dw_splitk(g2, x2):
     return slab_sum(torch.bmm(a, b))
 
 
+def bf16_shadow(p):
+    """The bf16 copy of an fp32 parameter that the optimizer kernel keeps next to it (engine.FusedOptimStep(shadows=True)), if it is there and
+    still describes the parameter's current value (same tensor version as when it was last derived); else None."""
+    s = getattr(p, '_tamtr_bf16', None)
+    if s is not None and s._tamtr_version == p._version and s.device == p.device and s.shape == p.shape:
+        return s
+    return None
+
+
+def bf16_of(p):
+    """A weight as bf16 for this step's products: the optimizer's shadow copy when there is one (no kernel), else the cast that autocast does."""
+    if p.dtype == torch.bfloat16:
+        return p
+    s = bf16_shadow(p)
+    return s if s is not None else p.to(torch.bfloat16)
+
+
+class _LinearMaster(torch.autograd.Function):
+    """y = x W^T + b for the SHORT token-wise linears of the decoder side (M = B * Q rows; nn.Linear under bf16 autocast, transformer.py:
+    539-558,869-889) with the gradients of W and b produced in fp32 FOR THE fp32 MASTERS: autocast's form casts W and b to bf16 per use, gets
+    bf16 gradients for the copies (the bias gradient from a torch reduction behind a memset) and casts each back - per linear and step four
+    cast kernels, a reduction and a memset around three GEMMs.  Here: the optimizer's shadow copies (ops.bf16_of), dW = dY^T X as one GEMM with
+    fp32 output, db by the ordered column-sum kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w16=None, b16=None):
+        # (w16 / b16: the caller's bf16 copies, for a SLICE of a parameter - e.g. the q/k and v rows of a packed in_proj - whose shadow is
+        # the same slice of the parameter's shadow)
+        w16 = bf16_of(weight) if w16 is None else w16
+        b16 = None if bias is None else (bf16_of(bias) if b16 is None else b16)
+        x16 = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+        ctx.save_for_backward(x16, w16)
+        ctx.cfg = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        return torch.nn.functional.linear(x16, w16, b16)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x16, w16 = ctx.saved_tensors
+        x_dt, w_dt, b_dt = ctx.cfg
+        N, K = w16.shape
+        g2 = _c(gy.reshape(-1, N).to(torch.bfloat16))
+        x2 = _c(x16.reshape(-1, K))
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.mm(g2, w16).view(x16.shape).to(x_dt)
+        if ctx.needs_input_grad[1]:
+            gw = _mm_f32(g2.t(), x2).to(w_dt)
+        if b_dt is not None and ctx.needs_input_grad[2]:
+            gb = colsum(g2).to(b_dt)
+        return gx, gw, gb, None, None
+
+
+_MM_F32_OUT = None
+
+
+def _mm_f32(a, b):
+    """a @ b for bf16 operands with the fp32 accumulator stored as it is (no rounding to bf16, no cast kernel) where this torch build's
+    mm takes out_dtype; else the bf16 product widened."""
+    global _MM_F32_OUT
+    if _MM_F32_OUT is not False:
+        try:
+            out = torch.mm(a, b, out_dtype=torch.float32)
+            _MM_F32_OUT = True
+            return out
+        except (NotImplementedError, RuntimeError, TypeError):
+            if _MM_F32_OUT:
+                raise
+            _MM_F32_OUT = False
+    return torch.mm(a, b).float()
+
+
+def linear_master_ok(x, lin):
+    return (x.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+            and isinstance(lin, torch.nn.Linear) and lin.weight.dtype == torch.float32 and x.dtype in (torch.float32, torch.bfloat16)
+            and lin.in_features % 8 == 0 and lin.out_features % 8 == 0 and _os.environ.get('TAMTR_LINEAR_MASTER') != '0')
+
+
+def linear(x, lin):
+    """lin(x) for an nn.Linear of the decoder side: in bf16 training mode on the GPU through _LinearMaster, else the module itself."""
+    if linear_master_ok(x, lin):
+        return _LinearMaster.apply(x, lin.weight, lin.bias)
+    return lin(x)
+
+
+def linear_rows(x, weight, bias, lo, hi):
+    """F.linear(x, weight[lo:hi], bias[lo:hi]) - a row block of a packed projection (nn.MultiheadAttention's in_proj) - the same way."""
+    w, b = weight[lo:hi], bias[lo:hi]
+    if (x.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+            and weight.dtype == torch.float32 and weight.shape[1] % 8 == 0 and (hi - lo) % 8 == 0 and _os.environ.get('TAMTR_LINEAR_MASTER') != '0'):
+        return _LinearMaster.apply(x, w, b, bf16_of(weight)[lo:hi], bf16_of(bias)[lo:hi])
+    return torch.nn.functional.linear(x, w, b)
+
+
 class _LinearSplitK(torch.autograd.Function):
     """y = x W^T + b through the library GEMM (forward and dX); dW through dw_splitk.  For the tall-skinny linears of the
     VSS blocks (in_proj / out_proj / fc1 / fc2: M = B*H*W rows, 128..2048 features)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        w16 = weight.to(x.dtype)
+        bf = x.dtype == torch.bfloat16
+        w16 = bf16_of(weight) if bf else weight.to(x.dtype)
         ctx.save_for_backward(x, w16)
         ctx.cfg = (weight.dtype, None if bias is None else bias.dtype)
-        return torch.nn.functional.linear(x, w16, None if bias is None else bias.to(x.dtype))
+        return torch.nn.functional.linear(x, w16, None if bias is None else (bf16_of(bias) if bf else bias.to(x.dtype)))
 
     @staticmethod
     def backward(ctx, gy):
@@ -554,7 +648,7 @@ class _LinearBF16(torch.autograd.Function):
         x2 = _c(x.reshape(-1, K))
         if x2.dtype != torch.bfloat16:
             raise _lib.TamtrHipError('linear_bf16 needs bf16 activations')
-        w16 = _c(weight.to(torch.bfloat16))
+        w16 = _c(bf16_of(weight))
         b32 = _c(bias.float()) if bias is not None else None
         y = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.bfloat16)
         rec = KERNEL_EVENTS.get('tamtr_linear_bf16')
@@ -630,7 +724,7 @@ class _LinearBF16ZeroRows(torch.autograd.Function):
         B, L, K = x.shape
         N = weight.shape[0]
         x2 = _c(x.reshape(-1, K))
-        w16 = _c(weight.to(torch.bfloat16))
+        w16 = _c(bf16_of(weight))
         b32 = _c(bias.float())
         y = torch.empty(B, L, N, device=x.device, dtype=torch.bfloat16)
         rec = KERNEL_EVENTS.get('tamtr_linear_bf16')

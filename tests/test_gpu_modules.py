@@ -484,6 +484,58 @@ def test_training_step_never_synchronises(pkg):
     assert torch.isfinite(loss).item() and torch.isfinite(loss2).item()
 
 
+def test_weight_shadows_train_like_autocast_casts(pkg):
+    """bf16 training with the optimizer kernel maintaining the bf16 copies of the weights (engine.FusedOptimStep(shadows=True)): after
+    every step each parameter's copy IS the master rounded to bf16 (bit for bit), the trunk's cast groups hand out aliases of the copies
+    (no multi-tensor cast), and - after three large steps, so that a stale copy would be far off - the token memory computed from the
+    copies equals the one computed with per-use casts of the same masters."""
+    from tamtr_amd.engine import FusedOptimStep, ModelEMA
+    torch.manual_seed(0)
+    model = pkg.model.RTDETRDetectionWorldModel(nc=10).cuda().train()
+    for m in model.modules():
+        if hasattr(m, 'drop_prob'):
+            m.drop_prob = 0.0
+    model.autocast_dtype = torch.bfloat16
+    B, S = 2, 128
+    g = torch.Generator().manual_seed(3)
+    batch = {'img': torch.rand(B, 3, S, S, generator=g).cuda(),
+             'txt_feats': torch.nn.functional.normalize(torch.randn(B, 10, 512, generator=g), dim=-1).cuda(),
+             'cls': torch.randint(0, 10, (7, 1), generator=g).float(),
+             'bboxes': torch.cat([0.2 + 0.6 * torch.rand(7, 2, generator=g), 0.02 + 0.2 * torch.rand(7, 2, generator=g)], 1),
+             'batch_idx': torch.tensor([0., 0, 0, 1, 1, 1, 1])}
+    w0 = {n: p.detach().clone() for n, p in model.named_parameters()}
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-3, weight_decay=1e-4, fused=True)
+    st = FusedOptimStep.create(model, opt, ModelEMA(model), max_norm=0.1, shadows=True)
+    assert st is not None and len(st.shadows) == len(w0)
+    calls = {'cast': 0, 'alias': 0}
+    cg, sg = pkg.model._CastGroup.forward, pkg.model._ShadowGroup.forward
+    pkg.model._CastGroup.forward = staticmethod(lambda ctx, *a: (calls.__setitem__('cast', calls['cast'] + 1), cg(ctx, *a))[1])
+    pkg.model._ShadowGroup.forward = staticmethod(lambda ctx, *a: (calls.__setitem__('alias', calls['alias'] + 1), sg(ctx, *a))[1])
+    try:
+        for step in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss, _ = model(batch)
+            assert torch.isfinite(loss).item()
+            loss.backward()
+            st.step()
+            bad = [n for n, p in model.named_parameters() if pkg.ops.bf16_shadow(p) is None or not torch.equal(pkg.ops.bf16_shadow(p), p.detach().bfloat16())]
+            assert not bad, (step, bad[:5])
+        assert calls['alias'] > 0 and calls['cast'] == 0, calls
+        moved = max(float((p.detach() - w0[n]).abs().max()) for n, p in model.named_parameters() if p.grad is not None)
+        assert moved > 5e-3, moved                       # the masters are far from where the copies started
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        fa = model.token_memory(batch['img'], batch['txt_feats'])[0].detach().float()
+        assert calls['cast'] == 0
+        st.drop_shadows()
+        model.load_state_dict(sd)                        # (BatchNorm statistics back to where the first pass found them)
+        fb = model.token_memory(batch['img'], batch['txt_feats'])[0].detach().float()
+        assert calls['cast'] > 0
+    finally:
+        pkg.model._CastGroup.forward, pkg.model._ShadowGroup.forward = staticmethod(cg), staticmethod(sg)
+    assert torch.isfinite(fa).all() and float(fa.abs().max()) > 0
+    assert_close(fa, fb, 2e-3, 2e-3 * float(fb.abs().max()), 'token memory: shadow copies vs per-use casts')
+
+
 def test_full_model_real_vss_vs_oracle(pkg):
     """Whole graph WITH the VSSBlocks (HIP scan) vs the CPU oracle (sequential scan): loss, eval output, sampled grads."""
     from oracle import specs

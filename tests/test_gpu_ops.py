@@ -828,14 +828,19 @@ def test_conv1x1_weight_gradient_off_the_library(ops, B, C1, C2, H, W, dt, slice
         assert float((gm.double() - ref).norm() / ref.norm()) <= err_own + 1e-9
 
 
-def test_fused_optim_step_equals_clip_adamw_ema():
+@pytest.mark.parametrize('shadows', [False, True])
+def test_fused_optim_step_equals_clip_adamw_ema(shadows):
     """engine.FusedOptimStep (csrc/optim.hip: clip_grad_norm_ + AdamW + EMA in four launches) against torch.nn.utils.clip_grad_norm_,
     torch.optim.AdamW and engine.ModelEMA on a twin model, over six steps: three parameter groups with their own lr / weight decay
     (engine.build_optimizer's layout), a channels-last convolution weight, BatchNorm statistics (EMA-only entries), a parameter that gets
     no gradient on some steps (its Adam step count must lag, like torch's), gradients far above and below the clipping norm, a changing
-    learning rate (warm-up).  Parameters, moments, step counts, EMA weights and the clipped gradients agree at fp32 rounding."""
+    learning rate (warm-up).  Parameters, moments, step counts, EMA weights and the clipped gradients agree at fp32 rounding.
+    shadows=True: the kernel also keeps a bf16 copy of every parameter (`p._tamtr_bf16`, ops.bf16_of): after every step each copy is the
+    master rounded to bf16, bit for bit; a copy whose master was changed behind the stepper's back is not handed out (tensor version) and is
+    re-derived by the next step(); model.load_state_dict refreshes them."""
     import copy
     import torch.nn as nn
+    import tamtr_amd.ops as ops
     from tamtr_amd.engine import FusedOptimStep, ModelEMA, build_optimizer
 
     class Net(nn.Module):
@@ -857,8 +862,16 @@ def test_fused_optim_step_equals_clip_adamw_ema():
     b = copy.deepcopy(a)
     oa, ob = build_optimizer(a, 'AdamW', lr=1e-2, decay=1e-2), build_optimizer(b, 'AdamW', lr=1e-2, decay=1e-2)
     ea, eb = ModelEMA(a, tau=3), ModelEMA(b, tau=3)
-    st = FusedOptimStep.create(b, ob, eb, max_norm=0.1)
+    st = FusedOptimStep.create(b, ob, eb, max_norm=0.1, shadows=shadows)
     assert st is not None
+    if shadows:
+        assert len(st.shadows) == len(list(b.parameters()))
+        for p_ in b.parameters():   # there before the first forward, in the master's layout
+            sh = ops.bf16_shadow(p_)
+            assert sh is not None and sh.dtype == torch.bfloat16 and sh.stride() == p_.stride() and torch.equal(sh, p_.detach().bfloat16())
+            assert ops.bf16_of(p_) is sh
+    else:
+        assert all(ops.bf16_shadow(p_) is None for p_ in b.parameters())
     g = torch.Generator(device='cuda').manual_seed(1)
     for step in range(6):
         x = torch.randn(4, 8, 6, 6, device='cuda', generator=g).contiguous(memory_format=torch.channels_last) * (10.0 if step % 2 else 1e-3)
@@ -887,6 +900,16 @@ def test_fused_optim_step_equals_clip_adamw_ema():
             if va.dtype.is_floating_point:
                 assert_close(vb, va, 1e-5, 2e-6, f'step {step} ema {k}')
         assert ea.updates == eb.updates == step + 1
+        if shadows:
+            for n, p_ in b.named_parameters():
+                sh = ops.bf16_shadow(p_)
+                assert sh is not None and torch.equal(sh, p_.detach().bfloat16()), f'step {step}: bf16 copy of {n}'
+            if step == 2:   # a master changed by something else: its copy is withheld until the next step() has re-derived it
+                with torch.no_grad():
+                    b.never.weight.mul_(2.0); a.never.weight.mul_(2.0)          # (never gets a gradient: only the stale-copy path can fix it)
+                    b.fc.bias.add_(0.25); a.fc.bias.add_(0.25)                  # (gets one: the kernel rewrites it)
+                assert ops.bf16_shadow(b.never.weight) is None and ops.bf16_shadow(b.fc.bias) is None
+                assert torch.equal(ops.bf16_of(b.never.weight), b.never.weight.detach().bfloat16())
     assert float(ob.state[b.sometimes.weight]['step']) == 4.0 and float(ob.state[b.never.weight]['step']) == 0.0 and b.never.weight.grad is None
     # the optimizer's state_dict round-trips (the step counts are ordinary tensors to it) and the stepper notices replaced state
     sd = copy.deepcopy(ob.state_dict())
@@ -894,6 +917,65 @@ def test_fused_optim_step_equals_clip_adamw_ema():
     b(x, True).backward()
     st.step()
     assert float(ob.state[b.fc.weight]['step']) == 7.0
+    if shadows:
+        addr = {n: ops.bf16_shadow(p_).data_ptr() for n, p_ in b.named_parameters()}
+        assert {id(p_): s_.data_ptr() for p_, s_ in st.shadows} == {id(p_): ops.bf16_shadow(p_).data_ptr() for p_ in b.parameters()}
+        sd_m = {k: v.clone() * 0.5 if v.dtype.is_floating_point else v.clone() for k, v in b.state_dict().items()}
+        b.load_state_dict(sd_m)
+        for n, p_ in b.named_parameters():
+            sh = ops.bf16_shadow(p_)
+            assert sh is not None and sh.data_ptr() == addr[n] and torch.equal(sh, p_.detach().bfloat16()), n
+        st.drop_shadows()
+        assert all(ops.bf16_shadow(p_) is None for p_ in b.parameters())
+
+
+@pytest.mark.parametrize('M,K,N,xdt,bias', [(4672, 512, 512, torch.float32, True), (4672, 512, 1024, torch.bfloat16, True), (1600, 1024, 512, torch.float32, True),
+                                           (292, 512, 96, torch.float32, True), (640, 64, 8, torch.bfloat16, False)])
+def test_linear_master_vs_autocast_linear(ops, M, K, N, xdt, bias):
+    """ops.linear on the decoder side's nn.Linear layers (transformer.py:539-558,869-889) against the module under bf16 autocast: the same
+    forward (same library GEMM on the same bf16 operands), the same input gradient, and weight / bias gradients that are the fp32 sums
+    autocast's path rounds to bf16 - compared with the exact sums of the same bf16 operands, they must be at least as close."""
+    import torch.nn as nn
+    torch.manual_seed(M + N)
+    lin = nn.Linear(K, N, bias=bias).cuda()
+    x0 = (rnd((M, K), 1)).to(xdt).cuda()
+    cot = rnd((M, N), 2).bfloat16().cuda()
+    res = []
+    for own in (False, True):
+        lin.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            assert ops.linear_master_ok(x, lin)
+            y = ops.linear(x, lin) if own else lin(x)
+        assert y.dtype == torch.bfloat16
+        y.backward(cot)
+        res.append((y.detach(), x.grad, lin.weight.grad.clone(), None if not bias else lin.bias.grad.clone()))
+    (y0, gx0, gw0, gb0), (y1, gx1, gw1, gb1) = res
+    assert torch.equal(y1, y0) and gx1.dtype == xdt
+    assert_close(gx1.float(), gx0.float(), 1e-2, 1e-2 * float(gx0.float().abs().max()), 'dX')
+    x16, w16 = x0.bfloat16().double(), lin.weight.detach().bfloat16().double()
+    gw_ref, gb_ref = cot.double().t() @ x16, cot.double().sum(0)
+    assert gw1.dtype == torch.float32
+    e_own, e_auto = float((gw1.double() - gw_ref).norm() / gw_ref.norm()), float((gw0.double() - gw_ref).norm() / gw_ref.norm())
+    assert e_own <= e_auto + 1e-7 and e_own <= 2e-3, (e_own, e_auto)
+    if bias:
+        e_own, e_auto = float((gb1.double() - gb_ref).norm() / gb_ref.norm()), float((gb0.double() - gb_ref).norm() / gb_ref.norm())
+        assert e_own <= e_auto + 1e-7 and e_own <= 1e-5, (e_own, e_auto)
+    # a second backward gives the same bits (no atomics, fixed order)
+    lin.zero_grad(set_to_none=True)
+    x = x0.clone().requires_grad_()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        ops.linear(x, lin).backward(cot)
+    assert torch.equal(lin.weight.grad, gw1) and (not bias or torch.equal(lin.bias.grad, gb1))
+    # packed projection rows (the self-attention's in_proj): row blocks of one parameter
+    wp, bp = nn.Parameter(rnd((3 * N, K), 3).cuda() * K ** -0.5), nn.Parameter(rnd((3 * N,), 4).cuda() * 0.1)
+    x = x0.clone().requires_grad_()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        ya = ops.linear_rows(x, wp, bp, 0, 2 * N)
+        yr = torch.nn.functional.linear(x, wp[:2 * N], bp[:2 * N])
+    assert torch.equal(ya, yr)
+    ya.float().pow(2).sum().backward()
+    assert wp.grad.shape == wp.shape and float(wp.grad[2 * N:].abs().max()) == 0 and float(wp.grad[:2 * N].abs().max()) > 0
 
 
 @pytest.mark.parametrize('B,D,H,W,R', [(2, 256, 24, 40, 8), (1, 512, 16, 24, 16), (1, 1024, 8, 16, 32), (1, 256, 36, 28, 8)])
