@@ -503,6 +503,13 @@ int tamtr_bncl_act_seg_bwd(const void* gy, long long seg_rows, long long seg_pit
                            const float* mean_rstd, void* gx, float* ggamma, float* gbeta, float* partials, long long N, int C, int act, int dtype,
                            void* stream);
 
+/*      The decoder's iterative box refinement (ultralytics/nn/modules/transformer.py:881-887, nn/modules/utils.py:46-52):
+ *          out = sigmoid(delta + inverse_sigmoid(ref)),  inverse_sigmoid(x) = log(max(clamp(x, 0, 1), 1e-5) / max(1 - clamp(x, 0, 1), 1e-5))
+ *      delta, ref, out f32 [n] (any shape, contiguous).  Backward: gdelta = gout out (1 - out); gref (NULL: not wanted - the reference detaches
+ *      `ref` between layers) = gdelta * d(inverse_sigmoid)/d(ref) with torch's clamp gradients. */
+int tamtr_box_refine_fwd(const float* delta, const float* ref, float* out, long long n, void* stream);
+int tamtr_box_refine_bwd(const float* gout, const float* out, const float* ref, float* gdelta, float* gref, long long n, void* stream);
+
 /*      Node census of the graph that `stream` is capturing into (hipStreamGetCaptureInfo_v2 + hipGraphGetNodes): counts[t] = nodes of
  *      hipGraphNodeType t, t < n_types <= 16 (0 kernel, 1 memcpy, 2 memset, ...).  Host-side helper of the HIP-graph replay
  *      (tam-tr_amd/graphs.py: memset nodes do not survive AQL packet capture); TAMTR_EINVAL when the stream is not capturing. */

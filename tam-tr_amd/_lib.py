@@ -10,7 +10,7 @@ from ctypes import c_float, c_int, c_longlong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TAMTR_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libtamtr_hip.so')  # env override: kernel A/B experiments
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 F32, BF16 = 0, 1
 _ERR = {-1: 'TAMTR_EINVAL (bad argument)', -2: 'TAMTR_EUNSUP (shape/dtype outside what the kernels are built for)',
@@ -61,6 +61,8 @@ _SIGS = {
     'tamtr_fold_add': [_P, _P, _P, _P, _I, _LL, _I, _P],
     'tamtr_slab_sum_rows': [_P, _P, _I, _LL, _I, _P],
     'tamtr_graph_capture_census': [_P, _P, _I],
+    'tamtr_box_refine_fwd': [_P, _P, _P, _LL, _P],
+    'tamtr_box_refine_bwd': [_P, _P, _P, _P, _P, _LL, _P],
     'tamtr_bncl_act_seg_fwd': [_P, _P, _P, _P, _P, _P, _LL, _LL, _P, _P, _LL, _I, _F, _F, _I, _I, _P],
     'tamtr_bncl_act_seg_bwd': [_P, _LL, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _P],
     'tamtr_detr_blocks': [_I],

@@ -217,6 +217,31 @@ __global__ __launch_bounds__(DL_THREADS) void detr_match_cost_kernel(const float
   C[e] = isfinite(c) ? c : 0.f;
 }
 
+// ---- iterative box refinement of the decoder (nn/modules/transformer.py:881-887: `refined = sigmoid(bbox_head(x) + inverse_sigmoid(ref))`,
+// nn/modules/utils.py:46-52 inverse_sigmoid with eps 1e-5): as torch ops a clamp pair, two clamps, a division, a log, an add and a sigmoid
+// on [B, Q, 4] - eight launches forward and as many backward, five times per step.  One kernel each way, the same formulas in fp32.
+constexpr float REF_EPS = 1e-5f;
+__global__ void box_refine_fwd_kernel(const float* __restrict__ d, const float* __restrict__ r, float* __restrict__ y, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = fminf(fmaxf(r[i], 0.f), 1.f);
+  const float z = d[i] + logf(fmaxf(x, REF_EPS) / fmaxf(1.f - x, REF_EPS));
+  y[i] = 1.f / (1.f + expf(-z));
+}
+// gd = gy y (1 - y);  gr = gd * d(inverse_sigmoid)/dr, with torch's clamp gradients (passed where the bound holds, bounds included)
+__global__ void box_refine_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ r, float* __restrict__ gd,
+                                      float* __restrict__ gr, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float yy = y[i], g = gy[i] * yy * (1.f - yy);
+  gd[i] = g;
+  if (gr) {
+    const float rr = r[i], x = fminf(fmaxf(rr, 0.f), 1.f), om = 1.f - x;
+    const float di = (x >= REF_EPS ? 1.f / x : 0.f) + (om >= REF_EPS ? 1.f / om : 0.f);
+    gr[i] = (rr >= 0.f && rr <= 1.f) ? g * di : 0.f;
+  }
+}
+
 }  // namespace
 
 extern "C" int tamtr_detr_blocks(int rows_per_layer) { return rows_per_layer > 0 ? (rows_per_layer + DL_THREADS - 1) / DL_THREADS : 0; }
@@ -261,5 +286,20 @@ extern "C" int tamtr_detr_match_cost(const float* ps, const float* pb, const flo
   if (blocks > 0x7fffffffLL) return TAMTR_EUNSUP;
   hipLaunchKernelGGL(detr_match_cost_kernel, dim3((unsigned)blocks), dim3(DL_THREADS), 0, (hipStream_t)stream, ps, pb, gt_bboxes, gt_cls, rows, nc, G, g_class,
                      g_bbox, g_giou, alpha, gamma, C);
+  return tamtr_launch_status();
+}
+
+/* see include/tamtr_hip.h */
+extern "C" int tamtr_box_refine_fwd(const float* delta, const float* ref, float* out, long long n, void* stream) {
+  if (!delta || !ref || !out || n <= 0) return TAMTR_EINVAL;
+  if ((n + 255) / 256 > 0x7fffffffLL) return TAMTR_EUNSUP;
+  hipLaunchKernelGGL(box_refine_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, delta, ref, out, n);
+  return tamtr_launch_status();
+}
+
+extern "C" int tamtr_box_refine_bwd(const float* gout, const float* out, const float* ref, float* gdelta, float* gref, long long n, void* stream) {
+  if (!gout || !out || !ref || !gdelta || n <= 0) return TAMTR_EINVAL;
+  if ((n + 255) / 256 > 0x7fffffffLL) return TAMTR_EUNSUP;
+  hipLaunchKernelGGL(box_refine_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gout, out, ref, gdelta, gref, n);
   return tamtr_launch_status();
 }

@@ -253,10 +253,10 @@ class TextDeformableTransformerDecoder(nn.Module):
             f_i = feats[i] if isinstance(feats, (list, tuple)) else feats   # per-layer handle on the token memory (ops.fanout)
             output = layer(output, refer_bbox, f_i, shapes, padding_mask, attn_mask, pos_mlp(refer_bbox))
             bbox = bbox_head[i](output)
-            refined = torch.sigmoid(bbox + inverse_sigmoid(refer_bbox))
+            refined = ops.box_refine(bbox, refer_bbox)       # sigmoid(bbox + inverse_sigmoid(refer_bbox)), one kernel
             if self.training:
                 dec_cls.append(score_head[i](output, text))
-                dec_bboxes.append(refined if i == 0 else torch.sigmoid(bbox + inverse_sigmoid(last_refined)))
+                dec_bboxes.append(refined if i == 0 else ops.box_refine(bbox, last_refined))
             elif i == self.eval_idx:
                 dec_cls.append(score_head[i](output, text))
                 dec_bboxes.append(refined)

@@ -515,6 +515,38 @@ def dw_splitk(g2, x2):
     return slab_sum(torch.bmm(a, b))
 
 
+class _BoxRefine(torch.autograd.Function):
+    """sigmoid(delta + inverse_sigmoid(ref)) - the decoder's box refinement (transformer.py:881-887) - as one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, delta, ref):
+        require_gpu(delta, ref)
+        d, r = _c(delta.float()), _c(ref.float())
+        out = torch.empty_like(d)
+        call('tamtr_box_refine_fwd', ptr(d), ptr(r), ptr(out), d.numel(), stream_ptr())
+        ctx.save_for_backward(out, r)
+        ctx.cfg = (delta.dtype, ref.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, r = ctx.saved_tensors
+        d_dt, r_dt = ctx.cfg
+        g = _c(g.float())
+        gd = torch.empty_like(out)
+        gr = torch.empty_like(out) if ctx.needs_input_grad[1] else None
+        call('tamtr_box_refine_bwd', ptr(g), ptr(out), ptr(r), ptr(gd), ptr(gr), out.numel(), stream_ptr())
+        return gd.to(d_dt), None if gr is None else gr.to(r_dt)
+
+
+def box_refine(delta, ref):
+    """sigmoid(delta + inverse_sigmoid(ref)); delta, ref of the same shape."""
+    if delta.is_cuda and delta.shape == ref.shape and delta.dtype in (torch.float32, torch.bfloat16) and _os.environ.get('TAMTR_BOX_REFINE') != 'torch':
+        return _BoxRefine.apply(delta, ref)
+    x = ref.clamp(min=0, max=1)
+    return torch.sigmoid(delta + torch.log(x.clamp(min=1e-5) / (1 - x).clamp(min=1e-5)))
+
+
 def bf16_shadow(p):
     """The bf16 copy of an fp32 parameter that the optimizer kernel keeps next to it (engine.FusedOptimStep(shadows=True)), if it is there and
     still describes the parameter's current value (same tensor version as when it was last derived); else None."""

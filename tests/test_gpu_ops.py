@@ -929,6 +929,39 @@ def test_fused_optim_step_equals_clip_adamw_ema(shadows):
         assert all(ops.bf16_shadow(p_) is None for p_ in b.parameters())
 
 
+@pytest.mark.parametrize('ddt', [torch.float32, torch.bfloat16])
+def test_box_refine_vs_torch_formula(ops, ddt):
+    """ops.box_refine = sigmoid(delta + inverse_sigmoid(ref)) (nn/modules/transformer.py:881-887, nn/modules/utils.py:46-52) against the
+    torch expression, values and both gradients, including references on and beyond the clamps (0, 1, below eps, above 1 - eps, outside
+    [0, 1]) where torch's clamp gradients decide."""
+    g = torch.Generator().manual_seed(5)
+    ref = torch.rand(16, 292, 4, generator=g)
+    edge = torch.tensor([0.0, 1.0, 5e-6, 1 - 5e-6, 1e-5, 1 - 1e-5, -0.2, 1.3, 0.5, 2e-5])
+    ref.view(-1)[:edge.numel()] = edge
+    delta = (torch.randn(16, 292, 4, generator=g) * 2).to(ddt)
+    cot = torch.randn(16, 292, 4, generator=g)
+
+    def formula(d, r):
+        x = r.clamp(min=0, max=1)
+        return torch.sigmoid(d + torch.log(x.clamp(min=1e-5) / (1 - x).clamp(min=1e-5)))
+    dr, rr = delta.double().requires_grad_(), ref.double().requires_grad_()
+    want = formula(dr, rr)
+    (want * cot.double()).sum().backward()
+    dd, rd = delta.cuda().requires_grad_(), ref.cuda().requires_grad_()
+    got = ops.box_refine(dd, rd)
+    assert got.dtype == torch.float32 and got.shape == ref.shape
+    (got * cot.cuda()).sum().backward()
+    assert_close(got, want, 1e-5, 1e-6, 'refined boxes')
+    assert dd.grad.dtype == ddt
+    tol = 1e-5 if ddt == torch.float32 else 1e-2
+    assert_close(dd.grad.float(), dr.grad, tol, tol * float(dr.grad.abs().max()) * 1e-1, 'd/d(delta)')
+    assert_close(rd.grad, rr.grad, 1e-4, 1e-5 * float(rr.grad.abs().max()), 'd/d(ref)')
+    # a detached reference (what the decoder passes between layers) gets no gradient buffer at all
+    d2 = delta.cuda().requires_grad_()
+    ops.box_refine(d2, ref.cuda()).sum().backward()
+    assert d2.grad is not None
+
+
 @pytest.mark.parametrize('M,K,N,xdt,bias', [(4672, 512, 512, torch.float32, True), (4672, 512, 1024, torch.bfloat16, True), (1600, 1024, 512, torch.float32, True),
                                            (292, 512, 96, torch.float32, True), (640, 64, 8, torch.bfloat16, False)])
 def test_linear_master_vs_autocast_linear(ops, M, K, N, xdt, bias):
