@@ -105,13 +105,13 @@ def gemm_traffic(args):
     """HBM bytes per launch of the roofline kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
     WRITE_SIZE in separate runs of tools/gemm_only.py, corrected as the MI355X guide prescribes).  Counters cannot be collected
     from inside this process; null when the committed measurement is not for this shape."""
-    path = os.path.join(ROOT, 'profiles', 'r03_gemm_pmc.json')
-    try:
-        d = json.load(open(path))
-        if d.get('M') == args.batch * (args.imgsz // 4) ** 2 * 21 // 16 and args.dtype == 'bf16':
-            return d['hbm_bytes_per_launch']
-    except Exception:
-        pass
+    for name in ('r04_gemm_pmc.json', 'r03_gemm_pmc.json'):   # (the kernel has not changed since round 3; the newest measurement wins)
+        try:
+            d = json.load(open(os.path.join(ROOT, 'profiles', name)))
+            if d.get('M') == args.batch * (args.imgsz // 4) ** 2 * 21 // 16 and args.dtype == 'bf16':
+                return d['hbm_bytes_per_launch']
+        except Exception:
+            pass
     return None
 
 

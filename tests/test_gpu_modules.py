@@ -523,17 +523,19 @@ def test_weight_shadows_train_like_autocast_casts(pkg):
         assert calls['alias'] > 0 and calls['cast'] == 0, calls
         moved = max(float((p.detach() - w0[n]).abs().max()) for n, p in model.named_parameters() if p.grad is not None)
         assert moved > 5e-3, moved                       # the masters are far from where the copies started
-        sd = {k: v.clone() for k, v in model.state_dict().items()}
-        fa = model.token_memory(batch['img'], batch['txt_feats'])[0].detach().float()
+        def memory():   # (with autograd on: the grouped casts / aliases are the training path)
+            return model.token_memory(batch['img'], batch['txt_feats'])[0].detach().float()
+        fa, fa2 = memory(), memory()
         assert calls['cast'] == 0
         st.drop_shadows()
-        model.load_state_dict(sd)                        # (BatchNorm statistics back to where the first pass found them)
-        fb = model.token_memory(batch['img'], batch['txt_feats'])[0].detach().float()
+        fb, fb2 = memory(), memory()
         assert calls['cast'] > 0
     finally:
         pkg.model._CastGroup.forward, pkg.model._ShadowGroup.forward = staticmethod(cg), staticmethod(sg)
     assert torch.isfinite(fa).all() and float(fa.abs().max()) > 0
-    assert_close(fa, fb, 2e-3, 2e-3 * float(fb.abs().max()), 'token memory: shadow copies vs per-use casts')
+    dist = lambda u, v: float((u - v).norm() / v.norm())   # noqa: E731
+    noise = max(dist(fa, fa2), dist(fb, fb2))              # what two runs of the SAME path differ by (library kernels with atomics)
+    assert dist(fa, fb) <= 2 * noise + 1e-6, (dist(fa, fb), dist(fa, fa2), dist(fb, fb2))
 
 
 def test_full_model_real_vss_vs_oracle(pkg):
