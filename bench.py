@@ -229,22 +229,34 @@ def other_kernels(args, dev):
         out.append({'kernel': f'gate_cl_fwd_kernel<bf16> (BTA-PAN text gate, {C} ch x {H}^2 x {B}: TIAGELAN site 32)', 'bound': 'hbm', 'achieved': byt / ms / 1e6,
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': byt / ms / 1e6 / HBM_PEAK_GBS, 'avg_ms': ms, 'algorithmic_bytes': byt})
         del wide, e, v
+    # the scan in the form the step runs it (tamtr_selective_scan_dtproj_* on the cross-scan pair layout; planes in bf16 in bf16 mode)
+    import tamtr_amd._lib as L_
+    from tamtr_amd._lib import call, ptr, stream_ptr
     D, L, R, K, N = 256, H * H, 8, 4, 16
     g = torch.Generator(device=dev).manual_seed(0)
     rn = lambda *sh: torch.randn(*sh, device=dev, generator=g)   # noqa: E731
-    ins = [rn(B, 2, D, L), rn(B, K, R, L), rn(K * D, R) * R ** -0.5, -torch.exp(rn(K * D, N) * 0.3), rn(B, K, N, L), rn(B, K, N, L), rn(K * D), rn(K * D) - 3]
-    ins = [t.requires_grad_() for t in ins]
-    y = ops.selective_scan_cross(*ins)
-    gy = torch.randn_like(y)
-    f_ms = t_ms(lambda: ops.selective_scan_cross(*ins), n=5, warm=2)
-
-    def fb():
-        torch.autograd.grad(ops.selective_scan_cross(*ins), ins, gy)
-    b_ms = t_ms(fb, n=5, warm=2) - f_ms
+    pc = 1 if args.dtype == 'bf16' else 0
+    pdt, e = (torch.bfloat16, 2) if pc else (torch.float32, 4)
+    u2, g2 = rn(B, 2, D, L).to(pdt), rn(B, 2, D, L).to(pdt)
+    dtr, Wdt, A, Bs, Cs, Dv, db = rn(B, K, R, L), rn(K * D, R) * R ** -0.5, -torch.exp(rn(K * D, N) * 0.3), rn(B, K, N, L), rn(B, K, N, L), rn(K * D), rn(K * D) - 3
+    y, gu = torch.empty(B, K, D, L, device=dev, dtype=pdt), torch.empty(B, K * D, L, device=dev, dtype=pdt)
+    chunk = L_.lib().tamtr_selective_scan_chunk()
+    hst = torch.empty(B, K * D, (L + chunk - 1) // chunk, N, device=dev)
+    gdelta = torch.empty(B, K * D, L, device=dev, dtype=torch.bfloat16 if pc else torch.float32)
+    gdtr, gB, gC = torch.empty_like(dtr), torch.empty_like(Bs), torch.empty_like(Cs)
+    grow = torch.empty(B, K * D, L_.lib().tamtr_selective_scan_row_sums(), device=dev)
+    ws = torch.empty(2 * L_.lib().tamtr_selective_scan_bwd_slabs(D) * Bs.numel(), device=dev)
+    sp = stream_ptr()
+    f_ms = t_ms(lambda: call('tamtr_selective_scan_dtproj_fwd', ptr(u2), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bs), ptr(Cs), ptr(Dv), ptr(db), ptr(y), ptr(hst), B, K, D, N,
+                             R, L, 1, pc, sp), n=5, warm=2)
+    b_ms = t_ms(lambda: call('tamtr_selective_scan_dtproj_bwd', ptr(g2), ptr(u2), ptr(dtr), ptr(Wdt), ptr(A), ptr(Bs), ptr(Cs), ptr(Dv), ptr(db), ptr(hst), ptr(gu),
+                             ptr(gdelta), ptr(gdtr), ptr(grow), ptr(gB), ptr(gC), ptr(ws), B, K, D, N, R, L, 3, 3 if pc else 0, sp), n=5, warm=2)
     state_steps = B * K * D * L * N
-    f_bytes = (2 + 4) * B * D * L * 4 + 3 * B * K * (R + 2 * N) * L * 4 // 3
-    b_bytes = (2 + 4 + 4) * B * D * L * 4 + 4 * B * D * L * 2
-    for name, ms, byt in (('selscan_fwd_kernel (MEH level 0: d_inner 256, L %d, 4 directions, 16 states)' % L, f_ms, f_bytes),
+    small = B * K * (R + 2 * N) * L * 4                       # dtr + B + C (or their gradients), f32
+    pl = B * D * L                                            # elements of one [B, D, L] plane
+    f_bytes = (2 + 4) * pl * e + small                        # u2 read, y written
+    b_bytes = (2 + 2 + 4) * pl * e + 2 * 4 * pl * (2 if pc else 4) + 2 * small   # d(y), u2 read, d(u) written; d(delta) workspace written + read
+    for name, ms, byt in (('selscan_fwd_kernel (MEH level 0: d_inner 256, L %d, 4 directions, 16 states; planes %s)' % (L, 'bf16' if pc else 'f32'), f_ms, f_bytes),
                           ('selscan_bwd (kernel + dtproj_gdtr + slab_sum, same shape)', b_ms, b_bytes)):
         out.append({'kernel': name, 'bound': 'hbm', 'limiter': 'VALU issue (fp32 recurrence: exp + 3 FMA per step and state, DPP scans)', 'achieved': byt / ms / 1e6,
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': byt / ms / 1e6 / HBM_PEAK_GBS, 'avg_ms': ms, 'algorithmic_bytes': byt,
