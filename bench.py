@@ -93,6 +93,24 @@ class KernelTimer:
         return {'launches': len(ms), 'avg_ms': avg, 'min_ms': ms[0], 'tflops': top / (avg * 1e-3) / 1e12}
 
 
+def event_bracket_overhead(dev):
+    """What a pair of events on the launch stream adds around ONE kernel on this runtime: the same bracket around a kernel that itself
+    runs ~2 us (a 1 024-element ordered sum), median of 50, between other work as in the step.  The roofline's `avg_ms` is the raw bracket
+    (conservative); rocprofv3's kernel durations (profiles/) are shorter by about this much."""
+    import tamtr_amd.ops as ops
+    t = torch.ones(4, 1024, device=dev)
+    big = torch.empty(1 << 24, device=dev)
+    ms = []
+    for _ in range(50):
+        big.zero_()                                  # something in front, so the start marker waits like in the step
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); ops.slab_sum(t); e1.record()
+        ms.append((e0, e1))
+    torch.cuda.synchronize()
+    v = sorted(a.elapsed_time(b) for a, b in ms)
+    return v[len(v) // 2]
+
+
 def _hbm_view(args, ks):
     if args.dtype != 'bf16':
         return None
@@ -451,6 +469,8 @@ def main():
                                            % (args.batch * (args.imgsz // 4) ** 2 * 21 // 16),
                 'achieved': ks['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': ks['tflops'] / peak, 'traffic': gemm_traffic(args),
                 'avg_ms': ks['avg_ms'], 'launches': ks['launches'],
+                # (an event pair around a ~2 us kernel, measured the same way right here: what the bracket itself adds on this runtime)
+                'event_bracket_ms_around_a_2us_kernel': event_bracket_overhead(dev),
                 # the same launches priced against the OTHER roof (the shape sits at the chip's balance point: 256 flop/B against 312):
                 # algorithmic bytes (X read once + Y written once) per second over the 8 TB/s HBM peak
                 'hbm_view': _hbm_view(args, ks)},
