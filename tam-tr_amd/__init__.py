@@ -13,5 +13,10 @@ if os.environ.get('TAMTR_CHANNELS_LAST', '1') != '0':
     os.environ.setdefault('PYTORCH_MIOPEN_SUGGEST_NHWC', '1')
 
 # (HIP graphs, graphs.py: the runtime's AQL packet capture stays at its default - on - since round 4; the recorded part holds no memset node)
+# ... except in the deterministic mode: MIOpen's deterministic NCHW solvers zero their outputs with memsets (59 memset nodes in the recorded
+# backward), which do not replay in order under packet capture - that mode keeps the node-by-node launches (~20 ms of host time per graph launch
+# on a 200 ms step).  Read at HIP initialisation: must be set before the first HIP call of the process.
+if os.environ.get('TAMTR_DETERMINISTIC') == '1':
+    os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
 
 from ._lib import LIB_PATH, TamtrHipError  # noqa: F401

@@ -481,7 +481,11 @@ def contrastive_logits(x, w, logit_scale, bias):
 
 
 # ------------------------------------------------------------------------------------------------ a-5 value projection
-def _split_count(M, min_rows=2048, max_split=64):
+_SPLIT_MAX = int(_os.environ.get('TAMTR_SPLITK_MAX', '64'))   # A/B knob: slices of the row-sliced weight-gradient products
+
+
+def _split_count(M, min_rows=2048, max_split=None):
+    max_split = _SPLIT_MAX if max_split is None else max_split
     S = 1
     while S < max_split and M % (2 * S) == 0 and M // (2 * S) >= min_rows:
         S *= 2
