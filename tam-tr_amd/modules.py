@@ -162,18 +162,21 @@ class MSDeformAttn(nn.Module):
             v = v.view(bs, len_v, self.n_heads, -1)
         else:
             v = self.project_value(value)
-        q32 = query.float()
-        off = F.linear(q32, self.sampling_offsets.weight.float(), self.sampling_offsets.bias.float())
-        off = off.view(bs, len_q, self.n_heads, self.n_levels, self.n_points, 2)
-        aw = F.linear(q32, self.attention_weights.weight.float(), self.attention_weights.bias.float())
-        aw = F.softmax(aw.view(bs, len_q, self.n_heads, -1), -1).view(bs, len_q, self.n_heads, self.n_levels, self.n_points)
+        q32 = ops.shared_bf16(query.float(), self.sampling_offsets, self.attention_weights)   # (bf16 mode: one cast for both projections)
+        off = ops.linear(q32, self.sampling_offsets) if q32.dtype == torch.bfloat16 else \
+            F.linear(q32, self.sampling_offsets.weight.float(), self.sampling_offsets.bias.float())
+        off = off.float().view(bs, len_q, self.n_heads, self.n_levels, self.n_points, 2)
+        aw = ops.linear(q32, self.attention_weights) if q32.dtype == torch.bfloat16 else \
+            F.linear(q32, self.attention_weights.weight.float(), self.attention_weights.bias.float())
+        aw = F.softmax(aw.float().view(bs, len_q, self.n_heads, -1), -1).view(bs, len_q, self.n_heads, self.n_levels, self.n_points)
         ref = refer_bbox.float()
         n = ref.shape[-1]
         if n == 2:
             norm = torch.as_tensor(value_shapes, dtype=torch.float32, device=query.device).flip(-1)
             loc = ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
         elif n == 4:
-            loc = ref[:, :, None, :, None, :2] + off / self.n_points * ref[:, :, None, :, None, 2:] * 0.5
+            # ref_xy + off / n_points * ref_wh * 0.5 as one fused multiply-add on the offsets (the small factor is formed first)
+            loc = torch.addcmul(ref[:, :, None, :, None, :2], off, ref[:, :, None, :, None, 2:] * (0.5 / self.n_points))
         else:
             raise ValueError(f'Last dim of reference_points must be 2 or 4, but got {n}.')
         out = ops.ms_deform_attn_core(v, value_shapes, loc, aw)
@@ -222,13 +225,13 @@ class DeformableTransformerDecoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, tgt):
-        return self.norm3(tgt + ops.linear(self.act(ops.linear(tgt, self.linear1)), self.linear2))
+        return ops.layer_norm_module(self.norm3, tgt + ops.linear(self.act(ops.linear(tgt, self.linear1)), self.linear2))
 
     def forward(self, embed, refer_bbox, feats, shapes, padding_mask=None, attn_mask=None, query_pos=None):
         qk = self.with_pos_embed(embed, query_pos)
-        embed = self.norm1(embed + self.self_attn(qk, embed, attn_mask))
+        embed = ops.layer_norm_module(self.norm1, embed + self.self_attn(qk, embed, attn_mask))
         t = self.cross_attn(self.with_pos_embed(embed, query_pos), refer_bbox.unsqueeze(2), feats, shapes, padding_mask)
-        embed = self.norm2(embed + t)
+        embed = ops.layer_norm_module(self.norm2, embed + t)
         return self.forward_ffn(embed)
 
 

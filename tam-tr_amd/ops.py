@@ -635,6 +635,14 @@ def linear(x, lin):
     return lin(x)
 
 
+def shared_bf16(x, *lins):
+    """x as the bf16 operand of SEVERAL ops.linear calls (one cast, and one cast of the summed input gradient, instead of one per consumer);
+    x itself where ops.linear would not take the _LinearMaster path."""
+    if x.dtype == torch.float32 and lins and all(linear_master_ok(x, lin) for lin in lins):
+        return x.to(torch.bfloat16)
+    return x
+
+
 def linear_rows(x, weight, bias, lo, hi):
     """F.linear(x, weight[lo:hi], bias[lo:hi]) - a row block of a packed projection (nn.MultiheadAttention's in_proj) - the same way."""
     w, b = weight[lo:hi], bias[lo:hi]
@@ -1645,6 +1653,16 @@ class _LayerNorm(torch.autograd.Function):
 
 def layer_norm(x, gamma, beta, eps=1e-5):
     return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+def layer_norm_module(norm, x):
+    """norm(x) for an nn.LayerNorm over the last axis: on the GPU the wave-per-token kernel (one launch forward; one + an ordered partial sum
+    backward, where torch launches three), in x's dtype - what torch's autocast gives for fp32 inputs; else the module."""
+    D = x.shape[-1]
+    if (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and len(norm.normalized_shape) == 1 and norm.elementwise_affine and norm.bias is not None
+            and D in (32, 64, 128, 256, 512, 1024) and _os.environ.get('TAMTR_DECODER_LN') != 'torch'):
+        return _LayerNorm.apply(x, norm.weight, norm.bias, norm.eps)
+    return norm(x)
 
 
 class _BNAct(torch.autograd.Function):
