@@ -721,12 +721,13 @@ def test_chunk_and_multi_input_cat_kernels(ops):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize('dt,n', [(torch.bfloat16, 4), (torch.float32, 3), (torch.bfloat16, 2)])
-def test_fanout_sums_consumer_gradients_in_one_pass(ops, dt, n):
+@pytest.mark.parametrize('dt,n,shape', [(torch.bfloat16, 4, (5, 37, 64)), (torch.float32, 3, (5, 37, 64)), (torch.bfloat16, 2, (5, 37, 64)),
+                                        (torch.bfloat16, 8, (3, 37, 12)), (torch.float32, 5, (1, 1, 4)), (torch.bfloat16, 4, (16, 2100, 256))])
+def test_fanout_sums_consumer_gradients_in_one_pass(ops, dt, n, shape):
     """ops.fanout: n handles on one tensor whose n gradients are added by tamtr_sum_n (the MEH token memory feeds enc_output and every
     decoder layer's value_proj) - same total gradient as letting autograd accumulate them."""
-    x = rnd((5, 37, 64), 1).to(dt).cuda()
-    ws = [rnd((5, 37, 64), 2 + i).to(dt).cuda() for i in range(n)]
+    x = rnd(shape, 1).to(dt).cuda()          # (odd and even numbers of 4-element groups, a one-group tensor, a token-memory-sized one)
+    ws = [rnd(shape, 2 + i).to(dt).cuda() for i in range(n)]
     a = x.clone().requires_grad_()
     hs = ops.fanout(a, n)
     assert len(hs) == n and all(torch.equal(h, a) for h in hs)
