@@ -259,6 +259,14 @@ int tamtr_cpam_fwd(const void* x, const void* p, void* out, float* s2, int32_t* 
 int tamtr_cpam_bwd(const void* gout, const void* x, const void* p, const float* s2, const int32_t* arg, void* dx_direct,
                    void* du_ws, void* dp, int B, int C, int H, int W, int dtype, void* stream);
 
+/*      The same on channels-last maps (what the trunk runs): x, p, out, gout, dx_direct, du_ws, dp (T) [B][H][W][C] / [B][H/2][W/2][C],
+ *      s2 f32 / arg i32 [B][H][W][8] (chunk innermost).  A lane owns a 2 x 2 pixel block x 16 bytes of channels, the chunk max / sum is a
+ *      butterfly over the chunk's lanes: C % 64 == 0 (bf16) / % 32 (f32), C / 8 a power of two times the vector width, 16-byte aligned
+ *      pointers.  No transposing copies around the op. */
+int tamtr_cpam_cl_fwd(const void* x, const void* p, void* out, float* s2, int32_t* arg, int B, int C, int H, int W, int dtype, void* stream);
+int tamtr_cpam_cl_bwd(const void* gout, const void* x, const void* p, const float* s2, const int32_t* arg, void* dx_direct, void* du_ws, void* dp, int B,
+                      int C, int H, int W, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * a-9  SS2D front end: depthwise 3x3 conv + bias + SiLU + cross-scan layout.  Replaces `x = self.act(self.conv2d(x))`
  *      (ultralytics/nn/extra_modules/VManba/vmamba.py:949-952, on the NCHW permutation of the in_proj output) together with

@@ -10,7 +10,7 @@ from ctypes import c_float, c_int, c_longlong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TAMTR_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libtamtr_hip.so')  # env override: kernel A/B experiments
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 F32, BF16 = 0, 1
 _ERR = {-1: 'TAMTR_EINVAL (bad argument)', -2: 'TAMTR_EUNSUP (shape/dtype outside what the kernels are built for)',
@@ -45,7 +45,9 @@ _SIGS = {
     'tamtr_lsap_assign': [_P, _P, _I, _I, _I, _P, _P, _P, _P],
     'tamtr_img_augment_u8': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'tamtr_cpam_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'tamtr_cpam_cl_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'tamtr_cpam_bwd': [_P] * 8 + [_I, _I, _I, _I, _I, _P],
+    'tamtr_cpam_cl_bwd': [_P] * 8 + [_I, _I, _I, _I, _I, _P],
     'tamtr_dwconv_silu_cross_fwd': [_P, _LL, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'tamtr_dwconv_tiles': [_I, _I],
     'tamtr_cross_merge_fwd': [_P, _P, _I, _I, _I, _I, _I, _P],

@@ -234,6 +234,209 @@ __global__ __launch_bounds__(CPAM_THREADS) void cpam_dp_kernel(const T* __restri
   Elt<T>::st(dp + bc * Hp * Wp + q, acc);
 }
 
+// ------------------------------------------------------------------------------------------------ channels-last forms
+// The trunk runs channels-last (model.py); the kernels above are NCHW and needed a transposing copy on the way in and out (16 launches,
+// 0.39 ms per step at the four sites) and walk a chunk's channels one dependent round trip at a time (65 - 75 us per site whatever its
+// size).  Here x / p / out are [B][H][W][C]: a lane owns a 2 x 2 pixel block x V consecutive channels (16 bytes: V = 8 bf16 | 4 f32), the
+// C / V lanes of a block sit side by side, a chunk (C / 8 channels) is LPC = C / (8 V) neighbouring lanes, and the chunk max / argmax /
+// sum is a butterfly over those lanes.  Thirteen 16-byte loads per lane (9 pooled taps + 4 pixels), all issued up front.
+// s2 / arg: f32 / i32 [B][H][W][8] (chunk innermost).
+template <typename T> struct VecT;
+template <> struct VecT<float> { static constexpr int V = 4; };
+template <> struct VecT<bf16_t> { static constexpr int V = 8; };
+
+template <typename T, int V>
+__device__ __forceinline__ void ldv(const T* p, float (&o)[V]) {
+  if constexpr (V == 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  } else {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+}
+template <typename T, int V>
+__device__ __forceinline__ void stv(T* p, const float (&v)[V]) {
+  if constexpr (V == 8) {
+    uint4 o;
+    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = o;
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// the block's geometry and its 13 vectors: pooled taps pt[3][3][V] (rows rA rB rC x columns cA cB cC) and pixels xv[4][V]
+// (pixel order: (2k, 2l), (2k, 2l + 1), (2k + 1, 2l), (2k + 1, 2l + 1) - the order of upsample4 / the NCHW kernels)
+template <typename T, int V>
+__device__ __forceinline__ void cl_upsample(const float (&pt)[3][3][V], const Taps& t, float (&u)[4][V]) {
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const float hla = t.wl0 * pt[0][0][j] + t.wl1 * pt[0][1][j], hra = 0.75f * pt[0][1][j] + 0.25f * pt[0][2][j];
+    const float hlb = t.wl0 * pt[1][0][j] + t.wl1 * pt[1][1][j], hrb = 0.75f * pt[1][1][j] + 0.25f * pt[1][2][j];
+    const float hlc = t.wl0 * pt[2][0][j] + t.wl1 * pt[2][1][j], hrc = 0.75f * pt[2][1][j] + 0.25f * pt[2][2][j];
+    u[0][j] = t.wt0 * hla + t.wt1 * hlb; u[1][j] = t.wt0 * hra + t.wt1 * hrb;
+    u[2][j] = 0.75f * hlb + 0.25f * hlc; u[3][j] = 0.75f * hrb + 0.25f * hrc;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(CPAM_THREADS) void cpam_cl_fwd_kernel(const T* __restrict__ x, const T* __restrict__ p, T* __restrict__ out,
+                                                                    float* __restrict__ s2_out, int32_t* __restrict__ arg_out, int B, int C,
+                                                                    int H, int W) {
+  constexpr int V = VecT<T>::V;
+  const int Hp = H / 2, Wp = W / 2, LPB = C / V, LPC = LPB / CHUNKS;   // lanes per block / per chunk
+  const int lb = threadIdx.x % LPB;                                    // this lane's channel vector inside the block
+  const long long blk = (long long)blockIdx.x * (CPAM_THREADS / LPB) + threadIdx.x / LPB;
+  const long long nblk = (long long)B * Hp * Wp;
+  const long long q = blk < nblk ? blk : nblk - 1;                      // (clamped: a lane past the end computes the last block again, stores nothing)
+  const int b = (int)(q / (Hp * Wp)), r = (int)(q - (long long)b * Hp * Wp), k = r / Wp, l = r - k * Wp;
+  const Taps t = make_taps(k, l, Hp, Wp);
+  const int ch0 = lb * V;
+  const T* pb = p + (size_t)b * Hp * Wp * C + ch0;
+  const T* xb = x + (((size_t)b * H + 2 * k) * W + 2 * l) * C + ch0;
+  const int rows[3] = {t.rA, t.rB, t.rC}, cols[3] = {t.cA, t.cB, t.cC};
+  float pt[3][3][V], xv[4][V];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ldv<T, V>(pb + ((size_t)rows[a] * Wp + cols[c]) * C, pt[a][c]);
+  ldv<T, V>(xb, xv[0]); ldv<T, V>(xb + C, xv[1]); ldv<T, V>(xb + (size_t)W * C, xv[2]); ldv<T, V>(xb + (size_t)W * C + C, xv[3]);
+  float u[4][V];
+  cl_upsample<T, V>(pt, t, u);
+  float m[4];
+  int am[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    m[i] = -INFINITY; am[i] = 0;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      u[i][j] = sigm(u[i][j]) * xv[i][j];                      // the channel-gated value c
+      if (u[i][j] > m[i]) { m[i] = u[i][j]; am[i] = (lb % LPC) * V + j; }
+    }
+    for (int o = 1; o < LPC; o <<= 1) {                        // chunk max over its LPC lanes; ties: the lower channel (the NCHW kernel's first maximum)
+      const float om = __shfl_xor(m[i], o, WAVE);
+      const int oa = __shfl_xor(am[i], o, WAVE);
+      if (om > m[i] || (om == m[i] && oa < am[i])) { m[i] = om; am[i] = oa; }
+    }
+  }
+  if (blk >= nblk) return;
+  float s2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s2[i] = sigm(m[i]);
+  T* ob = out + (((size_t)b * H + 2 * k) * W + 2 * l) * C + ch0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float o[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) o[j] = s2[i] * u[i][j];
+    stv<T, V>(ob + ((size_t)(i >> 1) * W + (i & 1)) * C, o);
+  }
+  if (lb % LPC == 0) {
+    const int g = lb / LPC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t sp = (((size_t)b * H + 2 * k + (i >> 1)) * W + 2 * l + (i & 1)) * CHUNKS + g;
+      s2_out[sp] = s2[i];
+      arg_out[sp] = am[i];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(CPAM_THREADS) void cpam_cl_bwd_kernel(const T* __restrict__ gout, const T* __restrict__ x, const T* __restrict__ p,
+                                                                    const float* __restrict__ s2_in, const int32_t* __restrict__ arg_in,
+                                                                    T* __restrict__ dxd, T* __restrict__ du, int B, int C, int H, int W) {
+  constexpr int V = VecT<T>::V;
+  const int Hp = H / 2, Wp = W / 2, LPB = C / V, LPC = LPB / CHUNKS;
+  const int lb = threadIdx.x % LPB;
+  const long long blk = (long long)blockIdx.x * (CPAM_THREADS / LPB) + threadIdx.x / LPB;
+  const long long nblk = (long long)B * Hp * Wp;
+  const long long q = blk < nblk ? blk : nblk - 1;
+  const int b = (int)(q / (Hp * Wp)), r = (int)(q - (long long)b * Hp * Wp), k = r / Wp, l = r - k * Wp;
+  const Taps t = make_taps(k, l, Hp, Wp);
+  const int ch0 = lb * V, g = lb / LPC;
+  const T* pb = p + (size_t)b * Hp * Wp * C + ch0;
+  const size_t pix = (((size_t)b * H + 2 * k) * W + 2 * l) * C + ch0;
+  const int rows[3] = {t.rA, t.rB, t.rC}, cols[3] = {t.cA, t.cB, t.cC};
+  float pt[3][3][V], xv[4][V], go[4][V], s2[4];
+  int am[4];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ldv<T, V>(pb + ((size_t)rows[a] * Wp + cols[c]) * C, pt[a][c]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const size_t o = ((size_t)(i >> 1) * W + (i & 1)) * C;
+    ldv<T, V>(x + pix + o, xv[i]);
+    ldv<T, V>(gout + pix + o, go[i]);
+    const size_t sp = (((size_t)b * H + 2 * k + (i >> 1)) * W + 2 * l + (i & 1)) * CHUNKS + g;
+    s2[i] = s2_in[sp];
+    am[i] = arg_in[sp];
+  }
+  float u[4][V];
+  cl_upsample<T, V>(pt, t, u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float S = 0.f;                                              // sum over the chunk of gout * c (what flows into the chunk max)
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      u[i][j] = sigm(u[i][j]);                                  // s1
+      S = fmaf(go[i][j], u[i][j] * xv[i][j], S);
+    }
+    for (int o = 1; o < LPC; o <<= 1) S += __shfl_xor(S, o, WAVE);
+    const float dm = s2[i] * (1.f - s2[i]) * S;
+    float dx[V], dd[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float s1 = u[i][j];
+      const float dc = go[i][j] * s2[i] + (am[i] == (lb % LPC) * V + j ? dm : 0.f);
+      dx[j] = dc * s1;
+      dd[j] = dc * xv[i][j] * s1 * (1.f - s1);
+    }
+    if (blk < nblk) {
+      const size_t o = pix + ((size_t)(i >> 1) * W + (i & 1)) * C;
+      stv<T, V>(dxd + o, dx);
+      stv<T, V>(du + o, dd);
+    }
+  }
+}
+
+// dp[b, k, l, :] = sum over the 4 x 4 pixel patch (2k-1..2k+2) x (2l-1..2l+2) of wy * wx * du[b, y, x, :]
+template <typename T>
+__global__ __launch_bounds__(CPAM_THREADS) void cpam_cl_dp_kernel(const T* __restrict__ du, T* __restrict__ dp, int B, int C, int H, int W) {
+  constexpr int V = VecT<T>::V;
+  const int Hp = H / 2, Wp = W / 2, LPB = C / V;
+  const long long id = (long long)blockIdx.x * CPAM_THREADS + threadIdx.x, total = (long long)B * Hp * Wp * LPB;
+  if (id >= total) return;
+  const int lb = (int)(id % LPB);
+  const long long q = id / LPB;
+  const int b = (int)(q / (Hp * Wp)), r = (int)(q - (long long)b * Hp * Wp), k = r / Wp, l = r - k * Wp;
+  const float wy[4] = {k >= 1 ? 0.25f : 0.f, k == 0 ? 1.f : 0.75f, k == Hp - 1 ? 1.f : 0.75f, k < Hp - 1 ? 0.25f : 0.f};
+  const float wx[4] = {l >= 1 ? 0.25f : 0.f, l == 0 ? 1.f : 0.75f, l == Wp - 1 ? 1.f : 0.75f, l < Wp - 1 ? 0.25f : 0.f};
+  const int xs[4] = {max(2 * l - 1, 0), 2 * l, 2 * l + 1, min(2 * l + 2, W - 1)};
+  const T* d = du + (size_t)b * H * W * C + lb * V;
+  float acc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int y = min(max(2 * k - 1 + i, 0), H - 1);            // clamped rows / columns carry weight 0
+    float v[4][V];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ldv<T, V>(d + ((size_t)y * W + xs[c]) * C, v[c]);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float row = wx[0] * v[0][j] + wx[1] * v[1][j] + wx[2] * v[2][j] + wx[3] * v[3][j];   // (the NCHW kernel's association)
+      acc[j] = fmaf(wy[i], row, acc[j]);
+    }
+  }
+  stv<T, V>(dp + (((size_t)b * Hp + k) * Wp + l) * C + lb * V, acc);
+}
+
 }  // namespace
 
 static int cpam_check(const void* a, const void* b, const void* c, int B, int C, int H, int W, int dtype) {
@@ -276,6 +479,56 @@ extern "C" int tamtr_cpam_bwd(const void* gout, const void* x, const void* p, co
     hipLaunchKernelGGL(cpam_bwd_kernel<bf16_t>, dim3(nb, CHUNKS, B), dim3(CPAM_THREADS), 0, s, (const bf16_t*)gout, (const bf16_t*)x,
                        (const bf16_t*)p, s2, arg, (bf16_t*)dx_direct, (bf16_t*)du_ws, C, H, W);
     hipLaunchKernelGGL(cpam_dp_kernel<bf16_t>, dim3(nb, B * C), dim3(CPAM_THREADS), 0, s, (const bf16_t*)du_ws, (bf16_t*)dp, H, W);
+  }
+  return tamtr_launch_status();
+}
+
+// channels-last forms: x, p, out, gout, dx_direct, du_ws, dp (T) [B][H][W][C] / [B][H/2][W/2][C]; s2 f32, arg i32 [B][H][W][8]
+static int cpam_cl_check(const void* a, const void* b, const void* c, int B, int C, int H, int W, int dtype) {
+  const int rc = cpam_check(a, b, c, B, C, H, W, dtype);
+  if (rc) return rc;
+  const int V = dtype == TAMTR_F32 ? 4 : 8, LPB = C / V;
+  // a chunk = a power-of-two number of whole lanes, a block's lanes inside one wave-aligned group of the 256 threads
+  if (C % (CHUNKS * V) || LPB > CPAM_THREADS || CPAM_THREADS % LPB || ((LPB / CHUNKS) & (LPB / CHUNKS - 1)) || LPB / CHUNKS > WAVE) return TAMTR_EUNSUP;
+  if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) % 16) return TAMTR_EUNSUP;
+  return TAMTR_OK;
+}
+
+extern "C" int tamtr_cpam_cl_fwd(const void* x, const void* p, void* out, float* s2, int32_t* arg, int B, int C, int H, int W, int dtype,
+                                 void* stream) {
+  const int rc = cpam_cl_check(x, p, out, B, C, H, W, dtype);
+  if (rc) return rc;
+  if (!s2 || !arg) return TAMTR_EINVAL;
+  const int V = dtype == TAMTR_F32 ? 4 : 8, bpw = CPAM_THREADS / (C / V);
+  const long long nblk = (long long)B * (H / 2) * (W / 2), grid = (nblk + bpw - 1) / bpw;
+  if (grid > 0x7fffffffLL) return TAMTR_EUNSUP;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == TAMTR_F32)
+    hipLaunchKernelGGL(cpam_cl_fwd_kernel<float>, dim3((unsigned)grid), dim3(CPAM_THREADS), 0, s, (const float*)x, (const float*)p, (float*)out, s2, arg, B, C, H, W);
+  else
+    hipLaunchKernelGGL(cpam_cl_fwd_kernel<bf16_t>, dim3((unsigned)grid), dim3(CPAM_THREADS), 0, s, (const bf16_t*)x, (const bf16_t*)p, (bf16_t*)out, s2, arg, B, C,
+                       H, W);
+  return tamtr_launch_status();
+}
+
+extern "C" int tamtr_cpam_cl_bwd(const void* gout, const void* x, const void* p, const float* s2, const int32_t* arg, void* dx_direct,
+                                 void* du_ws, void* dp, int B, int C, int H, int W, int dtype, void* stream) {
+  const int rc = cpam_cl_check(gout, x, p, B, C, H, W, dtype);
+  if (rc) return rc;
+  if (!s2 || !arg || !dx_direct || !du_ws || !dp) return TAMTR_EINVAL;
+  if (((uintptr_t)dx_direct | (uintptr_t)du_ws | (uintptr_t)dp) % 16) return TAMTR_EUNSUP;
+  const int V = dtype == TAMTR_F32 ? 4 : 8, LPB = C / V, bpw = CPAM_THREADS / LPB;
+  const long long nblk = (long long)B * (H / 2) * (W / 2), grid = (nblk + bpw - 1) / bpw, g2 = (nblk * LPB + CPAM_THREADS - 1) / CPAM_THREADS;
+  if (grid > 0x7fffffffLL || g2 > 0x7fffffffLL) return TAMTR_EUNSUP;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == TAMTR_F32) {
+    hipLaunchKernelGGL(cpam_cl_bwd_kernel<float>, dim3((unsigned)grid), dim3(CPAM_THREADS), 0, s, (const float*)gout, (const float*)x, (const float*)p, s2, arg,
+                       (float*)dx_direct, (float*)du_ws, B, C, H, W);
+    hipLaunchKernelGGL(cpam_cl_dp_kernel<float>, dim3((unsigned)g2), dim3(CPAM_THREADS), 0, s, (const float*)du_ws, (float*)dp, B, C, H, W);
+  } else {
+    hipLaunchKernelGGL(cpam_cl_bwd_kernel<bf16_t>, dim3((unsigned)grid), dim3(CPAM_THREADS), 0, s, (const bf16_t*)gout, (const bf16_t*)x, (const bf16_t*)p, s2,
+                       arg, (bf16_t*)dx_direct, (bf16_t*)du_ws, B, C, H, W);
+    hipLaunchKernelGGL(cpam_cl_dp_kernel<bf16_t>, dim3((unsigned)g2), dim3(CPAM_THREADS), 0, s, (const bf16_t*)du_ws, (bf16_t*)dp, B, C, H, W);
   }
   return tamtr_launch_status();
 }

@@ -1612,10 +1612,58 @@ class _CPAM(torch.autograd.Function):
         return dx
 
 
+class _CPAMCL(torch.autograd.Function):
+    """CPAM on a channels-last map where it lies (csrc/cpam.hip tamtr_cpam_cl_*, csrc/pool.hip with nhwc = 1): no transposing copies."""
+
+    @staticmethod
+    def forward(ctx, x):
+        require_gpu(x)
+        B, C, H, W = x.shape
+        Hp, Wp = H // 2, W // 2
+        cl = torch.channels_last
+        p = torch.empty((B, C, Hp, Wp), dtype=x.dtype, device=x.device, memory_format=cl)
+        idx = torch.empty((B, C, Hp, Wp), dtype=torch.uint8, device=x.device, memory_format=cl)
+        call('tamtr_maxpool_fwd', ptr(x), ptr(p), ptr(idx), B, C, H, W, 3, 2, 1, 1, dtype_code(x), stream_ptr())
+        out = torch.empty_like(x, memory_format=cl)
+        s2 = torch.empty(B, H, W, 8, device=x.device, dtype=torch.float32)
+        arg = torch.empty(B, H, W, 8, device=x.device, dtype=torch.int32)
+        call('tamtr_cpam_cl_fwd', ptr(x), ptr(p), ptr(out), ptr(s2), ptr(arg), B, C, H, W, dtype_code(x), stream_ptr())
+        ctx.save_for_backward(x, p, idx, s2, arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, p, idx, s2, arg = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gout = gout.to(x.dtype)
+        if not _is_cl(gout):
+            gout = gout.contiguous(memory_format=torch.channels_last)
+        cl = torch.channels_last
+        dxd, du, dp = torch.empty_like(x, memory_format=cl), torch.empty_like(x, memory_format=cl), torch.empty_like(p, memory_format=cl)
+        call('tamtr_cpam_cl_bwd', ptr(gout), ptr(x), ptr(p), ptr(s2), ptr(arg), ptr(dxd), ptr(du), ptr(dp), B, C, H, W, dtype_code(x), stream_ptr())
+        dx = torch.empty_like(x, memory_format=cl)
+        call('tamtr_maxpool_bwd', ptr(dp), ptr(idx), ptr(dxd), ptr(dx), B, C, H, W, 3, 2, 1, 1, dtype_code(x), stream_ptr())  # + the direct term
+        return dx
+
+
+def cpam_cl_ok(x):
+    """What tamtr_cpam_cl_* take: a packed channels-last map, even H and W, a chunk (C / 8 channels) = a power-of-two number of 16-byte vectors."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and _is_cl(x) and x.data_ptr() % 16 == 0):
+        return False
+    B, C, H, W = x.shape
+    V = 8 if x.dtype == torch.bfloat16 else 4
+    lpc = C // (8 * V)
+    return (H % 2 == 0 and W % 2 == 0 and C % (8 * V) == 0 and lpc >= 1 and lpc & (lpc - 1) == 0 and lpc <= 64 and C // V <= 256 and 256 % (C // V) == 0
+            and _os.environ.get('TAMTR_CPAM') != 'nchw')
+
+
 def cpam(x):
     """CPAM (extra_modules/block.py:271-308): x [B,C,H,W] fp32/bf16 -> channel gate sigmoid(up2(maxpool3s2(x))) * x followed by
     the per-chunk (8 chunks) spatial gate sigmoid(max over the chunk's channels).  One fused kernel after the pool.
-    The kernels are NCHW; a channels-last map is repacked on the way in and out (csrc/layout.hip; 4 sites per step)."""
+    Channels-last maps (the trunk's layout) take the channels-last kernels; the NCHW kernels remain for NCHW maps (deterministic mode)
+    and for channel counts the lane mapping does not cover (there a channels-last map is repacked on the way in and out)."""
+    if cpam_cl_ok(x):
+        return _CPAMCL.apply(x)
     if _is_cl(x):
         return to_channels_last(_CPAM.apply(to_nchw(x)))
     return _CPAM.apply(x)

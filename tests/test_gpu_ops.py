@@ -240,6 +240,43 @@ def test_cpam_bf16_and_argument_checks(ops):
         ops.cpam(torch.zeros(1, 16, 4, 4))             # CPU tensor
 
 
+@pytest.mark.parametrize('B,C,H,W,dt', [(2, 512, 10, 12, torch.bfloat16), (2, 256, 20, 16, torch.bfloat16), (1, 128, 36, 40, torch.bfloat16),
+                                          (2, 64, 12, 16, torch.bfloat16), (2, 128, 10, 6, torch.float32), (1, 32, 8, 8, torch.float32), (1, 512, 4, 2, torch.float32)])
+def test_cpam_channels_last_kernels(ops, B, C, H, W, dt):
+    """CPAM on channels-last maps (tamtr_cpam_cl_* + the NHWC max-pool; extra_modules/block.py:271-308): against the oracle's restatement
+    (fp32 reference of the same rounded input) and against the NCHW kernels on the repacked map - same formulas per element, so the two
+    kernel families agree to rounding of the chunk sums - at the trunk's channel counts (chunks of 2, 4, 8 and 16 lanes); the result is
+    channels-last, no transposing copy is launched."""
+    x = (rnd((B, C, H, W), 5) * 2).to(dt)
+    cot = rnd((B, C, H, W), 6).to(dt)
+    xr = x.float().clone().requires_grad_()
+    ref = O.cpam(xr)
+    (ref * cot.float()).sum().backward()
+    xc = x.cuda().contiguous(memory_format=torch.channels_last)
+    assert ops.cpam_cl_ok(xc)
+    xd = xc.clone(memory_format=torch.preserve_format).requires_grad_()
+    out = ops.cpam(xd)
+    assert out.dtype == dt and ops.is_cl(out)
+    (out.float() * cot.cuda().float()).sum().backward()
+    assert ops.is_cl(xd.grad)
+    t_o, t_g = (1e-5, 1e-4) if dt == torch.float32 else (1e-2, 3e-2)
+    assert_close(out.float(), ref, t_o, t_o if dt == torch.bfloat16 else 1e-6, 'cpam (channels-last) out')
+    assert_close(xd.grad.float(), xr.grad, t_g, t_g if dt == torch.bfloat16 else 1e-5, 'cpam (channels-last) dx')
+    # the NCHW kernels on the same values
+    xn = x.cuda().contiguous().requires_grad_()
+    on = ops._CPAM.apply(xn)
+    (on.float() * cot.cuda().float()).sum().backward()
+    if dt == torch.float32:
+        assert torch.equal(out.contiguous(), on)            # forward: identical arithmetic per element
+        assert_close(xd.grad.contiguous(), xn.grad, 1e-5, 1e-6, 'dx, channels-last vs NCHW kernels')
+    else:
+        assert_close(out.float(), on.float(), 1e-2, 1e-2, 'out, channels-last vs NCHW kernels')
+        assert_close(xd.grad.float(), xn.grad.float(), 3e-2, 3e-2, 'dx, channels-last vs NCHW kernels')
+    # channel counts outside the lane mapping fall back to the NCHW kernels behind a repack
+    odd = torch.zeros(1, 24, 4, 4, device='cuda').contiguous(memory_format=torch.channels_last)
+    assert not ops.cpam_cl_ok(odd) and ops.cpam(odd).shape == odd.shape
+
+
 def test_cpam_full_size_properties(ops):
     """BASELINE-size site (bs 16, 128 x 160 x 160, bf16): output bounded by |x| (two sigmoid gates), equals the fp32 kernel."""
     g = torch.Generator(device='cuda').manual_seed(0)
