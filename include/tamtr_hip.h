@@ -259,13 +259,16 @@ int tamtr_cpam_fwd(const void* x, const void* p, void* out, float* s2, int32_t* 
 int tamtr_cpam_bwd(const void* gout, const void* x, const void* p, const float* s2, const int32_t* arg, void* dx_direct,
                    void* du_ws, void* dp, int B, int C, int H, int W, int dtype, void* stream);
 
-/*      The same on channels-last maps (what the trunk runs): x, p, out, gout, dx_direct, du_ws, dp (T) [B][H][W][C] / [B][H/2][W/2][C],
- *      s2 f32 / arg i32 [B][H][W][8] (chunk innermost).  A lane owns a 2 x 2 pixel block x 16 bytes of channels, the chunk max / sum is a
- *      butterfly over the chunk's lanes: C % 64 == 0 (bf16) / % 32 (f32), C / 8 a power of two times the vector width, 16-byte aligned
- *      pointers.  No transposing copies around the op. */
-int tamtr_cpam_cl_fwd(const void* x, const void* p, void* out, float* s2, int32_t* arg, int B, int C, int H, int W, int dtype, void* stream);
-int tamtr_cpam_cl_bwd(const void* gout, const void* x, const void* p, const float* s2, const int32_t* arg, void* dx_direct, void* du_ws, void* dp, int B,
-                      int C, int H, int W, int dtype, void* stream);
+/*      The whole op on channels-last maps (what the trunk runs), its max-pool included: x, p, out, gout, dx and the workspaces (T)
+ *      [B][H][W][C] / [B][H/2][W/2][C]; code u8 [B][H/2][W/2][C]: which element of its 3 x 3 window each pooled value is (row-major position in
+ *      the unclipped window; first maximum wins, NaN wins - csrc/pool.hip's rules); s2 f32 / arg i32 [B][H][W][8] (chunk innermost).
+ *      A lane owns 16 bytes of channels of a pooled cell / a 2 x 2 pixel block / a pixel; the chunk max / sum is a butterfly over the chunk's
+ *      lanes: C % 64 == 0 (bf16) / % 32 (f32), C / 8 a power of two times the vector width, 16-byte aligned pointers.  Forward: p, code, out,
+ *      s2, arg are written (2 launches).  Backward: gout -> dx (3 launches: gates, bilinear gather into dp_ws, pool gather + direct term);
+ *      dxd_ws, du_ws [B][H][W][C] and dp_ws [B][H/2][W/2][C] are caller workspaces.  No transposing copies around the op. */
+int tamtr_cpam_cl_fwd(const void* x, void* p, uint8_t* code, void* out, float* s2, int32_t* arg, int B, int C, int H, int W, int dtype, void* stream);
+int tamtr_cpam_cl_bwd(const void* gout, const void* x, const void* p, const uint8_t* code, const float* s2, const int32_t* arg, void* dxd_ws,
+                      void* du_ws, void* dp_ws, void* dx, int B, int C, int H, int W, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * a-9  SS2D front end: depthwise 3x3 conv + bias + SiLU + cross-scan layout.  Replaces `x = self.act(self.conv2d(x))`

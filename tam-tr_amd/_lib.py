@@ -45,9 +45,9 @@ _SIGS = {
     'tamtr_lsap_assign': [_P, _P, _I, _I, _I, _P, _P, _P, _P],
     'tamtr_img_augment_u8': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'tamtr_cpam_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    'tamtr_cpam_cl_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'tamtr_cpam_cl_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'tamtr_cpam_bwd': [_P] * 8 + [_I, _I, _I, _I, _I, _P],
-    'tamtr_cpam_cl_bwd': [_P] * 8 + [_I, _I, _I, _I, _I, _P],
+    'tamtr_cpam_cl_bwd': [_P] * 10 + [_I, _I, _I, _I, _I, _P],
     'tamtr_dwconv_silu_cross_fwd': [_P, _LL, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'tamtr_dwconv_tiles': [_I, _I],
     'tamtr_cross_merge_fwd': [_P, _P, _I, _I, _I, _I, _I, _P],

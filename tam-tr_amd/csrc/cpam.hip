@@ -437,6 +437,92 @@ __global__ __launch_bounds__(CPAM_THREADS) void cpam_cl_dp_kernel(const T* __res
   stv<T, V>(dp + (((size_t)b * Hp + k) * Wp + l) * C + lb * V, acc);
 }
 
+// ---- CPAM's max-pool (3 x 3, stride 2, padding 1; block.py:274) on channels-last maps, 16-byte channel vectors per lane.  Same rules as
+// csrc/pool.hip (whose NHWC form handles one element per thread): the first maximum in row-major window order wins, NaN wins over everything;
+// the winner's position inside the unclipped window is kept as one byte per element and the backward is a gather (no atomics).
+template <typename T>
+__global__ __launch_bounds__(CPAM_THREADS) void pool3s2_cl_fwd_kernel(const T* __restrict__ x, T* __restrict__ p, uint8_t* __restrict__ code, int B, int C,
+                                                                       int H, int W) {
+  constexpr int V = VecT<T>::V;
+  const int Hp = H / 2, Wp = W / 2, LPB = C / V;
+  const long long id = (long long)blockIdx.x * CPAM_THREADS + threadIdx.x, total = (long long)B * Hp * Wp * LPB;
+  if (id >= total) return;
+  const int lb = (int)(id % LPB);
+  const long long q = id / LPB;
+  const int b = (int)(q / (Hp * Wp)), r = (int)(q - (long long)b * Hp * Wp), k = r / Wp, l = r - k * Wp;
+  const T* xb = x + (size_t)b * H * W * C + lb * V;
+  float v[9][V];
+#pragma unroll
+  for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw)   // (clamped addresses: every load is issued; taps outside the image are skipped below.  H, W even: only row / column -1 can be outside)
+      ldv<T, V>(xb + ((size_t)max(2 * k - 1 + dh, 0) * W + max(2 * l - 1 + dw, 0)) * C, v[dh * 3 + dw]);
+  float best[V];
+  int win[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { best[j] = -INFINITY; win[j] = (k == 0 ? 3 : 0) + (l == 0 ? 1 : 0); }
+#pragma unroll
+  for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw) {
+      const bool inside = (dh > 0 || k > 0) && (dw > 0 || l > 0);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float t = v[dh * 3 + dw][j];
+        if (inside && (t > best[j] || t != t)) { best[j] = t; win[j] = dh * 3 + dw; }
+      }
+    }
+  const size_t o = (((size_t)b * Hp + k) * Wp + l) * C + lb * V;
+  stv<T, V>(p + o, best);
+  if constexpr (V == 8) {
+    *reinterpret_cast<uint2*>(code + o) = make_uint2((uint32_t)win[0] | (win[1] << 8) | (win[2] << 16) | (win[3] << 24),
+                                                     (uint32_t)win[4] | (win[5] << 8) | (win[6] << 16) | (win[7] << 24));
+  } else {
+    *reinterpret_cast<uint32_t*>(code + o) = (uint32_t)win[0] | (win[1] << 8) | (win[2] << 16) | (win[3] << 24);
+  }
+}
+
+// gx[b, y, x, :] = addend + sum over the <= 2 x 2 windows that contain (y, x) of [code == my position] * gy
+template <typename T>
+__global__ __launch_bounds__(CPAM_THREADS) void pool3s2_cl_bwd_kernel(const T* __restrict__ gy, const uint8_t* __restrict__ code, const T* __restrict__ addend,
+                                                                       T* __restrict__ gx, int B, int C, int H, int W) {
+  constexpr int V = VecT<T>::V;
+  const int Hp = H / 2, Wp = W / 2, LPB = C / V;
+  const long long id = (long long)blockIdx.x * CPAM_THREADS + threadIdx.x, total = (long long)B * H * W * LPB;
+  if (id >= total) return;
+  const int lb = (int)(id % LPB);
+  const long long q = id / LPB;
+  const int b = (int)(q / (H * W)), r = (int)(q - (long long)b * H * W), y = r / W, xx = r - y * W;
+  // window rows containing y: y even -> {y / 2}; y odd -> {(y - 1) / 2, (y + 1) / 2} (the second only if it exists)
+  const int oh0 = y >> 1, oh1 = (y & 1) ? oh0 + 1 : -1, ow0 = xx >> 1, ow1 = (xx & 1) ? ow0 + 1 : -1;
+  const int ohs[2] = {oh0, oh1}, ows[2] = {ow0, ow1};
+  float acc[V], g[4][V];
+  ldv<T, V>(addend + (size_t)q * C + lb * V, acc);
+  uint32_t cd[4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const size_t o = (((size_t)b * Hp + min(max(ohs[a], 0), Hp - 1)) * Wp + min(max(ows[c], 0), Wp - 1)) * C + lb * V;
+      ldv<T, V>(gy + o, g[a * 2 + c]);
+      if constexpr (V == 8) { const uint2 t = *reinterpret_cast<const uint2*>(code + o); cd[a * 2 + c][0] = t.x; cd[a * 2 + c][1] = t.y; }
+      else { cd[a * 2 + c][0] = *reinterpret_cast<const uint32_t*>(code + o); cd[a * 2 + c][1] = 0; }
+    }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const bool live = ohs[a] >= 0 && ohs[a] < Hp && ows[c] >= 0 && ows[c] < Wp;
+      const int mine = (y - (2 * ohs[a] - 1)) * 3 + (xx - (2 * ows[c] - 1));
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const int cj = (cd[a * 2 + c][j >> 2] >> (8 * (j & 3))) & 0xff;
+        acc[j] += (live && cj == mine) ? g[a * 2 + c][j] : 0.f;
+      }
+    }
+  stv<T, V>(gx + (size_t)q * C + lb * V, acc);
+}
+
 }  // namespace
 
 static int cpam_check(const void* a, const void* b, const void* c, int B, int C, int H, int W, int dtype) {
@@ -494,41 +580,43 @@ static int cpam_cl_check(const void* a, const void* b, const void* c, int B, int
   return TAMTR_OK;
 }
 
-extern "C" int tamtr_cpam_cl_fwd(const void* x, const void* p, void* out, float* s2, int32_t* arg, int B, int C, int H, int W, int dtype,
+extern "C" int tamtr_cpam_cl_fwd(const void* x, void* p, uint8_t* code, void* out, float* s2, int32_t* arg, int B, int C, int H, int W, int dtype,
                                  void* stream) {
   const int rc = cpam_cl_check(x, p, out, B, C, H, W, dtype);
   if (rc) return rc;
-  if (!s2 || !arg) return TAMTR_EINVAL;
-  const int V = dtype == TAMTR_F32 ? 4 : 8, bpw = CPAM_THREADS / (C / V);
-  const long long nblk = (long long)B * (H / 2) * (W / 2), grid = (nblk + bpw - 1) / bpw;
-  if (grid > 0x7fffffffLL) return TAMTR_EUNSUP;
+  if (!s2 || !arg || !code || (uintptr_t)code % 8) return TAMTR_EINVAL;
+  const int V = dtype == TAMTR_F32 ? 4 : 8, LPB = C / V, bpw = CPAM_THREADS / LPB;
+  const long long nblk = (long long)B * (H / 2) * (W / 2), grid = (nblk + bpw - 1) / bpw, g1 = (nblk * LPB + CPAM_THREADS - 1) / CPAM_THREADS;
+  if (grid > 0x7fffffffLL || g1 > 0x7fffffffLL) return TAMTR_EUNSUP;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == TAMTR_F32)
+  if (dtype == TAMTR_F32) {
+    hipLaunchKernelGGL(pool3s2_cl_fwd_kernel<float>, dim3((unsigned)g1), dim3(CPAM_THREADS), 0, s, (const float*)x, (float*)p, code, B, C, H, W);
     hipLaunchKernelGGL(cpam_cl_fwd_kernel<float>, dim3((unsigned)grid), dim3(CPAM_THREADS), 0, s, (const float*)x, (const float*)p, (float*)out, s2, arg, B, C, H, W);
-  else
+  } else {
+    hipLaunchKernelGGL(pool3s2_cl_fwd_kernel<bf16_t>, dim3((unsigned)g1), dim3(CPAM_THREADS), 0, s, (const bf16_t*)x, (bf16_t*)p, code, B, C, H, W);
     hipLaunchKernelGGL(cpam_cl_fwd_kernel<bf16_t>, dim3((unsigned)grid), dim3(CPAM_THREADS), 0, s, (const bf16_t*)x, (const bf16_t*)p, (bf16_t*)out, s2, arg, B, C,
                        H, W);
+  }
   return tamtr_launch_status();
 }
 
-extern "C" int tamtr_cpam_cl_bwd(const void* gout, const void* x, const void* p, const float* s2, const int32_t* arg, void* dx_direct,
-                                 void* du_ws, void* dp, int B, int C, int H, int W, int dtype, void* stream) {
+extern "C" int tamtr_cpam_cl_bwd(const void* gout, const void* x, const void* p, const uint8_t* code, const float* s2, const int32_t* arg, void* dxd_ws,
+                                 void* du_ws, void* dp_ws, void* dx, int B, int C, int H, int W, int dtype, void* stream) {
   const int rc = cpam_cl_check(gout, x, p, B, C, H, W, dtype);
   if (rc) return rc;
-  if (!s2 || !arg || !dx_direct || !du_ws || !dp) return TAMTR_EINVAL;
-  if (((uintptr_t)dx_direct | (uintptr_t)du_ws | (uintptr_t)dp) % 16) return TAMTR_EUNSUP;
+  if (!s2 || !arg || !code || !dxd_ws || !du_ws || !dp_ws || !dx) return TAMTR_EINVAL;
+  if (((uintptr_t)dxd_ws | (uintptr_t)du_ws | (uintptr_t)dp_ws | (uintptr_t)dx) % 16 || (uintptr_t)code % 8) return TAMTR_EUNSUP;
   const int V = dtype == TAMTR_F32 ? 4 : 8, LPB = C / V, bpw = CPAM_THREADS / LPB;
-  const long long nblk = (long long)B * (H / 2) * (W / 2), grid = (nblk + bpw - 1) / bpw, g2 = (nblk * LPB + CPAM_THREADS - 1) / CPAM_THREADS;
-  if (grid > 0x7fffffffLL || g2 > 0x7fffffffLL) return TAMTR_EUNSUP;
+  const long long nblk = (long long)B * (H / 2) * (W / 2), grid = (nblk + bpw - 1) / bpw, g2 = (nblk * LPB + CPAM_THREADS - 1) / CPAM_THREADS,
+                  g3 = (4 * nblk * LPB + CPAM_THREADS - 1) / CPAM_THREADS;
+  if (grid > 0x7fffffffLL || g3 > 0x7fffffffLL) return TAMTR_EUNSUP;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == TAMTR_F32) {
-    hipLaunchKernelGGL(cpam_cl_bwd_kernel<float>, dim3((unsigned)grid), dim3(CPAM_THREADS), 0, s, (const float*)gout, (const float*)x, (const float*)p, s2, arg,
-                       (float*)dx_direct, (float*)du_ws, B, C, H, W);
-    hipLaunchKernelGGL(cpam_cl_dp_kernel<float>, dim3((unsigned)g2), dim3(CPAM_THREADS), 0, s, (const float*)du_ws, (float*)dp, B, C, H, W);
-  } else {
-    hipLaunchKernelGGL(cpam_cl_bwd_kernel<bf16_t>, dim3((unsigned)grid), dim3(CPAM_THREADS), 0, s, (const bf16_t*)gout, (const bf16_t*)x, (const bf16_t*)p, s2,
-                       arg, (bf16_t*)dx_direct, (bf16_t*)du_ws, B, C, H, W);
-    hipLaunchKernelGGL(cpam_cl_dp_kernel<bf16_t>, dim3((unsigned)g2), dim3(CPAM_THREADS), 0, s, (const bf16_t*)du_ws, (bf16_t*)dp, B, C, H, W);
-  }
+#define CPAM_CL_BWD(T)                                                                                                                              \
+  hipLaunchKernelGGL(cpam_cl_bwd_kernel<T>, dim3((unsigned)grid), dim3(CPAM_THREADS), 0, s, (const T*)gout, (const T*)x, (const T*)p, s2, arg,     \
+                     (T*)dxd_ws, (T*)du_ws, B, C, H, W);                                                                                            \
+  hipLaunchKernelGGL(cpam_cl_dp_kernel<T>, dim3((unsigned)g2), dim3(CPAM_THREADS), 0, s, (const T*)du_ws, (T*)dp_ws, B, C, H, W);                  \
+  hipLaunchKernelGGL(pool3s2_cl_bwd_kernel<T>, dim3((unsigned)g3), dim3(CPAM_THREADS), 0, s, (const T*)dp_ws, code, (const T*)dxd_ws, (T*)dx, B, C, H, W)
+  if (dtype == TAMTR_F32) { CPAM_CL_BWD(float); } else { CPAM_CL_BWD(bf16_t); }
+#undef CPAM_CL_BWD
   return tamtr_launch_status();
 }

@@ -1623,11 +1623,10 @@ class _CPAMCL(torch.autograd.Function):
         cl = torch.channels_last
         p = torch.empty((B, C, Hp, Wp), dtype=x.dtype, device=x.device, memory_format=cl)
         idx = torch.empty((B, C, Hp, Wp), dtype=torch.uint8, device=x.device, memory_format=cl)
-        call('tamtr_maxpool_fwd', ptr(x), ptr(p), ptr(idx), B, C, H, W, 3, 2, 1, 1, dtype_code(x), stream_ptr())
         out = torch.empty_like(x, memory_format=cl)
         s2 = torch.empty(B, H, W, 8, device=x.device, dtype=torch.float32)
         arg = torch.empty(B, H, W, 8, device=x.device, dtype=torch.int32)
-        call('tamtr_cpam_cl_fwd', ptr(x), ptr(p), ptr(out), ptr(s2), ptr(arg), B, C, H, W, dtype_code(x), stream_ptr())
+        call('tamtr_cpam_cl_fwd', ptr(x), ptr(p), ptr(idx), ptr(out), ptr(s2), ptr(arg), B, C, H, W, dtype_code(x), stream_ptr())   # pool + gates
         ctx.save_for_backward(x, p, idx, s2, arg)
         return out
 
@@ -1640,9 +1639,9 @@ class _CPAMCL(torch.autograd.Function):
             gout = gout.contiguous(memory_format=torch.channels_last)
         cl = torch.channels_last
         dxd, du, dp = torch.empty_like(x, memory_format=cl), torch.empty_like(x, memory_format=cl), torch.empty_like(p, memory_format=cl)
-        call('tamtr_cpam_cl_bwd', ptr(gout), ptr(x), ptr(p), ptr(s2), ptr(arg), ptr(dxd), ptr(du), ptr(dp), B, C, H, W, dtype_code(x), stream_ptr())
         dx = torch.empty_like(x, memory_format=cl)
-        call('tamtr_maxpool_bwd', ptr(dp), ptr(idx), ptr(dxd), ptr(dx), B, C, H, W, 3, 2, 1, 1, dtype_code(x), stream_ptr())  # + the direct term
+        call('tamtr_cpam_cl_bwd', ptr(gout), ptr(x), ptr(p), ptr(idx), ptr(s2), ptr(arg), ptr(dxd), ptr(du), ptr(dp), ptr(dx), B, C, H, W, dtype_code(x),
+             stream_ptr())
         return dx
 
 

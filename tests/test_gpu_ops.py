@@ -267,7 +267,7 @@ def test_cpam_channels_last_kernels(ops, B, C, H, W, dt):
     on = ops._CPAM.apply(xn)
     (on.float() * cot.cuda().float()).sum().backward()
     if dt == torch.float32:
-        assert torch.equal(out.contiguous(), on)            # forward: identical arithmetic per element
+        assert_close(out.contiguous(), on, 1e-6, 1e-6, 'out, channels-last vs NCHW kernels')   # same formulas; the compiler contracts the taps' products differently
         assert_close(xd.grad.contiguous(), xn.grad, 1e-5, 1e-6, 'dx, channels-last vs NCHW kernels')
     else:
         assert_close(out.float(), on.float(), 1e-2, 1e-2, 'out, channels-last vs NCHW kernels')
