@@ -240,6 +240,20 @@ template <typename T>
 __device__ __forceinline__ void ld4t(const T* p, float (&o)[4]) { Elt<T>::ld4(p, o); }
 
 __device__ __forceinline__ float wsum(float v) { return group_sum<WAVE>(v); }
+struct Vec8 {   // eight consecutive bf16 = 16 bytes
+  static __device__ __forceinline__ void ld(const bf16_t* p, float (&o)[8]) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {
+    uint4 o;
+    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = o;
+  }
+};
 
 template <typename T, int D>
 __global__ __launch_bounds__(LG_WAVES* WAVE) void ln_gate_fwd_kernel(const float* __restrict__ x, const T* __restrict__ xz, size_t zs,
@@ -463,6 +477,96 @@ __global__ __launch_bounds__(LG_WAVES* WAVE) void ln_bwd_kernel(const T* __restr
   }
 }
 
+// ---- LayerNorm over SHORT rows of bf16 (D = 64 | 128: VSSBlock.norm / norm2 at MEH level 0, hidden 128 - 409 600 tokens per pass at 640 px).
+// One wave per token leaves half the lanes idle at D = 128 and moves 8 bytes per lane: 105 us forward / 107 us backward for 210 MB (2 TB/s).
+// Here a token is LPT = D / 8 lanes x 16 bytes and a wave holds TPW = 64 / LPT tokens at a time; sums are butterflies over the LPT lanes.
+// Same partial-sum layout as ln_bwd_kernel (64 tokens per workgroup), so the callers do not change.
+template <int D>
+__global__ __launch_bounds__(LG_WAVES* WAVE) void ln_fwd_narrow_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                                        const float* __restrict__ beta, bf16_t* __restrict__ out,
+                                                                        float* __restrict__ stats, size_t ntok, float eps) {
+  constexpr int LPT = D / 8, TPW = WAVE / LPT;
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE, slot = lane / LPT, l = lane % LPT;
+  const size_t tok = ((size_t)blockIdx.x * LG_WAVES + wave) * TPW + slot;
+  const size_t tc = tok < ntok ? tok : ntok - 1;     // (clamped: lanes past the end take part in the butterflies, store nothing)
+  float v[8], g[8], be[8];
+  Vec8::ld(x + tc * D + l * 8, v);
+  Elt<float>::ld4(gamma + l * 8, *reinterpret_cast<float(*)[4]>(g)); Elt<float>::ld4(gamma + l * 8 + 4, *reinterpret_cast<float(*)[4]>(g + 4));
+  Elt<float>::ld4(beta + l * 8, *reinterpret_cast<float(*)[4]>(be)); Elt<float>::ld4(beta + l * 8 + 4, *reinterpret_cast<float(*)[4]>(be + 4));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sum += v[i];
+  const float mean = group_sum<LPT>(sum) * (1.f / D);
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const float c = v[i] - mean; sq = fmaf(c, c, sq); }
+  const float rstd = rsqrtf(group_sum<LPT>(sq) * (1.f / D) + eps);
+  if (tok >= ntok) return;
+  if (l == 0) { stats[2 * tok] = mean; stats[2 * tok + 1] = rstd; }
+  float o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = fmaf((v[i] - mean) * rstd, g[i], be[i]);
+  Vec8::st(out + tok * D + l * 8, o);
+}
+
+template <int D>
+__global__ __launch_bounds__(LG_WAVES* WAVE) void ln_bwd_narrow_kernel(const bf16_t* __restrict__ gout, const bf16_t* __restrict__ x,
+                                                                        const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                                        bf16_t* __restrict__ gx, float* __restrict__ part, size_t ntok) {
+  constexpr int LPT = D / 8, TPW = WAVE / LPT;
+  __shared__ float s_red[LG_WAVES][2][D];
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE, slot = lane / LPT, l = lane % LPT;
+  float gm[8], dgam[8], dbet[8];
+  Elt<float>::ld4(gamma + l * 8, *reinterpret_cast<float(*)[4]>(gm)); Elt<float>::ld4(gamma + l * 8 + 4, *reinterpret_cast<float(*)[4]>(gm + 4));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { dgam[i] = 0.f; dbet[i] = 0.f; }
+  const size_t tok0 = ((size_t)blockIdx.x * LG_WAVES + wave) * LG_TOK_BWD;
+  static_assert(LG_TOK_BWD % TPW == 0, "whole groups of tokens per wave");
+#pragma unroll 2
+  for (int t = 0; t < LG_TOK_BWD; t += TPW) {
+    const size_t tok = tok0 + t + slot;
+    const bool live = tok < ntok;
+    const size_t tc = live ? tok : ntok - 1;
+    const float mean = stats[2 * tc], rstd = stats[2 * tc + 1];
+    float xv[8], g[8], xh[8], gxh[8];
+    Vec8::ld(x + tc * D + l * 8, xv);
+    Vec8::ld(gout + tc * D + l * 8, g);
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (!live) g[i] = 0.f;
+      xh[i] = (xv[i] - mean) * rstd;
+      dgam[i] = fmaf(g[i], xh[i], dgam[i]);
+      dbet[i] += g[i];
+      gxh[i] = g[i] * gm[i];
+      c1 += gxh[i];
+      c2 = fmaf(gxh[i], xh[i], c2);
+    }
+    c1 = group_sum<LPT>(c1) * (1.f / D);
+    c2 = group_sum<LPT>(c2) * (1.f / D);
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = rstd * (gxh[i] - c1 - xh[i] * c2);
+    if (live) Vec8::st(gx + tok * D + l * 8, o);
+  }
+  // the TPW token slots of the wave hold sums for the same channels: add them (fixed order), slot 0 publishes
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int o = LPT; o < WAVE; o <<= 1) { dgam[i] += __shfl_xor(dgam[i], o, WAVE); dbet[i] += __shfl_xor(dbet[i], o, WAVE); }
+  if (slot == 0)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s_red[wave][0][l * 8 + i] = dgam[i]; s_red[wave][1][l * 8 + i] = dbet[i]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += LG_WAVES * WAVE) {
+    const int which = i / D, d = i - which * D;
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < LG_WAVES; ++w) a += s_red[w][which][d];
+    part[((size_t)blockIdx.x * 2 + which) * D + d] = a;
+  }
+}
+
 }  // namespace
 
 extern "C" int tamtr_cross_merge_fwd(const void* y4, float* ymT, int B, int D, int H, int W, int plane_dtype, void* stream) {
@@ -574,9 +678,16 @@ extern "C" int tamtr_layernorm_fwd(const void* x, const float* gamma, const floa
   const int rc = ln_check(x, gamma, out, ntok, D, dtype);
   if (rc) return rc;
   if (!beta || !stats) return TAMTR_EINVAL;
-  const dim3 grid((unsigned)((ntok + LG_WAVES - 1) / LG_WAVES));
   hipStream_t s = (hipStream_t)stream;
   const size_t nt = (size_t)ntok;
+  if (dtype == TAMTR_BF16 && (D == 64 || D == 128) && ((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) % 16 == 0) {   // short rows: several tokens per wave
+    const int tpw = WAVE / (D / 8);
+    const dim3 g2((unsigned)((ntok + LG_WAVES * tpw - 1) / (LG_WAVES * tpw)));
+    if (D == 64) hipLaunchKernelGGL(ln_fwd_narrow_kernel<64>, g2, dim3(LG_WAVES * WAVE), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)out, stats, nt, eps);
+    else hipLaunchKernelGGL(ln_fwd_narrow_kernel<128>, g2, dim3(LG_WAVES * WAVE), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)out, stats, nt, eps);
+    return tamtr_launch_status();
+  }
+  const dim3 grid((unsigned)((ntok + LG_WAVES - 1) / LG_WAVES));
   if (dtype == TAMTR_F32) { LN_DISPATCH(ln_fwd_kernel, float, (const float*)x, gamma, beta, (float*)out, stats, nt, eps) }
   else { LN_DISPATCH(ln_fwd_kernel, bf16_t, (const bf16_t*)x, gamma, beta, (bf16_t*)out, stats, nt, eps) }
   return tamtr_launch_status();
@@ -590,6 +701,11 @@ extern "C" int tamtr_layernorm_bwd(const void* gout, const void* x, const float*
   const dim3 grid((unsigned)tamtr_ln_gate_blocks(ntok));
   hipStream_t s = (hipStream_t)stream;
   const size_t nt = (size_t)ntok;
+  if (dtype == TAMTR_BF16 && (D == 64 || D == 128) && ((uintptr_t)x | (uintptr_t)gout | (uintptr_t)gx | (uintptr_t)gamma) % 16 == 0) {
+    if (D == 64) hipLaunchKernelGGL(ln_bwd_narrow_kernel<64>, grid, dim3(LG_WAVES * WAVE), 0, s, (const bf16_t*)gout, (const bf16_t*)x, gamma, stats, (bf16_t*)gx, partials, nt);
+    else hipLaunchKernelGGL(ln_bwd_narrow_kernel<128>, grid, dim3(LG_WAVES * WAVE), 0, s, (const bf16_t*)gout, (const bf16_t*)x, gamma, stats, (bf16_t*)gx, partials, nt);
+    return tamtr_launch_status();
+  }
   if (dtype == TAMTR_F32) { LN_DISPATCH(ln_bwd_kernel, float, (const float*)gout, (const float*)x, gamma, stats, (float*)gx, partials, nt) }
   else { LN_DISPATCH(ln_bwd_kernel, bf16_t, (const bf16_t*)gout, (const bf16_t*)x, gamma, stats, (bf16_t*)gx, partials, nt) }
   return tamtr_launch_status();
