@@ -491,11 +491,13 @@ __global__ __launch_bounds__(NW* WAVE) void selscan_fwd_kernel(const float* __re
       const __amdgpu_buffer_rsrc_t hs_rs = row_rsrc(hstate + row * (size_t)nblk * NS, nblk * NS);
       const int blk = c * (CH / BLK) + lane / LPB;
       const unsigned hs_off = (lane % LPB == LPB - 1 && blk < nblk) ? (unsigned)blk * NS * 4 : OOB;
+      float sdt = 0.f;   // sum of the lane's dt: the lane's composed decay is exp2(A2 * sdt) - one exp instead of IT - 1 multiplies per state
 #pragma unroll
       for (int i = 0; i < IT; ++i) {
         dt[i] = softplus_f((t + i < L) ? dt[i] + bias : -1e30f);  // steps beyond L become the identity map (dt = 0: a = 1, b = 0)
         dtu[i] = dt[i] * uu[i];
         yy[i] = Dd * uu[i];
+        sdt += dt[i];
       }
 #pragma unroll
       for (int n = 0; n < NS; n += 2) {
@@ -515,10 +517,14 @@ __global__ __launch_bounds__(NW* WAVE) void selscan_fwd_kernel(const float* __re
             a[j][i] = __builtin_amdgcn_exp2f(dt[i] * A2);
             bb[j][i] *= dtu[i];
           }
-          A[j] = a[j][0];
+#ifndef SCAN_FWD_SUMDT
+#define SCAN_FWD_SUMDT 1   // (A/B build: 0 = the lane's decay as the product of its steps' decays)
+#endif
+          constexpr bool SUMDT = SCAN_FWD_SUMDT && IT > ITEMS;
+          A[j] = SUMDT ? __builtin_amdgcn_exp2f(sdt * A2) : a[j][0];
           Bv[j] = bb[j][0];
 #pragma unroll
-          for (int i = 1; i < IT; ++i) { Bv[j] = fmaf(a[j][i], Bv[j], bb[j][i]); A[j] *= a[j][i]; }
+          for (int i = 1; i < IT; ++i) { Bv[j] = fmaf(a[j][i], Bv[j], bb[j][i]); if (!SUMDT) A[j] *= a[j][i]; }
           hin[j] = rdlane(hc, n + j);               // state entering the chunk: joins at lane 0, from there on Bv is the state itself
           Bv[j] = fmaf(A[j] * m0, hin[j], Bv[j]);
         }
