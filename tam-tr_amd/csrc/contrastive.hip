@@ -289,9 +289,9 @@ extern "C" int tamtr_contrastive_logits_bwd(const float* g, const void* x, const
   dim3 grid((Q + CT_BROWS - 1) / CT_BROWS, B);
 #define GO1(ET, NP, REGS)                                                                                       \
   {                                                                                                             \
-    if (lds > 64 * 1024)                                                                                        \
-      (void)hipFuncSetAttribute((const void*)contrastive_bwd_kernel<ET, NP, REGS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds);                                                                      \
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)contrastive_bwd_kernel<ET, NP, REGS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                               (int)lds) != hipSuccess)                                        \
+      return TAMTR_ELAUNCH;                                                                                     \
     hipLaunchKernelGGL((contrastive_bwd_kernel<ET, NP, REGS>), grid, dim3(CT_THREADS), lds, s, g, (const ET*)x, w, logit_scale, xinv, \
                        (ET*)dx, dwhat, Q, K, C);                                                                \
   }

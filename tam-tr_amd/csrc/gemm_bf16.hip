@@ -744,11 +744,11 @@ extern "C" int tamtr_linear_bf16(const void* X, const void* W, const float* bias
     if ((long long)mbl * nbl > 0x7fffffffLL) return TAMTR_EUNSUP;
     const size_t lds5 = (size_t)NST * ST_BYTES;  // 4 x 40 KB ring = all 160 KB of a CU (epilogue image aliases a stage)
     static_assert(NST * ST_BYTES <= 160 * 1024 && EP_BYTES <= ST_BYTES, "LDS budget");
-    (void)hipFuncSetAttribute((const void*)linear_bf16_n512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
+    if (hipFuncSetAttribute((const void*)linear_bf16_n512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5) != hipSuccess) return TAMTR_ELAUNCH;
     const int tiles = mbl * nbl;
     const int grid = tiles < 256 ? tiles : 256;  // one persistent workgroup per CU
     if (K % K6 == 0) {  // 128-B pieces, 2-stage ring (measured 5 % faster than the 64-B / 4-stage ring below)
-      (void)hipFuncSetAttribute((const void*)linear_bf16_n512_k64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST6);
+      if (hipFuncSetAttribute((const void*)linear_bf16_n512_k64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST6) != hipSuccess) return TAMTR_ELAUNCH;
       hipLaunchKernelGGL(linear_bf16_n512_k64_kernel, dim3((unsigned)grid), dim3(T5), 2 * ST6, (hipStream_t)stream,
                          (const bf16_t*)X, (const bf16_t*)W, bias, (bf16_t*)Y, M, N, K, nbl, tiles);
       return tamtr_launch_status();
