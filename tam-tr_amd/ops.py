@@ -495,14 +495,14 @@ def _split_count(M, min_rows=2048, max_split=None):
 _BMM_F32_OUT = None  # does this torch build take bmm(..., out_dtype=float32) on the GPU?
 
 
-def dw_splitk(g2, x2):
+def dw_splitk(g2, x2, min_rows=2048):
     """dW [N, K] = g2^T x2 for very tall operands (M = B*L rows >> N, K), fp32 result.
     A single M-reduction GEMM of this shape has only (N/64)*(K/128) = 8..32 output tiles: hipBLASLt ran it on that many
     workgroups (945 us for M = 537 600, N = K = 512: 0.3 PF/s).  Sliced into S row blocks it is ONE batched GEMM with S x
     the tiles, and the S partial products are summed in fp32."""
     M, N = g2.shape
     K = x2.shape[1]
-    S = _split_count(M)
+    S = _split_count(M, min_rows)
     if S == 1:
         return (g2.t() @ x2).float()
     a, b = g2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, K)
@@ -597,13 +597,16 @@ class _LinearMaster(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.mm(g2, w16).view(x16.shape).to(x_dt)
         if ctx.needs_input_grad[1]:
-            gw = _mm_f32(g2.t(), x2).to(w_dt)
+            # M = B * Q = 4 672 rows against N x K <= 1 024 x 1 024 outputs: as ONE product the library runs it on 16 - 64 workgroups (35 us
+            # whatever N and K: profiles/r03_gemm_census.txt); as 8 row slices it is a batched product on 8 x the tiles + the ordered sum
+            gw = (dw_splitk(g2, x2, _LM_MIN_ROWS) if _LM_MIN_ROWS else _mm_f32(g2.t(), x2)).to(w_dt)
         if b_dt is not None and ctx.needs_input_grad[2]:
             gb = colsum(g2).to(b_dt)
         return gx, gw, gb, None, None
 
 
 _MM_F32_OUT = None
+_LM_MIN_ROWS = int(_os.environ.get('TAMTR_LINEAR_MASTER_SLICE_ROWS', '512'))   # A/B knob: 0 = the weight gradient as one product
 
 
 def _mm_f32(a, b):
