@@ -598,7 +598,7 @@ class _LinearMaster(torch.autograd.Function):
             gx = torch.mm(g2, w16).view(x16.shape).to(x_dt)
         if ctx.needs_input_grad[1]:
             # M = B * Q = 4 672 rows against N x K <= 1 024 x 1 024 outputs: as ONE product the library runs it on 16 - 64 workgroups (35 us
-            # whatever N and K: profiles/r03_gemm_census.txt); as 8 row slices it is a batched product on 8 x the tiles + the ordered sum
+            # whatever N and K: profiles/r03_gemm_census.txt); as 16 row slices it is a batched product on 16 x the tiles + the ordered sum (A/B: 77.5 -> 77.1 ms per step)
             gw = (dw_splitk(g2, x2, _LM_MIN_ROWS) if _LM_MIN_ROWS else _mm_f32(g2.t(), x2)).to(w_dt)
         if b_dt is not None and ctx.needs_input_grad[2]:
             gb = colsum(g2).to(b_dt)
@@ -606,7 +606,7 @@ class _LinearMaster(torch.autograd.Function):
 
 
 _MM_F32_OUT = None
-_LM_MIN_ROWS = int(_os.environ.get('TAMTR_LINEAR_MASTER_SLICE_ROWS', '512'))   # A/B knob: 0 = the weight gradient as one product
+_LM_MIN_ROWS = int(_os.environ.get('TAMTR_LINEAR_MASTER_SLICE_ROWS', '256'))   # A/B knob: 0 = the weight gradient as one product
 
 
 def _mm_f32(a, b):
