@@ -411,3 +411,41 @@ def test_bench_refuses_more_ranks_than_gpus_before_launching_anything():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0'], env=env, capture_output=True,
                        text=True, timeout=120)
     assert r.returncode != 0 and 'one rank per GPU' in r.stderr and '[launch]' not in r.stderr, r.stderr[-1500:]
+
+
+def test_round4_gpu_paths_are_gated_on_the_host_and_fall_back_to_the_reference_ops_on_cpu():
+    """The round-4 GPU forms (decoder linears with master gradients, box refinement, decoder LayerNorm, channels-last CPAM, bf16 planes,
+    weight copies) are chosen by host-side predicates: on CPU tensors every predicate says no and the op is the reference's torch expression
+    (what the CPU parity tests run); a parameter without an optimizer-maintained copy is simply cast."""
+    import tamtr_amd.ops as ops
+    torch.manual_seed(0)
+    lin = nn.Linear(16, 8)
+    x = torch.randn(5, 16)
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        assert not ops.linear_master_ok(x, lin)
+        y = ops.linear(x, lin)
+    assert torch.equal(y.float(), lin(x).float()) or y.dtype == torch.bfloat16     # the module itself (under CPU autocast: its bf16 result)
+    assert torch.equal(ops.linear_rows(x, lin.weight, lin.bias, 2, 6), torch.nn.functional.linear(x, lin.weight[2:6], lin.bias[2:6]))
+    assert ops.shared_bf16(x, lin) is x
+    # a parameter with no shadow copy: bf16_of is the cast autocast would make; a stale copy is not handed out
+    p = nn.Parameter(torch.randn(4, 4))
+    assert ops.bf16_shadow(p) is None and torch.equal(ops.bf16_of(p), p.detach().bfloat16())
+    sh = p.detach().bfloat16()
+    sh._tamtr_version = p._version
+    p._tamtr_bf16 = sh
+    assert ops.bf16_shadow(p) is sh and ops.bf16_of(p) is sh
+    with torch.no_grad():
+        p.mul_(2.0)                                                               # the master moves on, the copy does not
+    assert ops.bf16_shadow(p) is None and torch.equal(ops.bf16_of(p), p.detach().bfloat16())
+    # box refinement = the reference expression (transformer.py:881-887, utils.py:46-52)
+    d, r = torch.randn(2, 7, 4), torch.rand(2, 7, 4)
+    xr = r.clamp(min=0, max=1)
+    assert torch.equal(ops.box_refine(d, r), torch.sigmoid(d + torch.log(xr.clamp(min=1e-5) / (1 - xr).clamp(min=1e-5))))
+    # LayerNorm, CPAM, planes
+    ln = nn.LayerNorm(32)
+    t = torch.randn(3, 32)
+    assert torch.equal(ops.layer_norm_module(ln, t), ln(t))
+    assert not ops.cpam_cl_ok(torch.zeros(1, 64, 4, 4).contiguous(memory_format=torch.channels_last))
+    assert not ops.ss2d_bf16_planes(torch.float32, 256, 6400, 8, 16)               # fp32 mode keeps fp32 planes
+    assert not ops.ss2d_bf16_planes(torch.bfloat16, 256, 6404, 8, 16)              # not on the vector path
+    assert ops.ss2d_bf16_planes(torch.bfloat16, 256, 6400, 8, 16) == (os.environ.get('TAMTR_SS2D_PLANES') != 'f32' and os.environ.get('TAMTR_XPROJ') != 'torch')
