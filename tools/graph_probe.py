@@ -14,6 +14,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import synth_batch
 from tamtr_amd.model import RTDETRDetectionWorldModel
 
+from tamtr_amd.tuning import use_tuned_convolutions
+use_tuned_convolutions(os.environ.get('CONV_TUNING', 'shipped'))   # as bench.py: with MIOpen's heuristic the backward records memset-based solvers
 tag = sys.argv[1] if len(sys.argv) > 1 else ''
 B, S = int(os.environ.get('BS', 16)), int(os.environ.get('IMG', 640))
 torch.manual_seed(0)

@@ -4,10 +4,14 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import synth_batch
 from tamtr_amd.model import RTDETRDetectionWorldModel
+from tamtr_amd.tuning import use_tuned_convolutions
+use_tuned_convolutions('shipped')
 torch.manual_seed(0)
 model = RTDETRDetectionWorldModel(nc=10).cuda().train()
 model.autocast_dtype = torch.bfloat16
 batch = synth_batch(16, 640, 1, 'cuda')
+if os.environ.get('STATIC_PART', 'graph') == 'graph':
+    model.capture_static_part(batch['img'], batch['txt_feats'])
 for _ in range(3):
     model.zero_grad(set_to_none=True)
     l, _ = model(batch); l.backward()
