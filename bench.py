@@ -412,6 +412,13 @@ def main():
             model.release_static_part()
             static_part = f'eager (capture failed: {type(e).__name__}: {e})'[:200]
             note(static_part)
+        if world > 1:   # every rank runs the same form of the step (and the same checks with collectives in them afterwards): graphs only if ALL captured
+            ok = torch.tensor([1 if static_part == 'hip-graph' else 0], device=dev, dtype=torch.int32)
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+            if int(ok) == 0 and static_part == 'hip-graph':
+                model.release_static_part()
+                static_part = 'eager (another rank could not capture its static part)'
+                note(static_part)
     note(f'model built on {world} GPU(s), dtype {args.dtype}; warm-up ({args.warmup} steps; the first one includes MIOpen kernel selection)')
     for i in range(args.warmup):
         t1 = time.perf_counter()

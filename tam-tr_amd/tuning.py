@@ -97,7 +97,7 @@ def _no_naive_solvers():
         os.environ.setdefault(f'MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_{d}', '0')
 
 
-def use_tuned_convolutions(mode='shipped', db_dir=None, log=None):
+def use_tuned_convolutions(mode='shipped', db_dir=None, log=None, rank_suffix=''):
     """Call before the first convolution.  mode: 'shipped' - timed-search mode backed by the shipped tables if they match this
     MIOpen build, else MIOpen's default heuristic; 'search' - timed search into db_dir (slow first run; how the tables are made);
     'off' - default heuristic.  TAMTR_DETERMINISTIC=1 overrides all of them with use_deterministic_convolutions().
@@ -110,7 +110,7 @@ def use_tuned_convolutions(mode='shipped', db_dir=None, log=None):
     if mode == 'off':
         return 'off (MIOpen heuristic)'
     if mode == 'search':
-        db_dir = db_dir or _user_db_dir()[0]
+        db_dir = db_dir or _user_db_dir(rank_suffix)[0]
         os.makedirs(db_dir, exist_ok=True)
         os.environ['MIOPEN_USER_DB_PATH'] = db_dir
         torch.backends.cudnn.benchmark = True
@@ -120,7 +120,7 @@ def use_tuned_convolutions(mode='shipped', db_dir=None, log=None):
         raise ValueError(mode)
     if not shipped_db_matches():
         return 'off (shipped tables are for another MIOpen build)'
-    work, persistent = _user_db_dir()
+    work, persistent = _user_db_dir(rank_suffix)
     _seed(work)
     os.environ['MIOPEN_USER_DB_PATH'] = work
     torch.backends.cudnn.benchmark = True
@@ -133,12 +133,13 @@ def use_tuned_convolutions(mode='shipped', db_dir=None, log=None):
 
 
 def use_tuned_convolutions_ranked(mode='shipped', db_dir=None, log=None, rank=0, world=1):
-    """use_tuned_convolutions() for one rank of a data-parallel job on one host: the ranks share the per-user table directory, so rank 0
-    seeds it (the copy of the shipped tables) while the others wait at a barrier, and no rank opens a table another one is still
-    writing.  Needs the process group (and, for RCCL, the rank's device) to be set up; world == 1 is the plain call."""
-    if world > 1 and rank != 0:
-        torch.distributed.barrier()
-    out = use_tuned_convolutions(mode, db_dir, log)
-    if world > 1 and rank == 0:
-        torch.distributed.barrier()
-    return out
+    """use_tuned_convolutions() for one rank of a data-parallel job on one host.  Every rank gets a table directory OF ITS OWN
+    (`...-rank<r>`, seeded from the shipped tables): MIOpen guards its writable tables with lock files, and a rank that does not get the
+    lock in time treats the lookup as a miss - it then runs a real timed search for that convolution and may come back with another
+    solver than the table holds (round 4's 2-rank rehearsal: seven weight-gradient convolutions on memset-based solvers on one rank, which
+    the graph recorder refuses under AQL packet capture - profiles/r04_ddp_memset_probe.txt).  world == 1 is the plain call (shared
+    per-user directory)."""
+    if world <= 1:
+        return use_tuned_convolutions(mode, db_dir, log)
+    sub = None if db_dir is None else os.path.join(db_dir, f'rank{rank}')
+    return use_tuned_convolutions(mode, sub, log, rank_suffix=f'-rank{rank}')

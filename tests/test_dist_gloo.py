@@ -290,8 +290,7 @@ def test_eight_ranks_self_launched_bf16_buckets_one_rank_without_boxes(tmp_path)
     """The 8-GPU configuration (BASELINE configs[3]) rehearsed on the CPU: a script started as `python script --gpus 8` becomes the
     launcher of 8 gloo ranks (launch_plan / self_launch, as bench.py does); the ranks shard 64 samples, reduce their gradients through
     GradReducer with bf16 buckets on the wire, one rank's step has no contribution for the `late` parameter (a batch without boxes:
-    no gradient for `denoising_class_embed`), the table directory is seeded by rank 0 first (tuning.use_tuned_convolutions_ranked's
-    barrier protocol).  Checked: every rank issues the collectives in bucket order on every step, every rank ends with the same fp32
+    no gradient for `denoising_class_embed`), every rank has a MIOpen table directory of its own (tuning.use_tuned_convolutions_ranked).  Checked: every rank issues the collectives in bucket order on every step, every rank ends with the same fp32
     gradients, and they are the bf16-wire sums of the single-process gradient of the whole batch."""
     script = tmp_path / 'dp8.py'
     script.write_text(f'''
@@ -305,14 +304,16 @@ import torch, torch.nn as nn, torch.distributed as dist
 rank, local, world = tdist.init_from_env('gloo')
 torch.set_num_threads(1)
 out = sys.argv[sys.argv.index('--out') + 1]
-# rank 0 first, the others behind its barrier (the order tuning.use_tuned_convolutions_ranked keeps for the shared table directory)
-mark = os.path.join(out, 'seeded')
-if rank != 0:
-    dist.barrier()
-    assert os.path.exists(mark), 'a rank passed the barrier before rank 0 had seeded'
-else:
-    open(mark, 'w').close()
-    dist.barrier()
+# every rank works on a MIOpen table directory of its own (tuning.use_tuned_convolutions_ranked: ranks that share one directory contend for
+# MIOpen's lock files, and a rank that loses the race searches instead of looking up)
+os.environ['TAMTR_MIOPEN_DB_DIR'] = out
+from tamtr_amd import tuning
+mine, _ = tuning._user_db_dir(f'-rank{{rank}}')
+open(os.path.join(mine, 'owner'), 'w').write(str(rank))
+dist.barrier()
+dirs = sorted(d for d in os.listdir(out) if '-rank' in d)
+assert len(dirs) == world, dirs
+assert open(os.path.join(mine, 'owner')).read() == str(rank)
 
 
 class Net(nn.Module):
