@@ -26,7 +26,7 @@ figure between two eager passes (`eager_noise_*`: MIOpen's split-K / atomic solv
 `config.static_part_check`: the capture-time check (GraphedPart.verify: token memory and all 552 parameter gradients of a replay
 against eager execution).  `host_cpu_ms_per_step`: process CPU time (user + system, all threads of the rank) per timed step, max and
 per rank - the share of a step the host spends issuing work, which is what N ranks on one host compete for.
-`config.conv_tuning`: how MIOpen picked the trunk's convolution kernels (tam-tr_amd/tuning.py: its own timed search, replayed from
+`config.conv_tuning`: how MIOpen picked the trunk's convolution kernels (tam-tr_amd/tuning.py: its own timed search, looked up in immediate mode from
 the tables shipped in the repo).  `config.static_part`: "hip-graph" when the shape-static part of the step (trunk, VSS blocks, input projection: ~3/4 of the
 launches) is replayed as two HIP graphs (model.capture_static_part), "eager" otherwise (--static-part eager).
 For N > 1 the process group must be RCCL (`nccl`): the line records backend and world size, anything else is refused.
@@ -301,7 +301,7 @@ def main():
     ap.add_argument('--static-part', default='graph', choices=['graph', 'eager'],
                     help='trunk + VSS blocks + input projection replayed as two HIP graphs (forward, backward) or launched kernel by kernel')
     ap.add_argument('--conv-tuning', default='shipped', choices=['shipped', 'search', 'off'],
-                    help="MIOpen solver choice for the trunk's convolutions: its timed search backed by the tables shipped under "
+                    help="MIOpen solver choice for the trunk's convolutions: immediate mode on the tables of its own timed search shipped under "
                          'tam-tr_amd/tuned/miopen (default), a fresh search (minutes), or its heuristic')
     ap.add_argument('--conv-db', default=None, help='directory the search writes its tables to (--conv-tuning search)')
     ap.add_argument('--grad-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire (N > 1)')

@@ -98,8 +98,8 @@ def _no_naive_solvers():
 
 
 def use_tuned_convolutions(mode='shipped', db_dir=None, log=None, rank_suffix=''):
-    """Call before the first convolution.  mode: 'shipped' - timed-search mode backed by the shipped tables if they match this
-    MIOpen build, else MIOpen's default heuristic; 'search' - timed search into db_dir (slow first run; how the tables are made);
+    """Call before the first convolution.  mode: 'shipped' - MIOpen's immediate mode on the shipped tables (the best recorded solution per
+    convolution, nothing timed in this process) if they match this MIOpen build, else MIOpen's default heuristic; 'search' - timed search into db_dir (slow first run; how the tables are made);
     'off' - default heuristic.  TAMTR_DETERMINISTIC=1 overrides all of them with use_deterministic_convolutions().
     Returns what was set up, for logs."""
     if os.environ.get('TAMTR_DETERMINISTIC') == '1':
@@ -123,12 +123,18 @@ def use_tuned_convolutions(mode='shipped', db_dir=None, log=None, rank_suffix=''
     work, persistent = _user_db_dir(rank_suffix)
     _seed(work)
     os.environ['MIOPEN_USER_DB_PATH'] = work
-    torch.backends.cudnn.benchmark = True
+    # MIOpen's IMMEDIATE mode on the tables (cudnn.benchmark off): every convolution takes the best RECORDED solution; nothing is timed in this
+    # process.  With cudnn.benchmark on, ATen calls MIOpen's Find, which re-times the candidates in every process whatever the tables hold (it
+    # rewrote the user copy of the find-db in every run): the solver choice then depends on that run's timings - identical on an idle GPU, but
+    # with several ranks timing on one GPU at once some weight-gradient convolutions came back on memset-based solvers (round 4's 2-rank
+    # rehearsal, profiles/r04_ddp_memset_probe.txt), a different set on every rank and run.  Same step time (77.5 against 77.6 ms on one box).
+    # TAMTR_CONV_FIND=search restores the timed search (what 'search' mode uses to write tables for other shapes).
+    torch.backends.cudnn.benchmark = os.environ.get('TAMTR_CONV_FIND') == 'search'
     _no_naive_solvers()
     if log:
-        log(f'convolutions: MIOpen timed search backed by the shipped tables (640 px / 16 images, 1280 px / 8 images) in {work}'
-            f'{"" if persistent else " (temporary)"}; a shape outside them - a tail batch, the validation batch - is searched once (minutes) '
-            'and kept there')
+        log(f'convolutions: MIOpen immediate mode on the shipped tables (640 px / 16 images, 1280 px / 8 images) in {work}'
+            f'{"" if persistent else " (temporary)"}; a shape outside them - a tail batch, the validation batch - gets MIOpen\'s heuristic choice '
+            '(tools/tune_miopen.sh / --conv-tuning search writes tables for other shapes)')
     return 'shipped tables'
 
 

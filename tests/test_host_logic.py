@@ -272,9 +272,22 @@ def test_tuned_tables_go_to_a_persistent_directory_and_are_never_clobbered(tmp_p
         logs = []
         assert tuning.use_tuned_convolutions('shipped', log=logs.append) == 'shipped tables'
         work = os.environ['MIOPEN_USER_DB_PATH']
-        assert work.startswith(str(tmp_path)) and str(torch.backends.cudnn.version()) in work and logs and 'searched once' in logs[0]
+        assert work.startswith(str(tmp_path)) and str(torch.backends.cudnn.version()) in work and logs and 'immediate mode' in logs[0]
         shipped = sorted(os.path.basename(f) for f in glob.glob(os.path.join(tuning._DIR, '*.txt')))
-        assert sorted(os.listdir(work)) == shipped and torch.backends.cudnn.benchmark
+        # immediate mode: the best recorded solution per convolution, no timing in this process (ranks timing on one GPU at once chose
+        # memset-based solvers: round 4); TAMTR_CONV_FIND=search brings MIOpen's timed Find back
+        assert sorted(os.listdir(work)) == shipped and not torch.backends.cudnn.benchmark
+        monkeypatch.setenv('TAMTR_CONV_FIND', 'search')
+        tuning.use_tuned_convolutions('shipped')
+        assert torch.backends.cudnn.benchmark
+        monkeypatch.delenv('TAMTR_CONV_FIND')
+        # every rank of a multi-rank job works on a directory of its own
+        monkeypatch.delenv('MIOPEN_USER_DB_PATH', raising=False)
+        assert tuning.use_tuned_convolutions_ranked('shipped', rank=3, world=8) == 'shipped tables'
+        assert os.environ['MIOPEN_USER_DB_PATH'].endswith('-rank3') and os.environ['MIOPEN_USER_DB_PATH'] != work
+        assert sorted(os.listdir(os.environ['MIOPEN_USER_DB_PATH'])) == shipped
+        tuning.use_tuned_convolutions('shipped')
+        assert os.environ['MIOPEN_USER_DB_PATH'] == work
         grown = os.path.join(work, shipped[0])
         with open(grown, 'a') as f:
             f.write('entry found by a later run\n')

@@ -20,6 +20,9 @@ rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1
 if world > 1:
     dist.init_process_group('gloo', rank=rank, world_size=world)
 torch.cuda.set_device(0)
+if os.environ.get('PROBE_SERIAL') == '1' and world > 1:   # one rank after the other: is it the concurrency on the shared GPU, or the set-up?
+    for r in range(rank):
+        dist.barrier()
 print(f'[rank {rank}] OMP_NUM_THREADS={os.environ.get("OMP_NUM_THREADS")} torch threads {torch.get_num_threads()}', flush=True)
 use_tuned_convolutions_ranked('shipped', None, rank=rank, world=world)
 torch.manual_seed(0)
@@ -54,8 +57,12 @@ for e in prof.events():
         if 'emset' in k.name or 'fillBuffer' in k.name:
             frame = next((f for f in (e.stack or []) if 'tam-tr_amd' in f or 'tamtr_amd' in f), (e.stack or ['?'])[0] if e.stack else '?')
             rows[(e.name, str(e.input_shapes)[:120], frame.strip()[-100:])][0] += 1
-if world > 1:
+if os.environ.get('PROBE_SERIAL') == '1' and world > 1:
+    for r in range(rank, world - 1):
+        dist.barrier()
+elif world > 1:
     dist.barrier()
+print(f'[rank {rank}] memset kernels: {sum(v[0] for v in rows.values())}', flush=True)
 if rank == 0:
     print(f'# world {world}: memset kernels of one eager pass over the recorded part: {sum(v[0] for v in rows.values())}')
     for (op, shp, fr), (n, _) in sorted(rows.items(), key=lambda x: -x[1][0]):
