@@ -159,7 +159,8 @@ class FusedOptimStep:
                 s._tamtr_version = p._version
 
     def drop_shadows(self):
-        for p, _ in self.shadows:
+        for p, s in self.shadows:
+            s._tamtr_version = -1     # (a recorded graph that still reads this copy re-derives it before every replay: graphs.GraphedPart.__call__)
             if hasattr(p, '_tamtr_bf16'):
                 del p._tamtr_bf16
         self.shadows = []

@@ -62,6 +62,15 @@ class GraphedPart:
         self.module = module
         self.names, self.params = zip(*[(n, p) for n, p in module.named_parameters()])
         alias = {n: torch.nn.Parameter(p.detach(), requires_grad=p.requires_grad) for n, p in zip(self.names, self.params)}  # same storage
+        # bf16 copies of the weights kept by the optimizer kernel (engine.FusedOptimStep(shadows=True)): the recorded function reads them through
+        # the aliases (ops.bf16_shadow follows `_tamtr_alias_of` to the real parameter for the version check).  A replay runs no Python inside,
+        # so __call__ re-derives any copy whose master was written behind the stepper's back BEFORE the replay (self.shadow_pairs).
+        self.shadow_pairs = []
+        for n, p in zip(self.names, self.params):
+            sh = getattr(p, '_tamtr_bf16', None)
+            if sh is not None and getattr(sh, '_tamtr_version', None) == p._version:
+                alias[n]._tamtr_bf16, alias[n]._tamtr_alias_of = sh, p
+                self.shadow_pairs.append((p, sh))
         self.static_in = [a.detach().clone() for a in sample_args]
         self.stream = torch.cuda.Stream()
         self.fwd, self.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -224,4 +233,11 @@ class GraphedPart:
             # AccumulateGrad adopted the static gradient buffer as .grad last step; accumulating onto it would add the new
             # gradient to itself
             raise RuntimeError('GraphedPart: clear gradients with zero_grad(set_to_none=True) (or give .grad its own storage) between steps')
+        if self.shadow_pairs:
+            stale = [(p, s) for p, s in self.shadow_pairs if s._tamtr_version != p._version]
+            if stale:   # (not on the normal path: FusedOptimStep.step() keeps the copies current)
+                with torch.no_grad():
+                    torch._foreach_copy_([s for _, s in stale], [p for p, _ in stale])
+                for p_, s_ in stale:
+                    s_._tamtr_version = p_._version
         return self._fn.apply(*args, *self.params)

@@ -555,8 +555,10 @@ def bf16_shadow(p):
     """The bf16 copy of an fp32 parameter that the optimizer kernel keeps next to it (engine.FusedOptimStep(shadows=True)), if it is there and
     still describes the parameter's current value (same tensor version as when it was last derived); else None."""
     s = getattr(p, '_tamtr_bf16', None)
-    if s is not None and s._tamtr_version == p._version and s.device == p.device and s.shape == p.shape:
-        return s
+    if s is not None:
+        base = getattr(p, '_tamtr_alias_of', p)   # (graphs.GraphedPart records through aliases of the parameters: the version is the real one's)
+        if s._tamtr_version == base._version and s.device == p.device and s.shape == p.shape:
+            return s
     return None
 
 

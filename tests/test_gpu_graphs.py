@@ -218,6 +218,67 @@ def test_capture_after_eager_steps_then_train(pkg):
 
 
 
+def test_recorded_part_reads_the_optimizers_weight_copies_and_never_a_stale_one(pkg):
+    """With engine.FusedOptimStep(shadows=True) the recorded static part reads the bf16 copies of the weights that the update kernel keeps
+    (no cast kernels in the forward graph: fewer kernel nodes than a recording without copies).  A replay runs no Python inside, so
+    GraphedPart re-derives, BEFORE replaying, any copy whose master was written by something else: after an in-place change of two weights
+    behind the stepper's back - and after drop_shadows() - a replay still equals the eager forward on the current weights."""
+    from tamtr_amd.engine import FusedOptimStep, ModelEMA
+    torch.manual_seed(0)
+    model = pkg.model.RTDETRDetectionWorldModel(nc=10).cuda().train()
+    for m in model.modules():
+        if hasattr(m, 'drop_prob'):
+            m.drop_prob = 0.0
+    model.autocast_dtype = torch.bfloat16
+    B, S = 2, 256
+    batch = {k: (dev(v) if k in ('img', 'txt_feats') else v) for k, v in _bench_batch(B, S, 3).items()}
+    model.capture_static_part(batch['img'], batch['txt_feats'], verify='loose')
+    plain_nodes = model._static[0].census['forward']['kernel']
+    assert not model._static[0].shadow_pairs
+    model.release_static_part()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
+    st = FusedOptimStep.create(model, opt, ModelEMA(model), max_norm=0.1, shadows=True)
+    model.capture_static_part(batch['img'], batch['txt_feats'], verify='loose')
+    gp = model._static[0]
+    assert len(gp.shadow_pairs) == len(gp.params) and gp.census['forward']['kernel'] < plain_nodes, (len(gp.shadow_pairs), gp.census, plain_nodes)
+
+    img, txt, dp = batch['img'], batch['txt_feats'].float(), torch.ones(3, 2, B, device='cuda')
+
+    def memory(graphed):
+        sd = {k: v.clone() for k, v in model.state_dict().items() if 'running_' in k or 'num_batches' in k}   # (BatchNorm statistics stay put)
+        try:
+            if graphed:
+                return model._static[0](img, txt, dp).detach().float()
+            return model.token_memory(img, txt, autocast_cache=False, drop_scales=dp)[0].detach().float()
+        finally:
+            with torch.no_grad():
+                for k, v in model.state_dict().items():
+                    if k in sd:
+                        v.copy_(sd[k])
+
+    def close(a, b, what):
+        assert_close(a, b, 2e-2, 2e-2 * float(b.abs().max()), what)
+    for step in range(2):                                     # two optimizer steps: the kernel rewrites the copies the graph reads
+        opt.zero_grad(set_to_none=True)
+        loss, _ = model(batch)
+        loss.backward()
+        st.step()
+    close(memory(True), memory(False), 'replay vs eager after two steps')
+    names = dict(model.named_parameters())
+    w1, w2 = names['model.0.conv.weight'], next(p for n, p in names.items() if n.endswith('VSSBlocks.0.op.in_proj.weight') or n.endswith('in_proj.weight'))
+    with torch.no_grad():
+        w1.mul_(1.5); w2.mul_(0.5)                            # masters written behind the stepper's back
+    assert pkg.ops.bf16_shadow(w1) is None and pkg.ops.bf16_shadow(w2) is None
+    stale_mem = memory(True)                                  # __call__ re-derives the two stale copies first
+    assert pkg.ops.bf16_shadow(w1) is not None and torch.equal(pkg.ops.bf16_shadow(w1), w1.detach().bfloat16())
+    close(stale_mem, memory(False), 'replay vs eager after an in-place change of two masters')
+    st.drop_shadows()
+    with torch.no_grad():
+        w1.mul_(0.8)
+    close(memory(True), memory(False), 'replay vs eager after drop_shadows()')
+    model.release_static_part()
+
+
 def test_packet_capture_mode_whole_static_part_in_its_own_process():
     """The mode bench.py and tools/train.py run since round 4: the HIP runtime's AQL packet capture of graph nodes ON (its default), the
     whole static part (trunk + VSS blocks + input projection, 640 x 640, 16 images, bf16, shipped convolution tables) recorded and
