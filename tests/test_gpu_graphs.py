@@ -223,6 +223,7 @@ def test_recorded_part_reads_the_optimizers_weight_copies_and_never_a_stale_one(
     (no cast kernels in the forward graph: fewer kernel nodes than a recording without copies).  A replay runs no Python inside, so
     GraphedPart re-derives, BEFORE replaying, any copy whose master was written by something else: after an in-place change of two weights
     behind the stepper's back - and after drop_shadows() - a replay still equals the eager forward on the current weights."""
+    import tamtr_amd.ops as ops
     from tamtr_amd.engine import FusedOptimStep, ModelEMA
     torch.manual_seed(0)
     model = pkg.model.RTDETRDetectionWorldModel(nc=10).cuda().train()
@@ -248,6 +249,7 @@ def test_recorded_part_reads_the_optimizers_weight_copies_and_never_a_stale_one(
         sd = {k: v.clone() for k, v in model.state_dict().items() if 'running_' in k or 'num_batches' in k}   # (BatchNorm statistics stay put)
         try:
             if graphed:
+                model.zero_grad(set_to_none=True)              # (the last step's .grad tensors ARE the recorded backward's output buffers)
                 return model._static[0](img, txt, dp).detach().float()
             return model.token_memory(img, txt, autocast_cache=False, drop_scales=dp)[0].detach().float()
         finally:
@@ -257,7 +259,10 @@ def test_recorded_part_reads_the_optimizers_weight_copies_and_never_a_stale_one(
                         v.copy_(sd[k])
 
     def close(a, b, what):
-        assert_close(a, b, 2e-2, 2e-2 * float(b.abs().max()), what)
+        # (2 images at 256 px: MIOpen's heuristic solvers, bf16 - two eager passes differ; a replay has to be as close to eager as eager is to itself)
+        dist = lambda u, v: float((u - v).norm() / v.norm())   # noqa: E731
+        noise = dist(memory(False), b)
+        assert dist(a, b) <= 3 * noise + 1e-3, (what, dist(a, b), noise)
     for step in range(2):                                     # two optimizer steps: the kernel rewrites the copies the graph reads
         opt.zero_grad(set_to_none=True)
         loss, _ = model(batch)
@@ -268,9 +273,9 @@ def test_recorded_part_reads_the_optimizers_weight_copies_and_never_a_stale_one(
     w1, w2 = names['model.0.conv.weight'], next(p for n, p in names.items() if n.endswith('VSSBlocks.0.op.in_proj.weight') or n.endswith('in_proj.weight'))
     with torch.no_grad():
         w1.mul_(1.5); w2.mul_(0.5)                            # masters written behind the stepper's back
-    assert pkg.ops.bf16_shadow(w1) is None and pkg.ops.bf16_shadow(w2) is None
+    assert ops.bf16_shadow(w1) is None and ops.bf16_shadow(w2) is None
     stale_mem = memory(True)                                  # __call__ re-derives the two stale copies first
-    assert pkg.ops.bf16_shadow(w1) is not None and torch.equal(pkg.ops.bf16_shadow(w1), w1.detach().bfloat16())
+    assert ops.bf16_shadow(w1) is not None and torch.equal(ops.bf16_shadow(w1), w1.detach().bfloat16())
     close(stale_mem, memory(False), 'replay vs eager after an in-place change of two masters')
     st.drop_shadows()
     with torch.no_grad():
