@@ -298,6 +298,10 @@ def main():
     ap.add_argument('--imgsz', type=int, default=640)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--rccl-solo', action='store_true',
+                    help='--gpus 1 only: run the N > 1 form of the step (gradient buckets, all-reduces from the hooks, barriers, the all-rank agreement) '
+                         'on a ONE-rank RCCL process group - every collective goes through the real backend, nothing is exchanged.  A rehearsal of the '
+                         'data-parallel code path on a one-GPU box (two ranks cannot share a device under RCCL), not the N = 1 measurement')
     ap.add_argument('--static-part', default='graph', choices=['graph', 'eager'],
                     help='trunk + VSS blocks + input projection replayed as two HIP graphs (forward, backward) or launched kernel by kernel')
     ap.add_argument('--conv-tuning', default='shipped', choices=['shipped', 'search', 'off'],
@@ -324,10 +328,20 @@ def main():
     if plan is not None:     # `python bench.py --gpus N`: become the launcher of N ranks; nothing below runs in this process
         raise SystemExit(tdist.self_launch(plan))
     from tamtr_amd.model import RTDETRDetectionWorldModel
-    rank, local, world = tdist.init_from_env()
+    # stdout carries ONE line, the JSON.  Native libraries write there too - RCCL prints a five-line version banner to stdout when rank 0
+    # creates its communicator (seen on the one-rank rehearsal, profiles/r04_rccl_one_rank_rehearsal.txt) - so from here on file descriptor 1
+    # is stderr for everybody, and the line goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    solo = bool(args.rccl_solo)
+    if solo and args.gpus != 1:
+        raise SystemExit('--rccl-solo is the one-rank rehearsal: --gpus 1')
+    rank, local, world = tdist.init_from_env(backend='nccl' if solo else None, solo=solo)
+    grouped = world > 1 or solo     # a process group exists: the step runs its data-parallel form
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
-    backend = torch.distributed.get_backend() if world > 1 else None
+    backend = torch.distributed.get_backend() if grouped else None
     if world > 1 and backend != 'nccl' and os.environ.get('TAMTR_BENCH_ALLOW_GLOO') != '1':
         # (a gloo run on one shared GPU is a rehearsal of the code path, not a measurement: set TAMTR_BENCH_ALLOW_GLOO=1 to run it)
         raise SystemExit(f'--gpus {world} needs the RCCL process group (backend "nccl"), got "{backend}"')
@@ -350,9 +364,9 @@ def main():
     shadows = args.weight_shadows == 'on' and args.dtype == 'bf16'
     stepper = FusedOptimStep.create(model, opt, ema, max_norm=0.1, shadows=shadows) if args.optim_step == 'fused' else None
     reducer = None
-    if world > 1:
+    if grouped:
         reducer = tdist.GradReducer(model.named_parameters(), skip=lambda n: '.attn.' in n, late=lambda n: 'denoising_class_embed' in n,
-                                    grad_dtype=torch.bfloat16 if args.grad_dtype == 'bf16' else None)
+                                    grad_dtype=torch.bfloat16 if args.grad_dtype == 'bf16' else None, always_collective=solo)
     batch = synth_batch(args.batch, args.imgsz, 1 + rank, dev)
     timer = KernelTimer()
     timer.install()
@@ -375,7 +389,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if grouped:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -412,7 +426,7 @@ def main():
             model.release_static_part()
             static_part = f'eager (capture failed: {type(e).__name__}: {e})'[:200]
             note(static_part)
-        if world > 1:   # every rank runs the same form of the step (and the same checks with collectives in them afterwards): graphs only if ALL captured
+        if grouped:   # every rank runs the same form of the step (and the same checks with collectives in them afterwards): graphs only if ALL captured
             ok = torch.tensor([1 if static_part == 'hip-graph' else 0], device=dev, dtype=torch.int32)
             torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
             if int(ok) == 0 and static_part == 'hip-graph':
@@ -436,7 +450,7 @@ def main():
     host_ms = (time.process_time() - c0) / args.steps * 1e3   # CPU time of this rank's process (all threads) per step
     timer.enabled = False
     host_all = [host_ms]
-    if world > 1:
+    if grouped:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
@@ -468,7 +482,9 @@ def main():
                        'global_batch': world * args.batch, 'parallelism': f'dp{world}',
                        'reduced_precision': 'bf16 (BASELINE configs[4] names fp16: this build serves every reduced-precision configuration as bf16 - same MFMA rate on gfx950, fp32 exponent range, no loss scaler; DESIGN 7)', 'final_loss': float(loss.detach()),
                        'bf16_vs_fp32': mode_err, 'dist_backend': backend, 'dist_world_size': world,
-                       'grad_bucket_dtype': (args.grad_dtype if world > 1 else None), 'static_part': static_part,
+                       **({'rccl_solo_rehearsal': 'one-rank RCCL group: the data-parallel form of the step with every collective issued (%d gradient buckets per step), '
+                                                  'nothing exchanged - not the N = 1 measurement' % len(reducer.buckets)} if solo else {}),
+                       'grad_bucket_dtype': (args.grad_dtype if grouped else None), 'static_part': static_part,
                        'optim_step': 'fused (csrc/optim.hip)' if stepper is not None else 'torch', 'weight_shadows': bool(stepper is not None and stepper.use_shadows), 'static_part_check': _brief(getattr(model, 'static_part_check', None)), 'graph_vs_eager': gve, 'conv_tuning': conv_tuning,
                        'hbm_GiB_peak': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
             'roofline': None if ks is None else {
@@ -491,8 +507,8 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args.cpu_baseline_images, args.imgsz)
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out))
-    if world > 1:
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
+    if grouped:
         torch.distributed.destroy_process_group()
 
 

@@ -19,14 +19,20 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  Returns (rank, local_rank, world)."""
+def init_from_env(backend=None, solo=False):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  Returns (rank, local_rank, world).
+    solo: create the process group even for ONE rank (a one-rank RCCL communicator: every collective of the N > 1 path is
+    issued through the real backend - what a one-GPU box can show of it; two ranks cannot share a device under RCCL)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or solo) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29500')
+        if 'MASTER_PORT' not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(sk.getsockname()[1]) if world == 1 else '29500'
         if backend is None:
             backend = os.environ.get('TAMTR_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
@@ -80,12 +86,14 @@ class GradReducer:
     zero fill of every bucket - ~700 launches.)"""
 
     def __init__(self, named_params, bucket_bytes=32 << 20, op='sum', grad_dtype=None, skip=lambda name: False,
-                 late=lambda name: False):
+                 late=lambda name: False, always_collective=False):
         """grad_dtype: dtype of the buckets on the wire (torch.bfloat16 halves the 168.5 MB of fp32 gradients per step;
         the optimizer still sees fp32 gradients).  skip(name): parameters that never get a gradient.  late(name):
         parameters that may get none on some steps (`denoising_class_embed` when a rank's batch has no boxes) - they go
-        into the last bucket, so that a missing hook delays only that bucket's launch to finish()."""
+        into the last bucket, so that a missing hook delays only that bucket's launch to finish().  always_collective: issue the
+        all-reduces on a one-rank group too (the RCCL rehearsal on one GPU: same calls, same streams, nothing to exchange)."""
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.collective = self.world > 1 or (always_collective and dist.is_initialized())
         self.op = op
         self.buckets = []   # dicts: flat, params, views, pending, handle
         self._hooks = []
@@ -108,12 +116,19 @@ class GradReducer:
             dt = grad_dtype or g[0][1].dtype
             flat = torch.zeros(sum(p.numel() for _, p in g), device=g[0][1].device, dtype=dt)
             off = 0
-            bucket = {'flat': flat, 'params': g, 'pending': 0, 'handle': None, 'views': []}
+            bucket = {'flat': flat, 'params': g, 'pending': 0, 'handle': None, 'views': [], 'wide': None, 'wide_views': []}
+            if any(p.dtype != dt for _, p in g):
+                # a narrower wire dtype: the reduced bucket is widened back with ONE copy into a twin buffer of the parameters' dtype, whose
+                # slices become .grad (round 4: was one cast launch per parameter, ~600 per step, 0.8 ms on the one-rank RCCL rehearsal)
+                if len({p.dtype for _, p in g}) != 1:
+                    raise ValueError('a gradient bucket with a wire dtype needs parameters of one dtype')
+                bucket['wide'] = torch.zeros_like(flat, dtype=g[0][1].dtype)
             for _, p in g:
                 # same strides as the parameter (channels-last conv weights): the optimizer stays on its fast path
-                v = flat[off:off + p.numel()].view_as(p) if p.is_contiguous() else torch.as_strided(flat, p.shape, p.stride(), off)
+                for buf, key in ((flat, 'views'), (bucket['wide'], 'wide_views')):
+                    if buf is not None:
+                        bucket[key].append(buf[off:off + p.numel()].view_as(p) if p.is_contiguous() else torch.as_strided(buf, p.shape, p.stride(), off))
                 off += p.numel()
-                bucket['views'].append(v)
             self.buckets.append(bucket)
             for _, p in g:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bucket)))
@@ -147,7 +162,7 @@ class GradReducer:
         while self._next < len(self.buckets) and self.buckets[self._next]['pending'] == 0:
             b = self.buckets[self._next]
             self._gather(b)
-            if self.world > 1:
+            if self.collective:
                 b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
             self._next += 1
 
@@ -168,13 +183,14 @@ class GradReducer:
             b['pending'] = 0
         self._launch_ready()
         for b in self.buckets:
-            if self.world > 1:
+            if self.collective:
                 b['handle'].wait()
-                if self.op == 'mean':
+                if self.op == 'mean' and self.world > 1:
                     b['flat'].div_(self.world)
-            for (_, p), v in zip(b['params'], b['views']):
-                if v.dtype != p.dtype:
-                    p.grad = v.to(p.dtype)
+            if b['wide'] is not None:
+                b['wide'].copy_(b['flat'])
+                for (_, p), v in zip(b['params'], b['wide_views']):
+                    p.grad = v
 
     def remove(self):
         for h in self._hooks:

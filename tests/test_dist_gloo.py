@@ -237,6 +237,36 @@ def test_reducer_buckets_keep_channels_last_strides_single_process():
     red.remove()
 
 
+def test_one_rank_group_issues_every_collective_when_asked(monkeypatch):
+    """`always_collective` (bench.py --rccl-solo: the one-rank rehearsal on the real backend) - here on a one-rank gloo group: one
+    all-reduce per bucket, values untouched; without the flag a one-rank group issues none.  `init_from_env(solo=True)` makes the group."""
+    from tamtr_amd import dist as tdist
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        monkeypatch.delenv(k, raising=False)
+    assert tdist.init_from_env(backend='gloo', solo=True) == (0, 0, 1) and dist.is_initialized() and dist.get_world_size() == 1
+    try:
+        torch.manual_seed(0)
+        net = nn.Sequential(nn.Linear(8, 16), nn.ReLU(), nn.Linear(16, 4))
+        x = torch.randn(5, 8)
+        net(x).sum().backward()
+        want = [p.grad.clone() for p in net.parameters()]
+        calls = []
+        real = dist.all_reduce
+        monkeypatch.setattr(dist, 'all_reduce', lambda t, *a, **k: (calls.append(t.numel()), real(t, *a, **k))[1])
+        for flag in (False, True):
+            red = tdist.GradReducer(net.named_parameters(), bucket_bytes=128, always_collective=flag)
+            calls.clear()
+            red.prepare()
+            net(x).sum().backward()
+            red.finish()
+            assert len(calls) == (len(red.buckets) if flag else 0) and len(red.buckets) > 1
+            for p, w in zip(net.parameters(), want):
+                assert torch.equal(p.grad, w)
+            red.remove()
+    finally:
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------------------------------------ `--gpus N` starts its own ranks
 def test_launch_plan_decision_and_argv():
     """bench.py / tools/train.py started as plain `python script --gpus N` become the launcher of N ranks (reference:
