@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4, GPU call AU: final verification with immediate-mode tables: GPU suite, smoke, default bench (with CPU baseline), configs[4], deterministic, 2- and 4-rank rehearsals
 set -o pipefail
-O=gpurun_out/r4az; mkdir -p $O
+O=${O:-gpurun_out/r4az}; mkdir -p $O
 timeout -k 10 900 python3 -m pytest tests -q -m gpu > $O/gpu_tests.txt 2>&1; echo "gpu suite rc=$?" | tee -a $O/status.txt; tail -2 $O/gpu_tests.txt | cut -c1-200
 timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; echo "smoke rc=$?" | tee -a $O/status.txt
 timeout -k 10 600 python3 bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" | tee -a $O/status.txt; grep -E "timed|capture" $O/bench.err | cut -c1-200
