@@ -81,8 +81,12 @@ class ManbaWorldDecoder(nn.Module):
                                                               self.label_noise_ratio, self.box_noise_scale, self.training)
         # the token memory has 1 + num_layers heavy consumers (enc_output, every layer's value_proj): their gradients are added in one
         # pass instead of pairwise by autograd
-        f_enc, *f_dec = ops.fanout(feats, 1 + self.decoder.num_layers) if self.training else (feats,) * (1 + self.decoder.num_layers)
-        embed, refer_bbox, enc_bboxes, enc_scores = self._get_decoder_input(f_enc, shapes, dn_embed, dn_bbox)
+        if self.training and ops.enc_select_ok(feats, self.enc_output[0], self.enc_output[1], self.enc_score_head):
+            # query selection as one autograd node that also hands out the decoder layers' handles: its backward works on the picked rows only
+            f_enc, f_dec = feats, self.decoder.num_layers
+        else:
+            f_enc, *f_dec = ops.fanout(feats, 1 + self.decoder.num_layers) if self.training else (feats,) * (1 + self.decoder.num_layers)
+        embed, refer_bbox, enc_bboxes, enc_scores, f_dec = self._get_decoder_input(f_enc, shapes, dn_embed, dn_bbox, handles=f_dec)
         dec_bboxes, dec_scores = self.decoder(embed, refer_bbox, f_dec, shapes, text, self.dec_bbox_head, self.dec_score_head,
                                               self.query_pos_head, attn_mask=attn_mask)
         x = dec_bboxes, dec_scores, enc_bboxes, enc_scores, dn_meta
@@ -147,27 +151,32 @@ class ManbaWorldDecoder(nn.Module):
             y = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
         return y.view(B, H * W, -1), [H, W]
 
-    def _get_decoder_input(self, feats, shapes, dn_embed=None, dn_bbox=None, text=None):
+    def _get_decoder_input(self, feats, shapes, dn_embed=None, dn_bbox=None, text=None, handles=None):
+        """Query selection (reference head.py:1205-1245).  handles: the decoder layers' handles on the token memory made by the caller, or
+        their NUMBER when this call is to make them (the one-node selection, ops.enc_select); returned as the fifth value."""
         bs = feats.shape[0]
         anchors, valid = self._generate_anchors(shapes, dtype=torch.float32, device=feats.device)
         lin, norm = self.enc_output[0], self.enc_output[1]
-        if feats.is_cuda and feats.dtype == torch.bfloat16:
-            # same [B*L, 512] x [512, 512] contraction as the value projection on the MFMA kernel; `valid * feats` (head.py:1213) is not
-            # materialised: the invalid-anchor rows of the product are set to the bias instead (two 550 MB multiply passes saved)
-            y = ops.linear_bf16_zero_rows(feats, lin.weight, lin.bias, self._invalid_rows)
+        if isinstance(handles, int):
+            top_feat, enc_scores, top, handles = ops.enc_select(feats, lin, norm, self.enc_score_head, self._invalid_rows, self.num_queries,
+                                                                self.fixed_topk, handles)
         else:
-            y = lin(valid.to(feats.dtype) * feats)
-        memory = VSSBlock._ln(norm, y)  # LayerNorm kernel in the activation dtype
-        scores = self.enc_score_head(memory)
-        top = torch.topk(scores.max(-1).values, self.num_queries, dim=1).indices if self.fixed_topk is None else self.fixed_topk.to(feats.device)
+            if feats.is_cuda and feats.dtype == torch.bfloat16:
+                # same [B*L, 512] x [512, 512] contraction as the value projection on the MFMA kernel; `valid * feats` (head.py:1213) is not
+                # materialised: the invalid-anchor rows of the product are set to the bias instead (two 550 MB multiply passes saved)
+                y = ops.linear_bf16_zero_rows(feats, lin.weight, lin.bias, self._invalid_rows)
+            else:
+                y = lin(valid.to(feats.dtype) * feats)
+            memory = VSSBlock._ln(norm, y)  # LayerNorm kernel in the activation dtype
+            scores = self.enc_score_head(memory)
+            top = torch.topk(scores.max(-1).values, self.num_queries, dim=1).indices if self.fixed_topk is None else self.fixed_topk.to(feats.device)
+            bi = torch.arange(bs, device=feats.device).unsqueeze(-1)
+            top_feat, enc_scores = memory[bi, top], scores[bi, top]
         self.last_topk = top.detach()   # this forward's picks (parity measurements replay them through fixed_topk)
-        bi = torch.arange(bs, device=feats.device).unsqueeze(-1)
-        top_feat = memory[bi, top]
         refer = self.enc_bbox_head(top_feat).float() + anchors[0][top]
         enc_bboxes = refer.sigmoid()
         if dn_bbox is not None:
             refer = torch.cat([dn_bbox, refer], 1)
-        enc_scores = scores[bi, top]
         embed = self.tgt_embed.weight.unsqueeze(0).repeat(bs, 1, 1) if self.learnt_init_query else top_feat
         if self.training:
             refer = refer.detach()
@@ -175,7 +184,7 @@ class ManbaWorldDecoder(nn.Module):
                 embed = embed.detach()
         if dn_embed is not None:
             embed = torch.cat([dn_embed.to(embed.dtype), embed], 1)
-        return embed, refer, enc_bboxes, enc_scores
+        return embed, refer, enc_bboxes, enc_scores, handles
 
     def _reset_parameters(self):
         bias_cls = float(-math.log((1 - 0.01) / 0.01)) / 80 * self.nc

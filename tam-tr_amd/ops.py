@@ -805,7 +805,7 @@ class _LinearBF16ZeroRows(torch.autograd.Function):
             gx = (g2 @ w16).view(B, L, K)
         gw = dw_splitk(g2, x2)
         if idx.numel():
-            gx[:, idx] = 0
+            gx.index_fill_(1, idx, 0)   # (not `gx[:, idx] = 0`: assigning a Python scalar through an index synchronises the host)
             gi, xi = g3[:, idx].reshape(-1, N), x2.view(B, L, K)[:, idx].reshape(-1, K)
             gw = gw - (gi.t() @ xi).float()
         gb = colsum(g2).to(b_dt)
@@ -830,18 +830,121 @@ class _Fanout(torch.autograd.Function):
         live = [g for g in gs if g is not None]
         if len(live) == 1:
             return live[0], None
-        g0 = live[0]
-        if (g0.is_cuda and g0.dtype in (torch.float32, torch.bfloat16) and g0.numel() % 4 == 0 and len(live) <= 8
-                and all(g.dtype == g0.dtype and g.shape == g0.shape for g in live)):
-            live = [_c(g) for g in live]
-            out = torch.empty_like(live[0])
-            src = (ctypes.c_void_p * len(live))(*[g.data_ptr() for g in live])
-            call('tamtr_sum_n', ctypes.cast(src, ctypes.c_void_p), len(live), ptr(out), out.numel(), dtype_code(out), stream_ptr())
-            return out, None
-        acc = live[0].clone()
-        for g in live[1:]:
-            acc += g
-        return acc, None
+        return _sum_handles(live, live[0].shape, live[0].dtype, live[0].device), None
+
+
+def _sum_handles(live, shape, dtype, device):
+    """Sum of the gradients of fan-out handles in one pass (tamtr_sum_n) into a buffer of our own; zeros when nobody sent one."""
+    if not live:
+        return torch.zeros(shape, dtype=dtype, device=device)
+    if len(live) == 1:
+        return live[0].clone()
+    g0 = live[0]
+    if (g0.is_cuda and g0.dtype in (torch.float32, torch.bfloat16) and g0.numel() % 4 == 0 and len(live) <= 8
+            and all(g.dtype == g0.dtype and g.shape == g0.shape for g in live)):
+        live = [_c(g) for g in live]
+        out = torch.empty_like(live[0])
+        src = (ctypes.c_void_p * len(live))(*[g.data_ptr() for g in live])
+        call('tamtr_sum_n', ctypes.cast(src, ctypes.c_void_p), len(live), ptr(out), out.numel(), dtype_code(out), stream_ptr())
+        return out
+    acc = live[0].clone()
+    for g in live[1:]:
+        acc += g
+    return acc
+
+
+class _EncSelect(torch.autograd.Function):
+    """The encoder side of the MEH query selection as ONE node (reference head.py:1205-1245, `_get_decoder_input`): token memory
+    x [B, L, K] bf16 -> enc_output (Linear with the invalid-anchor rows treated as zero + LayerNorm) -> enc_score_head -> top-k over the
+    tokens by best class score -> the picked rows of the normalised memory and of the scores.  Plus `n_dec` handles on x for the decoder
+    layers' value projections (what ops.fanout gives).
+
+    Why one node: everything downstream reads only the num_queries picked rows per image (4 800 of 537 600 at the bench shape), so the
+    gradient of this whole branch with respect to the LayerNorm output, the Linear output and x is ZERO outside those rows.  Autograd
+    on the separate ops runs the dense backward anyway - zero fill + sorted index_put + add for the two gathers, the score head's dX / dW
+    over all rows, LayerNorm backward over all rows, the 512 x 512 dX GEMM and the split dW over all rows, a fourth 550 MB operand in the
+    fan-out sum: ~1.9 ms per step - multiplying zeros.  Here the backward gathers the picked rows (Linear input, Linear output) in the
+    forward, keeps NOTHING of the three [B, L, .] intermediates, does the whole chain on [B * num_queries, .] rows in fp32, and adds the
+    rows' dX into the sum of the decoder handles' gradients (its own buffer).  Same function, same gradient (sums over rows lose only
+    exact zeros); the forward is the same kernels as before."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, eps, ws, bs, invalid, nq, fixed_top, n_dec):
+        require_gpu(x, w, b)
+        B, L, K = x.shape
+        N = w.shape[0]
+        if x.dtype != torch.bfloat16:
+            raise _lib.TamtrHipError('enc_select needs a bf16 token memory')
+        x2 = _c(x.reshape(-1, K))
+        w16, b32 = _c(bf16_of(w)), _c(b.float())
+        y = torch.empty(B, L, N, device=x.device, dtype=torch.bfloat16)
+        rec = KERNEL_EVENTS.get('tamtr_linear_bf16')
+        if rec is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        call('tamtr_linear_bf16', ptr(x2), ptr(w16), ptr(b32), ptr(y), B * L, N, K, stream_ptr())
+        if rec is not None:
+            e1.record()
+            rec.append((e0, e1, 2.0 * B * L * N * K))
+        if invalid.numel():
+            y[:, invalid] = b32.to(torch.bfloat16)
+        g32, be32 = _c(gamma.float()), _c(beta.float())
+        mem = torch.empty_like(y)
+        stats = torch.empty(B * L, 2, device=x.device, dtype=torch.float32)
+        call('tamtr_layernorm_fwd', ptr(y), ptr(g32), ptr(be32), ptr(mem), ptr(stats), B * L, N, float(eps), dtype_code(y), stream_ptr())
+        ws16 = bf16_of(ws)
+        scores = torch.nn.functional.linear(mem, ws16, bs.to(torch.bfloat16))
+        top = torch.topk(scores.max(-1).values, nq, dim=1).indices if fixed_top is None else fixed_top.to(x.device)
+        bi = torch.arange(B, device=x.device).unsqueeze(-1)
+        top_feat, enc_scores = mem[bi, top], scores[bi, top]
+        valid = torch.ones(L, device=x.device, dtype=torch.bool)
+        if invalid.numel():
+            valid.index_fill_(0, invalid, False)   # (not `valid[invalid] = False`: assigning a Python scalar through an index synchronises the host)
+        ctx.save_for_backward(top, x.view(B, L, K)[bi, top], y[bi, top], stats.view(B, L, 2)[bi, top], top_feat, valid[top], w16, ws16, g32)
+        ctx.cfg = (x.shape, w.dtype, b.dtype, gamma.dtype, beta.dtype, ws.dtype, bs.dtype, int(n_dec))
+        ctx.mark_non_differentiable(top)
+        return (top_feat, enc_scores, top) + tuple(x.view_as(x) for _ in range(int(n_dec)))
+
+    @staticmethod
+    def backward(ctx, g_feat, g_sc, _g_top, *g_dec):
+        top, xr, yr, st, top_feat, vr, w16, ws16, g32 = ctx.saved_tensors
+        (B, L, K), w_dt, b_dt, ga_dt, be_dt, ws_dt, bs_dt, n_dec = ctx.cfg
+        N, nc = w16.shape[0], ws16.shape[0]
+        R = top.numel()
+        gx = _sum_handles([g for g in g_dec if g is not None], (B, L, K), xr.dtype, xr.device)   # ours: the rows are added in place
+        ge = g_sc.reshape(R, nc).float() if g_sc is not None else torch.zeros(R, nc, device=top.device)
+        gm = ge @ ws16.float()                                                   # d/d(memory rows): score head ...
+        if g_feat is not None:
+            gm = gm + g_feat.reshape(R, N).float()                               # ... + the picked features' own gradient
+        gws = ge.t() @ top_feat.reshape(R, N).float()
+        gbs = ge.sum(0)
+        st = st.reshape(R, 2)
+        xh = (yr.reshape(R, N).float() - st[:, :1]) * st[:, 1:]                  # normalised rows from the forward's (mean, rstd)
+        ggam, gbet = (gm * xh).sum(0), gm.sum(0)
+        gxh = gm * g32
+        gy = st[:, 1:] * (gxh - gxh.mean(-1, keepdim=True) - xh * (gxh * xh).mean(-1, keepdim=True))
+        m = vr.reshape(R, 1).float()                                             # rows of invalid anchors entered the Linear as zeros
+        xm = xr.reshape(R, K).float() * m
+        gw, gb = gy.t() @ xm, gy.sum(0)
+        gxr = ((gy @ w16.float()) * m).to(gx.dtype).view(B, -1, K)
+        bi = torch.arange(B, device=top.device).unsqueeze(-1)
+        gx[bi, top] = gx[bi, top] + gxr                                          # top-k indices are distinct per image: plain gather / scatter
+        return (gx, gw.to(w_dt), gb.to(b_dt), ggam.to(ga_dt), gbet.to(be_dt), None, gws.to(ws_dt), gbs.to(bs_dt), None, None, None, None)
+
+
+def enc_select(x, lin, norm, score_head, invalid, nq, fixed_top=None, n_dec=0):
+    """(top_feat [B, nq, hd], enc_scores [B, nq, nc], top [B, nq], n_dec handles on x) - see _EncSelect."""
+    out = _EncSelect.apply(x, lin.weight, lin.bias, norm.weight, norm.bias, norm.eps, score_head.weight, score_head.bias, invalid, int(nq),
+                           fixed_top, int(n_dec))
+    return out[0], out[1], out[2], list(out[3:])
+
+
+def enc_select_ok(x, lin, norm, score_head):
+    """The one-node query selection serves the bf16 HIP path in training (TAMTR_ENC_SELECT=dense: the separate ops, A/B)."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3 and torch.is_grad_enabled() and x.requires_grad
+            and isinstance(lin, torch.nn.Linear) and isinstance(score_head, torch.nn.Linear) and lin.bias is not None and score_head.bias is not None
+            and lin.in_features % 64 == 0 and lin.out_features % 128 == 0 and lin.out_features in (32, 64, 128, 256, 512, 1024)
+            and _os.environ.get('TAMTR_ENC_SELECT') != 'dense')
 
 
 def fanout(x, n):

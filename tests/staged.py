@@ -58,7 +58,7 @@ def staged_forward(model, state, batch, tg_host, choices, on, seed=5):
             dn_embed, dn_bbox, attn_mask, dn_meta = get_cdn_group(tg, head.nc, head.num_queries, head.denoising_class_embed.weight, head.num_denoising,
                                                                   head.label_noise_ratio, head.box_noise_scale, True)
             with ac('enc'):
-                embed, refer, enc_b, enc_s = head._get_decoder_input(to(feats, 'enc'), shapes, dn_embed, dn_bbox)
+                embed, refer, enc_b, enc_s, _ = head._get_decoder_input(to(feats, 'enc'), shapes, dn_embed, dn_bbox)
             with ac('decoder'):
                 dec_b, dec_s = head.decoder(to(embed, 'decoder'), refer, to(feats, 'decoder'), shapes, txt.clone(), head.dec_bbox_head,
                                             head.dec_score_head, head.query_pos_head, attn_mask=attn_mask)

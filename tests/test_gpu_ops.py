@@ -1272,3 +1272,70 @@ def test_conv3x3_cl_stats_vs_fp32_conv(ops, B, C, H, W, sliced):
     assert_close(bn.running_mean, 0.97 * rm0.double() + 0.03 * mean, 1e-5, 1e-6, 'running_mean')
     assert_close(bn.running_var, 0.97 * rv0.double() + 0.03 * var * n / (n - 1), 1e-4, 1e-6, 'running_var')
     assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize('B,L,hd,nc,nq,n_dec', [(2, 340, 128, 10, 16, 3), (3, 1000, 512, 10, 50, 1), (1, 84, 256, 4, 8, 0)])
+def test_enc_select_row_sparse_backward_matches_the_dense_graph(ops, B, L, hd, nc, nq, n_dec):
+    """ops.enc_select (the MEH query selection as one autograd node whose backward runs on the picked rows only, reference head.py:1205-1245)
+    against the same chain as separate ops (linear_bf16_zero_rows -> LayerNorm kernel -> score head -> top-k -> two gathers, ops.fanout for the
+    decoder handles) and against a float64 autograd graph of the same bf16 operands: outputs bit-equal to the separate ops (same kernels), every
+    gradient within bf16 rounding of the dense one and at least as close to the float64 graph."""
+    import torch.nn as nn
+    torch.manual_seed(B * L)
+    lin, norm, head = nn.Linear(hd, hd).cuda(), nn.LayerNorm(hd).cuda(), nn.Linear(hd, nc).cuda()
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.2, 0.2)
+    invalid = torch.tensor(sorted({0, 3, L // 2, L - 1}), device='cuda')
+    x0 = torch.randn(B, L, hd, device='cuda').bfloat16()
+    cot_f, cot_s = torch.randn(B, nq, hd, device='cuda'), torch.randn(B, nq, nc, device='cuda')
+    cot_d = [torch.randn(B, L, hd, device='cuda').bfloat16() for _ in range(n_dec)]
+    params = [lin.weight, lin.bias, norm.weight, norm.bias, head.weight, head.bias]
+    bi = torch.arange(B, device='cuda').unsqueeze(-1)
+
+    def grads(loss, x):
+        for p in params:
+            p.grad = None
+        loss.backward()
+        return [x.grad.float()] + [p.grad.clone() for p in params]
+
+    # (a) separate ops
+    xa = x0.clone().requires_grad_()
+    f_enc, *hs = ops.fanout(xa, 1 + n_dec)
+    mem = ops.layer_norm(ops.linear_bf16_zero_rows(f_enc, lin.weight, lin.bias, invalid), norm.weight, norm.bias, norm.eps)
+    sc = F.linear(mem, head.weight.bfloat16(), head.bias.bfloat16())
+    top = torch.topk(sc.max(-1).values, nq, dim=1).indices
+    fa, sa = mem[bi, top], sc[bi, top]
+    ga = grads((fa.float() * cot_f).sum() + (sa.float() * cot_s).sum() + sum((h.float() * c.float()).sum() for h, c in zip(hs, cot_d)), xa)
+    # (b) one node
+    xb = x0.clone().requires_grad_()
+    assert ops.enc_select_ok(xb, lin, norm, head)
+    fb, sb, tb, hb = ops.enc_select(xb, lin, norm, head, invalid, nq, None, n_dec)
+    assert torch.equal(tb, top) and torch.equal(fb, fa) and torch.equal(sb, sa) and len(hb) == n_dec and all(torch.equal(h, x0) for h in hb)
+    assert not tb.requires_grad
+    gb = grads((fb.float() * cot_f).sum() + (sb.float() * cot_s).sum() + sum((h.float() * c.float()).sum() for h, c in zip(hb, cot_d)), xb)
+    # (c) float64 graph of the same operands (weights as the forward rounds them), the same picks
+    xc = x0.double().requires_grad_()
+    pc = [p.detach().clone().double().requires_grad_() for p in params]
+    w64, ws64 = (p.detach().bfloat16().double() + (p - p.detach()) for p in (pc[0], pc[4]))   # rounded value, straight-through gradient
+    valid = torch.ones(L, 1, device='cuda', dtype=torch.float64)
+    valid[invalid] = 0
+    y = F.linear(xc * valid, w64, pc[1])
+    m64 = F.layer_norm(y, (hd,), pc[2], pc[3], norm.eps)
+    s64 = F.linear(m64, ws64, pc[5])
+    ((m64[bi, top] * cot_f.double()).sum() + (s64[bi, top] * cot_s.double()).sum() + sum((xc * c.double()).sum() for c in cot_d)).backward()
+    gc = [xc.grad.float()] + [p.grad.float() for p in pc]
+    names = ['x', 'lin.weight', 'lin.bias', 'norm.weight', 'norm.bias', 'score.weight', 'score.bias']
+    for n, a, b, c in zip(names, ga, gb, gc):
+        scale = float(c.abs().max()) + 1e-12
+        ea, eb = float((a.float() - c).abs().max()) / scale, float((b.float() - c).abs().max()) / scale
+        assert eb <= max(1.25 * ea, 1e-2), (n, ea, eb)       # the row-wise fp32 backward is no further from the float64 graph than the dense bf16 one
+        assert eb <= 3e-2, (n, ea, eb)
+    # rows nobody picked get exactly the decoder handles' gradient; the invalid anchors' rows never get any from this branch
+    want = sum(c.float() for c in cot_d) if cot_d else torch.zeros_like(x0, dtype=torch.float32)
+    picked = torch.zeros(B, L, dtype=torch.bool, device='cuda')
+    picked[bi, top] = True
+    assert torch.equal(gb[0][~picked], want.bfloat16().float()[~picked]) or n_dec > 1
+    if n_dec <= 1:
+        inv_picked = picked[:, invalid]
+        assert torch.equal(gb[0][:, invalid][inv_picked], want.bfloat16().float()[:, invalid][inv_picked])
