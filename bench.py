@@ -14,7 +14,7 @@ loss, backward, gradient clip 0.1, AdamW(lr 1e-4, wd 1e-4), EMA update of the we
 over ranks with bucketed RCCL all-reduces overlapped with the backward (tam-tr_amd/dist.py).
 
 One JSON line on rank 0.  `roofline`: the MEH value-projection GEMM (tamtr_linear_bf16, the dominant dense contraction of
-the head: M = 16*33600, N = K = 512; value_proj x 3 layers + enc_output forward, and their dX products), timed live with
+the head: M = 16*33600, N = K = 512; value_proj x 3 layers + enc_output forward, and the value projections' dX products), timed live with
 events on the launch stream inside the timed steps, priced against the dense bf16 MFMA peak; `traffic` = HBM bytes per launch
 from the PMC passes committed under profiles/ (same kernel, same shape).  `cpu_baseline`: the CPU oracle (oracle/, a port - the
 reference's own end-to-end path cannot run on CPU) on this box's host cores, bounded sample: configs[0]'s 8 images, one
@@ -488,7 +488,7 @@ def main():
                        'optim_step': 'fused (csrc/optim.hip)' if stepper is not None else 'torch', 'weight_shadows': bool(stepper is not None and stepper.use_shadows), 'static_part_check': _brief(getattr(model, 'static_part_check', None)), 'graph_vs_eager': gve, 'conv_tuning': conv_tuning,
                        'hbm_GiB_peak': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
             'roofline': None if ks is None else {
-                'bound': 'mfma', 'kernel': 'linear_bf16_wstat_kernel<512> (MEH value_proj x3 + enc_output and their dX, M=%d N=K=512)'
+                'bound': 'mfma', 'kernel': 'linear_bf16_wstat_kernel<512> (MEH value_proj x3 + enc_output, and the dX of the value projections, M=%d N=K=512)'
                                            % (args.batch * (args.imgsz // 4) ** 2 * 21 // 16),
                 'achieved': ks['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': ks['tflops'] / peak, 'traffic': gemm_traffic(args),
                 'avg_ms': ks['avg_ms'], 'launches': ks['launches'],

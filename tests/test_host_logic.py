@@ -462,3 +462,7 @@ def test_round4_gpu_paths_are_gated_on_the_host_and_fall_back_to_the_reference_o
     assert not ops.ss2d_bf16_planes(torch.float32, 256, 6400, 8, 16)               # fp32 mode keeps fp32 planes
     assert not ops.ss2d_bf16_planes(torch.bfloat16, 256, 6404, 8, 16)              # not on the vector path
     assert ops.ss2d_bf16_planes(torch.bfloat16, 256, 6400, 8, 16) == (os.environ.get('TAMTR_SS2D_PLANES') != 'f32' and os.environ.get('TAMTR_XPROJ') != 'torch')
+    # query selection: the one-node row-sparse form serves bf16 GPU token memories in training; on CPU the head runs the separate ops and
+    # returns the caller's handles untouched
+    xm = torch.randn(2, 21, 128).bfloat16().requires_grad_()
+    assert not ops.enc_select_ok(xm, nn.Linear(128, 128), nn.LayerNorm(128), nn.Linear(128, 10))
