@@ -947,6 +947,32 @@ def enc_select_ok(x, lin, norm, score_head):
             and _os.environ.get('TAMTR_ENC_SELECT') != 'dense')
 
 
+class _EmbedRows(torch.autograd.Function):
+    """weight[idx] for a SMALL table and MANY lookups (the denoising queries' class embeddings, reference models/utils/ops.py:215-216:
+    3 072 lookups into 11 rows at the bench shape).  torch's backward of that index is its sorted `index_put` accumulate, which walks the
+    duplicates of a row one after the other: 293 us for a [11, 256] gradient.  Here: dW = onehot(idx)^T @ g, one tiny GEMM, fixed order."""
+
+    @staticmethod
+    def forward(ctx, weight, idx):
+        ctx.save_for_backward(idx)
+        ctx.rows = weight.shape[0]
+        return weight.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        onehot = (idx.view(1, -1) == torch.arange(ctx.rows, device=idx.device).view(-1, 1)).to(torch.float32)   # [rows, n]
+        return (onehot @ g.reshape(idx.numel(), -1).float()).to(g.dtype).view(ctx.rows, *g.shape[1:]), None
+
+
+def embed_rows(weight, idx):
+    """weight[idx] (idx 1-D int64); on the GPU with a gradient the one-hot product backward of _EmbedRows (TAMTR_EMBED_ROWS=torch: plain index)."""
+    if (weight.is_cuda and idx.dim() == 1 and weight.dim() == 2 and weight.shape[0] <= 4096 and weight.requires_grad and torch.is_grad_enabled()
+            and _os.environ.get('TAMTR_EMBED_ROWS') != 'torch'):
+        return _EmbedRows.apply(weight, idx)
+    return weight[idx]
+
+
 def fanout(x, n):
     """x -> n tensors with x's values (views), whose gradients are summed in one kernel; for tensors that feed several heavy consumers."""
     if n <= 1 or not (x.requires_grad and torch.is_grad_enabled()):

@@ -1339,3 +1339,25 @@ def test_enc_select_row_sparse_backward_matches_the_dense_graph(ops, B, L, hd, n
     if n_dec <= 1:
         inv_picked = picked[:, invalid]
         assert torch.equal(gb[0][:, invalid][inv_picked], want.bfloat16().float()[:, invalid][inv_picked])
+
+
+@pytest.mark.parametrize('rows,D,n', [(11, 256, 3072), (81, 512, 500), (2, 8, 1)])
+def test_embed_rows_backward_is_the_index_backward(ops, rows, D, n):
+    """ops.embed_rows (the denoising queries' class-embedding lookup, reference models/utils/ops.py:215-216): weight[idx] with the weight gradient as
+    onehot^T @ g instead of torch's sorted index_put over thousands of duplicates - same values as the plain index, same gradient, same bits twice."""
+    torch.manual_seed(rows + n)
+    w0 = torch.randn(rows, D, device='cuda')
+    idx = torch.randint(0, rows, (n,), device='cuda')
+    cot = torch.randn(n, D, device='cuda')
+    wa = w0.clone().requires_grad_()
+    (wa[idx] * cot).sum().backward()
+    grads = []
+    for _ in range(2):
+        wb = w0.clone().requires_grad_()
+        out = ops.embed_rows(wb, idx)
+        assert torch.equal(out, w0[idx])
+        (out * cot).sum().backward()
+        grads.append(wb.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    assert_close(grads[0], wa.grad, 1e-5, 1e-5 * float(wa.grad.abs().max()) + 1e-6, 'embed_rows grad')
+    assert ops.embed_rows(w0, idx).grad_fn is None and torch.equal(ops.embed_rows(w0, idx), w0[idx])      # no gradient wanted: the plain index
