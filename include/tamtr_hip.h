@@ -120,10 +120,14 @@ int tamtr_msdeform_attn_bwd(const void* gout, const void* value, const int32_t* 
  *      grid_sample backward is the atomic scatter this replaces).  Per (image, head, level) the Q*P*4 bilinear corners are sorted
  *      by destination row in LDS and every row sums its run.  gvalue rows have pitch ldg elements (M*D for a plain [B,L,M,D]
  *      tensor).  Limits: Q*P*4 <= 8192, D % 8 == 0, D <= 256, H*W < 2^19 - 1 per level; TAMTR_EUNSUP otherwise.
+ *      colw f32 [B, Q, M] or NULL (ABI 34): per (image, query, head) the total weight it put ON the map - the sum over levels, points
+ *      and the corners that lie on the map of aw * bilinear weight (1 when no corner falls off).  The column sums of gvalue over
+ *      its B*L rows are then sum_{b,q} gout[b,q,m,:] * colw[b,q,m]: the bias gradient of the linear layer that produced `value`
+ *      (MSDeformAttn.value_proj, nn/modules/transformer.py:273-275) from Q-sized operands, without a pass over the 550 MB gvalue.
  */
 int tamtr_msdeform_attn_bwd_sorted(const void* gout, const void* value, const int32_t* shapes_host, const float* loc,
-                                   const float* aw, void* gvalue, float* gloc, float* gaw, int B, int L, int M, int D, int Q,
-                                   int nl, int P, long long ldg, int dtype, void* stream);
+                                   const float* aw, void* gvalue, float* gloc, float* gaw, float* colw, int B, int L, int M,
+                                   int D, int Q, int nl, int P, long long ldg, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * a-8  Text-contrastive logits.  Replaces ContrastiveHeadMLP.forward, ultralytics/nn/modules/block.py:534-541:

@@ -10,7 +10,7 @@ from ctypes import c_float, c_int, c_longlong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TAMTR_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libtamtr_hip.so')  # env override: kernel A/B experiments
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 F32, BF16 = 0, 1
 _ERR = {-1: 'TAMTR_EINVAL (bad argument)', -2: 'TAMTR_EUNSUP (shape/dtype outside what the kernels are built for)',
@@ -28,7 +28,7 @@ _SIGS = {
     'tamtr_maxsigmoid_gate_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     'tamtr_msdeform_attn_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'tamtr_msdeform_attn_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    'tamtr_msdeform_attn_bwd_sorted': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _LL, _I, _P],
+    'tamtr_msdeform_attn_bwd_sorted': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _LL, _I, _P],
     'tamtr_contrastive_logits_fwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'tamtr_contrastive_logits_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'tamtr_contrastive_bwd_slabs': [_I],

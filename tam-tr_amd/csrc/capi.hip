@@ -2,7 +2,7 @@
 #include "common.h"
 #include <stdlib.h>
 
-extern "C" int tamtr_abi_version(void) { return 33; }
+extern "C" int tamtr_abi_version(void) { return 34; }
 
 
 // Node census of the graph a stream is currently capturing into: counts[t] = number of nodes of hipGraphNodeType t (t < n_types <= 16).

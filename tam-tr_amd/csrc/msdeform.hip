@@ -168,7 +168,8 @@ __global__ __launch_bounds__(MSDA_THREADS) void msda_bwd_kernel(const ET* __rest
 template <typename ET, int VEC, int LPG>
 __global__ __launch_bounds__(MSDA_THREADS) void msda_bwd_locaw_kernel(const ET* __restrict__ gout, const ET* __restrict__ value,
                                                                        const float* __restrict__ loc, const float* __restrict__ aw,
-                                                                       float* __restrict__ gloc, float* __restrict__ gaw, Levels lv,
+                                                                       float* __restrict__ gloc, float* __restrict__ gaw,
+                                                                       float* __restrict__ colw, Levels lv,
                                                                        int n_items, int L, int M, int D, int Q, int nl, int P) {
   const int gid = (blockIdx.x * MSDA_THREADS + threadIdx.x) / LPG;
   const int gl = threadIdx.x % LPG;
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(MSDA_THREADS) void msda_bwd_locaw_kernel(const ET* 
   VecLd<ET, VEC>::ld(gout + (size_t)gid * D + (act ? d0 : 0), g);
 #pragma unroll
   for (int i = 0; i < VEC; ++i) g[i] = act ? g[i] : 0.f;
+  float cw = 0.f;   // the item's total weight on the map: sum over (level, point, corner on the map) of a * bilinear weight
   for (int l = 0; l < nl; ++l) {
     const int H = lv.H[l], W = lv.W[l];
     const ET* vl = vb + (size_t)lv.start[l] * tok;
@@ -212,6 +214,8 @@ __global__ __launch_bounds__(MSDA_THREADS) void msda_bwd_locaw_kernel(const ET* 
         for (int i = 0; i < VEC; ++i) d = fmaf(g[i], vv[c][i], d);
         dc[c] = okc[c] ? d : 0.f;
       }
+      cw = fmaf(a, (okc[0] ? (1.f - fx) * (1.f - fy) : 0.f) + (okc[1] ? fx * (1.f - fy) : 0.f) + (okc[2] ? (1.f - fx) * fy : 0.f) +
+                       (okc[3] ? fx * fy : 0.f), cw);
       // v(x,y) = (1-fy)((1-fx) v00 + fx v01) + fy((1-fx) v10 + fx v11);  dc = <gout, {v00, v01, v10, v11}>
       float s_aw = (1.f - fy) * ((1.f - fx) * dc[0] + fx * dc[1]) + fy * ((1.f - fx) * dc[2] + fx * dc[3]);
       float s_x = (1.f - fy) * (dc[1] - dc[0]) + fy * (dc[3] - dc[2]);
@@ -225,6 +229,7 @@ __global__ __launch_bounds__(MSDA_THREADS) void msda_bwd_locaw_kernel(const ET* 
       }
     }
   }
+  if (colw && gl == 0) colw[gid] = cw;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -529,8 +534,8 @@ extern "C" int tamtr_msdeform_attn_bwd(const void* gout, const void* value, cons
 // value's dtype (no zero fill by the caller, no float atomics, bitwise reproducible).  ldg: token pitch of gvalue in elements
 // (M*D when it is its own [B,L,M,D] tensor; larger when it is a column block of a wider [B*L, ldg] matrix).
 extern "C" int tamtr_msdeform_attn_bwd_sorted(const void* gout, const void* value, const int32_t* shapes_host, const float* loc,
-                                              const float* aw, void* gvalue, float* gloc, float* gaw, int B, int L, int M, int D, int Q,
-                                              int nl, int P, long long ldg, int dtype, void* stream) {
+                                              const float* aw, void* gvalue, float* gloc, float* gaw, float* colw, int B, int L, int M,
+                                              int D, int Q, int nl, int P, long long ldg, int dtype, void* stream) {
   if (!gout || !value || !shapes_host || !loc || !aw || !gvalue || !gloc || !gaw || B <= 0 || L <= 0 || M <= 0 || D <= 0 ||
       Q <= 0 || P <= 0 || ldg < (long long)M * D)
     return TAMTR_EINVAL;
@@ -556,7 +561,7 @@ extern "C" int tamtr_msdeform_attn_bwd_sorted(const void* gout, const void* valu
     const int per_blk = MSDA_THREADS / LPG;                                                                               \
     dim3 g1((unsigned)((n_items + per_blk - 1) / per_blk));                                                               \
     hipLaunchKernelGGL((msda_bwd_locaw_kernel<ET, VEC, LPG>), g1, dim3(MSDA_THREADS), 0, s, (const ET*)gout, (const ET*)value, loc, aw, \
-                       gloc, gaw, lv, (int)n_items, L, M, D, Q, nl, P);                                                   \
+                       gloc, gaw, colw, lv, (int)n_items, L, M, D, Q, nl, P);                                             \
   }
     if (dtype == TAMTR_F32) {
       const int lanes = D / 4;

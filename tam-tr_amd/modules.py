@@ -157,7 +157,10 @@ class MSDeformAttn(nn.Module):
         bs, len_q = query.shape[:2]
         len_v = value.shape[1]
         assert sum(s[0] * s[1] for s in value_shapes) == len_v
-        if value_mask is not None:
+        paired = value_mask is None and ops.value_proj_msda_ok(value, self.value_proj, self.n_heads, len_q, self.n_points)
+        if paired:
+            v = None   # projected inside the paired node (ops.value_proj_msda)
+        elif value_mask is not None:
             v = F.linear(value, self.value_proj.weight, self.value_proj.bias).masked_fill(value_mask[..., None], 0.0)
             v = v.view(bs, len_v, self.n_heads, -1)
         else:
@@ -179,7 +182,7 @@ class MSDeformAttn(nn.Module):
             loc = torch.addcmul(ref[:, :, None, :, None, :2], off, ref[:, :, None, :, None, 2:] * (0.5 / self.n_points))
         else:
             raise ValueError(f'Last dim of reference_points must be 2 or 4, but got {n}.')
-        out = ops.ms_deform_attn_core(v, value_shapes, loc, aw)
+        out = ops.value_proj_msda(value, self.value_proj, self.n_heads, value_shapes, loc, aw) if paired else ops.ms_deform_attn_core(v, value_shapes, loc, aw)
         return ops.linear(out.to(query.dtype), self.output_proj)
 
 

@@ -419,7 +419,7 @@ class _MSDeformCore(torch.autograd.Function):
             # no 1.1 GB fp32 zero fill, no float atomics, no cast pass, and the same bits on every run
             gvalue = torch.empty(B, L, M, D, device=value.device, dtype=value.dtype)
             call('tamtr_msdeform_attn_bwd_sorted', ptr(gout), ptr(value), ctypes.cast(sh, ctypes.c_void_p), ptr(loc32), ptr(aw32),
-                 ptr(gvalue), ptr(gloc), ptr(gaw), B, L, M, D, Q, nl, P, M * D, dtype_code(value), stream_ptr())
+                 ptr(gvalue), ptr(gloc), ptr(gaw), None, B, L, M, D, Q, nl, P, M * D, dtype_code(value), stream_ptr())
             return gvalue, None, gloc.to(loc_dt), gaw.to(aw_dt)
         _atomic_fallback(f'the deformable-attention backward has no atomics-free kernel for Q*P*4 = {Q * P * 4} > 8192 corners per level '
                          f'or D = {D} (csrc/msdeform.hip)')
@@ -432,6 +432,77 @@ class _MSDeformCore(torch.autograd.Function):
 def ms_deform_attn_core(value, shapes, loc, aw):
     """value [B,L,M,D]; shapes [[H,W]]*nl; loc [B,Q,M,nl,P,2]; aw [B,Q,M,nl,P] -> [B,Q,M*D] (nn/modules/utils.py:42-89)."""
     return _MSDeformCore.apply(value, [tuple(int(v) for v in s) for s in shapes], loc, aw)
+
+
+class _ValueProjMSDA(torch.autograd.Function):
+    """MSDeformAttn's value projection and its sampling core as ONE node (reference nn/modules/transformer.py:273-311,
+    nn/modules/utils.py:42-89): out = msda(x W^T + b, loc, aw).  Same kernels as linear_bf16 + ms_deform_attn_core in both directions;
+    what the pairing buys is the BIAS gradient: db = column sums of d(value) over its B*L rows = sum_{b,q} gout[b,q,m,:] * colw[b,q,m],
+    where colw is the weight an item put on the map (1 unless a corner falls off) - the backward kernel that computes d/d(loc), d/d(aw)
+    emits it on the side, so the 550 MB pass over d(value) that colsum() made per decoder layer (111 us each) is a product of
+    [B*Q, M, D] operands."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, shapes, loc, aw, M):
+        require_gpu(x, weight, bias, loc, aw)
+        B, L, K = x.shape
+        N = weight.shape[0]
+        D = N // M
+        _, Q, _, nl, P, _ = loc.shape
+        x2 = _c(x.reshape(-1, K))
+        w16, b32 = _c(bf16_of(weight)), _c(bias.float())
+        value = torch.empty(B, L, M, D, device=x.device, dtype=torch.bfloat16)
+        rec = KERNEL_EVENTS.get('tamtr_linear_bf16')
+        if rec is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        call('tamtr_linear_bf16', ptr(x2), ptr(w16), ptr(b32), ptr(value), B * L, N, K, stream_ptr())
+        if rec is not None:
+            e1.record()
+            rec.append((e0, e1, 2.0 * B * L * N * K))
+        loc32, aw32 = _c(loc.float()), _c(aw.float())
+        sh = (ctypes.c_int32 * (2 * nl))(*[int(v) for hw in shapes for v in hw])
+        out = torch.empty(B, Q, N, device=x.device, dtype=torch.bfloat16)
+        call('tamtr_msdeform_attn_fwd', ptr(value), ctypes.cast(sh, ctypes.c_void_p), ptr(loc32), ptr(aw32), ptr(out), B, L, M, D,
+             Q, nl, P, dtype_code(value), stream_ptr())
+        ctx.save_for_backward(x2, w16, value, loc32, aw32)
+        ctx.cfg = (x.shape, sh, nl, P, M, weight.dtype, bias.dtype, loc.dtype, aw.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x2, w16, value, loc32, aw32 = ctx.saved_tensors
+        (B, L, K), sh, nl, P, M, w_dt, b_dt, loc_dt, aw_dt = ctx.cfg
+        N = w16.shape[0]
+        D = N // M
+        Q = loc32.shape[1]
+        gout = _c(gout.to(torch.bfloat16))
+        gloc, gaw = torch.empty_like(loc32), torch.empty_like(aw32)
+        colw = torch.empty(B, Q, M, device=gout.device, dtype=torch.float32)
+        gvalue = torch.empty(B * L, N, device=gout.device, dtype=torch.bfloat16)
+        call('tamtr_msdeform_attn_bwd_sorted', ptr(gout), ptr(value), ctypes.cast(sh, ctypes.c_void_p), ptr(loc32), ptr(aw32),
+             ptr(gvalue), ptr(gloc), ptr(gaw), ptr(colw), B, L, M, D, Q, nl, P, N, dtype_code(value), stream_ptr())
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(B * L, K, device=gout.device, dtype=torch.bfloat16)
+            call('tamtr_linear_bf16', ptr(gvalue), ptr(_c(w16.t())), None, ptr(gx), B * L, K, N, stream_ptr())
+            gx = gx.view(B, L, K)
+        gw = dw_splitk(gvalue, x2).to(w_dt) if ctx.needs_input_grad[1] else None
+        gb = (gout.view(B * Q, M, D).float() * colw.view(B * Q, M, 1)).sum(0).view(N).to(b_dt) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None, gloc.to(loc_dt), gaw.to(aw_dt), None
+
+
+def value_proj_msda_ok(x, lin, n_heads, Q, P):
+    """The paired node serves the bf16 token memory on the W-stationary GEMM's shapes with the sorted (atomics-free) backward
+    (TAMTR_VALUE_BIAS=colsum: linear_bf16 + ms_deform_attn_core as separate nodes, the bias gradient as a pass over d(value))."""
+    K, N = lin.in_features, lin.out_features
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3 and lin.bias is not None and N % n_heads == 0 and K % 128 == 0 and N % 64 == 0
+            and K % 64 == 0 and N % 128 == 0 and msda_sorted_ok(Q, P, N // n_heads) and not _MSDA_ATOMICS and _os.environ.get('TAMTR_VALUE_BIAS') != 'colsum')
+
+
+def value_proj_msda(x, lin, n_heads, shapes, loc, aw):
+    """msda(value_proj(x), loc, aw): x [B, L, K] bf16 -> [B, Q, N] bf16; see _ValueProjMSDA."""
+    return _ValueProjMSDA.apply(x, lin.weight, lin.bias, [tuple(int(v) for v in s) for s in shapes], loc, aw, int(n_heads))
 
 
 # ------------------------------------------------------------------------------------------------ a-8 contrastive head

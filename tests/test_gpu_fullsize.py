@@ -400,7 +400,7 @@ def test_msdeform_backward_is_bit_reproducible_and_matches_the_atomic_kernel(pkg
 
     def sorted_bwd():
         gv, gl, ga = torch.empty_like(value), torch.empty_like(loc), torch.empty_like(aw)
-        _lib.call('tamtr_msdeform_attn_bwd_sorted', P(gout), P(value), ctypes.cast(sh, ctypes.c_void_p), P(loc), P(aw), P(gv), P(gl), P(ga),
+        _lib.call('tamtr_msdeform_attn_bwd_sorted', P(gout), P(value), ctypes.cast(sh, ctypes.c_void_p), P(loc), P(aw), P(gv), P(gl), P(ga), None,
                   B, L, M, Dh, Q, 3, 4, M * Dh, _lib.BF16, _lib.stream_ptr())
         return gv, gl, ga
     a, b = sorted_bwd(), sorted_bwd()
@@ -416,7 +416,7 @@ def test_msdeform_backward_is_bit_reproducible_and_matches_the_atomic_kernel(pkg
     assert_close(a[0].float(), gv32, 2 ** -7, 2e-3 * scale, 'sorted vs atomic g_value (bf16 store)')
     assert float((a[0].float() != 0).float().mean()) < 0.6              # most rows are never sampled: written as zeros, not left unwritten
     stale = torch.full_like(value, float('nan'))
-    _lib.call('tamtr_msdeform_attn_bwd_sorted', P(gout), P(value), ctypes.cast(sh, ctypes.c_void_p), P(loc), P(aw), P(stale), P(gl2), P(ga2),
+    _lib.call('tamtr_msdeform_attn_bwd_sorted', P(gout), P(value), ctypes.cast(sh, ctypes.c_void_p), P(loc), P(aw), P(stale), P(gl2), P(ga2), None,
               B, L, M, Dh, Q, 3, 4, M * Dh, _lib.BF16, _lib.stream_ptr())
     assert torch.isfinite(stale.float()).all() and torch.equal(stale, a[0])   # every element written, whatever was there before
 

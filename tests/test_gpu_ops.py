@@ -1361,3 +1361,48 @@ def test_embed_rows_backward_is_the_index_backward(ops, rows, D, n):
     assert torch.equal(grads[0], grads[1])
     assert_close(grads[0], wa.grad, 1e-5, 1e-5 * float(wa.grad.abs().max()) + 1e-6, 'embed_rows grad')
     assert ops.embed_rows(w0, idx).grad_fn is None and torch.equal(ops.embed_rows(w0, idx), w0[idx])      # no gradient wanted: the plain index
+
+
+@pytest.mark.parametrize('B,Q,M,D,shapes,P', [(2, 37, 8, 64, [(12, 10), (6, 5), (3, 3)], 4), (1, 292, 8, 64, [(20, 20), (10, 10), (5, 5)], 4)])
+def test_value_proj_msda_pair_gives_the_bias_gradient_from_query_sized_operands(ops, B, Q, M, D, shapes, P):
+    """ops.value_proj_msda (MSDeformAttn.value_proj + the sampling core as one node, reference transformer.py:273-311): the same kernels as the two
+    separate nodes - output, d/dx, d/dW, d/dloc, d/daw bit-equal - and the bias gradient as sum_{b,q} gout * colw (ABI 34: the on-map weight of every
+    (image, query, head), emitted by tamtr_msdeform_attn_bwd_sorted) instead of a pass over d(value); colw against its definition computed in torch,
+    sampling locations reaching over the map's edges."""
+    import torch.nn as nn
+    torch.manual_seed(Q)
+    L, N, nl = sum(h * w for h, w in shapes), M * D, len(shapes)
+    lin = nn.Linear(N, N).cuda()
+    x0 = torch.randn(B, L, N, device='cuda').bfloat16()
+    loc0 = torch.rand(B, Q, M, nl, P, 2, device='cuda') * 1.3 - 0.15
+    aw0 = torch.softmax(torch.randn(B, Q, M, nl * P, device='cuda'), -1).view(B, Q, M, nl, P)
+    cot = torch.randn(B, Q, N, device='cuda').bfloat16()
+    assert ops.value_proj_msda_ok(x0, lin, M, Q, P)
+
+    def run(paired):
+        x, loc, aw = x0.clone().requires_grad_(), loc0.clone().requires_grad_(), aw0.clone().requires_grad_()
+        lin.weight.grad = lin.bias.grad = None
+        if paired:
+            out = ops.value_proj_msda(x, lin, M, shapes, loc, aw)
+        else:
+            out = ops.ms_deform_attn_core(ops.linear_bf16(x, lin.weight, lin.bias).view(B, L, M, D), shapes, loc, aw)
+        (out.float() * cot.float()).sum().backward()
+        return out.detach(), x.grad, lin.weight.grad.clone(), lin.bias.grad.clone(), loc.grad, aw.grad
+
+    a, b = run(False), run(True)
+    for name, u, v in zip(('out', 'dx', 'dW', 'dloc', 'daw'), (a[0], a[1], a[2], a[4], a[5]), (b[0], b[1], b[2], b[4], b[5])):
+        assert torch.equal(u, v), name
+    # colw by its definition, and the bias gradient from it
+    colw = torch.zeros(B, Q, M, device='cuda')
+    for l, (H, W) in enumerate(shapes):
+        x, y = loc0[..., l, :, 0] * W - 0.5, loc0[..., l, :, 1] * H - 0.5
+        xf, yf = x.floor(), y.floor()
+        fx, fy = x - xf, y - yf
+        sx = ((xf >= 0) & (xf < W)).float() * (1 - fx) + ((xf + 1 >= 0) & (xf + 1 < W)).float() * fx
+        sy = ((yf >= 0) & (yf < H)).float() * (1 - fy) + ((yf + 1 >= 0) & (yf + 1 < H)).float() * fy
+        colw += (aw0[..., l, :] * sx * sy).sum(-1)
+    assert float(colw.min()) < 0.999 and float(colw.max()) <= 1.0 + 1e-5          # some weight does fall off the map in this draw
+    want = (cot.view(B * Q, M, D).double() * colw.view(B * Q, M, 1).double()).sum(0).view(N)
+    scale = float(want.abs().max())
+    assert float((b[3].double() - want).abs().max()) <= 1e-5 * scale + 1e-6, 'db from colw'
+    assert float((a[3].double() - want).abs().max()) <= 2e-2 * scale, 'the column sums of the bf16 d(value) agree with it to bf16 rounding'
