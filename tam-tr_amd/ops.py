@@ -972,14 +972,14 @@ class _EncSelect(torch.autograd.Function):
         if invalid.numel():
             valid.index_fill_(0, invalid, False)   # (not `valid[invalid] = False`: assigning a Python scalar through an index synchronises the host)
         ctx.save_for_backward(top, x.view(B, L, K)[bi, top], y[bi, top], stats.view(B, L, 2)[bi, top], top_feat, valid[top], w16, ws16, g32)
-        ctx.cfg = (x.shape, w.dtype, b.dtype, gamma.dtype, beta.dtype, ws.dtype, bs.dtype, int(n_dec))
+        ctx.cfg = (x.shape, w.dtype, b.dtype, gamma.dtype, beta.dtype, ws.dtype, bs.dtype, fixed_top is None)
         ctx.mark_non_differentiable(top)
         return (top_feat, enc_scores, top) + tuple(x.view_as(x) for _ in range(int(n_dec)))
 
     @staticmethod
     def backward(ctx, g_feat, g_sc, _g_top, *g_dec):
         top, xr, yr, st, top_feat, vr, w16, ws16, g32 = ctx.saved_tensors
-        (B, L, K), w_dt, b_dt, ga_dt, be_dt, ws_dt, bs_dt, n_dec = ctx.cfg
+        (B, L, K), w_dt, b_dt, ga_dt, be_dt, ws_dt, bs_dt, distinct = ctx.cfg
         N, nc = w16.shape[0], ws16.shape[0]
         R = top.numel()
         gx = _sum_handles([g for g in g_dec if g is not None], (B, L, K), xr.dtype, xr.device)   # ours: the rows are added in place
@@ -999,7 +999,10 @@ class _EncSelect(torch.autograd.Function):
         gw, gb = gy.t() @ xm, gy.sum(0)
         gxr = ((gy @ w16.float()) * m).to(gx.dtype).view(B, -1, K)
         bi = torch.arange(B, device=top.device).unsqueeze(-1)
-        gx[bi, top] = gx[bi, top] + gxr                                          # top-k indices are distinct per image: plain gather / scatter
+        if distinct:
+            gx[bi, top] = gx[bi, top] + gxr                                      # top-k indices are distinct per image: plain gather / scatter
+        else:
+            gx.index_put_((bi, top), gxr, accumulate=True)                       # injected picks may repeat a row: the (sorted, ordered) accumulating form
         return (gx, gw.to(w_dt), gb.to(b_dt), ggam.to(ga_dt), gbet.to(be_dt), None, gws.to(ws_dt), gbs.to(bs_dt), None, None, None, None)
 
 

@@ -1274,8 +1274,9 @@ def test_conv3x3_cl_stats_vs_fp32_conv(ops, B, C, H, W, sliced):
     assert int(bn.num_batches_tracked) == 1
 
 
-@pytest.mark.parametrize('B,L,hd,nc,nq,n_dec', [(2, 340, 128, 10, 16, 3), (3, 1000, 512, 10, 50, 1), (1, 84, 256, 4, 8, 0)])
-def test_enc_select_row_sparse_backward_matches_the_dense_graph(ops, B, L, hd, nc, nq, n_dec):
+@pytest.mark.parametrize('B,L,hd,nc,nq,n_dec,dup', [(2, 340, 128, 10, 16, 3, False), (3, 1000, 512, 10, 50, 1, False), (1, 84, 256, 4, 8, 0, False),
+                                                    (2, 340, 128, 10, 16, 1, True)])
+def test_enc_select_row_sparse_backward_matches_the_dense_graph(ops, B, L, hd, nc, nq, n_dec, dup):
     """ops.enc_select (the MEH query selection as one autograd node whose backward runs on the picked rows only, reference head.py:1205-1245)
     against the same chain as separate ops (linear_bf16_zero_rows -> LayerNorm kernel -> score head -> top-k -> two gathers, ops.fanout for the
     decoder handles) and against a float64 autograd graph of the same bf16 operands: outputs bit-equal to the separate ops (same kernels), every
@@ -1305,12 +1306,15 @@ def test_enc_select_row_sparse_backward_matches_the_dense_graph(ops, B, L, hd, n
     mem = ops.layer_norm(ops.linear_bf16_zero_rows(f_enc, lin.weight, lin.bias, invalid), norm.weight, norm.bias, norm.eps)
     sc = F.linear(mem, head.weight.bfloat16(), head.bias.bfloat16())
     top = torch.topk(sc.max(-1).values, nq, dim=1).indices
+    if dup:                      # injected picks (fixed_topk) that name a row twice: its gradient is the sum of both uses
+        top = top.clone()
+        top[:, 1] = top[:, 0]
     fa, sa = mem[bi, top], sc[bi, top]
     ga = grads((fa.float() * cot_f).sum() + (sa.float() * cot_s).sum() + sum((h.float() * c.float()).sum() for h, c in zip(hs, cot_d)), xa)
     # (b) one node
     xb = x0.clone().requires_grad_()
     assert ops.enc_select_ok(xb, lin, norm, head)
-    fb, sb, tb, hb = ops.enc_select(xb, lin, norm, head, invalid, nq, None, n_dec)
+    fb, sb, tb, hb = ops.enc_select(xb, lin, norm, head, invalid, nq, top if dup else None, n_dec)
     assert torch.equal(tb, top) and torch.equal(fb, fa) and torch.equal(sb, sa) and len(hb) == n_dec and all(torch.equal(h, x0) for h in hb)
     assert not tb.requires_grad
     gb = grads((fb.float() * cot_f).sum() + (sb.float() * cot_s).sum() + sum((h.float() * c.float()).sum() for h, c in zip(hb, cot_d)), xb)
@@ -1334,7 +1338,7 @@ def test_enc_select_row_sparse_backward_matches_the_dense_graph(ops, B, L, hd, n
     # rows nobody picked get exactly the decoder handles' gradient; the invalid anchors' rows never get any from this branch
     want = sum(c.float() for c in cot_d) if cot_d else torch.zeros_like(x0, dtype=torch.float32)
     picked = torch.zeros(B, L, dtype=torch.bool, device='cuda')
-    picked[bi, top] = True
+    picked.index_put_((bi, top), torch.ones((), dtype=torch.bool, device='cuda'))
     assert torch.equal(gb[0][~picked], want.bfloat16().float()[~picked]) or n_dec > 1
     if n_dec <= 1:
         inv_picked = picked[:, invalid]
