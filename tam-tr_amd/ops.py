@@ -496,8 +496,8 @@ def value_proj_msda_ok(x, lin, n_heads, Q, P):
     """The paired node serves the bf16 token memory on the W-stationary GEMM's shapes with the sorted (atomics-free) backward
     (TAMTR_VALUE_BIAS=colsum: linear_bf16 + ms_deform_attn_core as separate nodes, the bias gradient as a pass over d(value))."""
     K, N = lin.in_features, lin.out_features
-    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3 and lin.bias is not None and N % n_heads == 0 and K % 128 == 0 and N % 64 == 0
-            and K % 64 == 0 and N % 128 == 0 and msda_sorted_ok(Q, P, N // n_heads) and not _MSDA_ATOMICS and _os.environ.get('TAMTR_VALUE_BIAS') != 'colsum')
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3 and lin.bias is not None and N % n_heads == 0 and K % 128 == 0 and N % 128 == 0
+            and msda_sorted_ok(Q, P, N // n_heads) and not _MSDA_ATOMICS and _os.environ.get('TAMTR_VALUE_BIAS') != 'colsum')
 
 
 def value_proj_msda(x, lin, n_heads, shapes, loc, aw):
